@@ -1,0 +1,193 @@
+/*
+ * dswin_hip.h - C ABI of libdswin_hip.so: hand-written gfx950 (MI355X) kernels for
+ * the deformable-sparse-window-attention / windowed-MSA hot path of
+ * jackwoodleigh/VisionTransformer.
+ *
+ * The reference is pure PyTorch and has no FFI of its own; each entry point below
+ * replaces the torch / torchvision call sequence cited next to it.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (nothing is allocated,
+ *     freed or retained by the library); `stream` is a hipStream_t passed as void*;
+ *   - every function only enqueues work on `stream` and returns at once, never
+ *     synchronises, keeps no mutable global state and may be called concurrently
+ *     from several host threads (forward thread and autograd worker threads);
+ *   - return value 0 = DSW_OK, otherwise a DSW_E* code; dswin_last_error_string()
+ *     gives the calling thread's last message;
+ *   - activations are DSW_F32 or DSW_BF16 as stated per argument; integer tensors
+ *     are int32; images are NHWC ([B,H,W,C], C fastest) unless stated.
+ */
+#ifndef DSWIN_HIP_H
+#define DSWIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DSW_F32 = 0, DSW_BF16 = 1 };
+
+enum {
+    DSW_OK = 0,
+    DSW_EINVAL = 1,      /* bad shape / null pointer / inconsistent arguments      */
+    DSW_EUNSUPPORTED = 2, /* window size, head dim or dtype outside the built range */
+    DSW_ELAUNCH = 3      /* hipGetLastError() after a launch was not hipSuccess     */
+};
+
+/* qkv channel layouts of the packed [.., 3C] projection */
+enum {
+    DSW_QKV_CHUNKED = 0,     /* q|k|v thirds, each split in heads: DSwinT_arch.py:303-304, msft_arch.py:129 */
+    DSW_QKV_INTERLEAVED = 1  /* head h owns [h*3d,(h+1)*3d) = q|k|v:  DSwinT_arch.py:335                   */
+};
+
+int dswin_version(void);
+const char *dswin_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (1) Window selection: softmax / Gumbel-softmax over the windows of each image, top-k,
+ *     straight-through value, hard gate, compaction, window-corner arithmetic.
+ *     Replaces DSwinT_arch.py:201-225 (candidate_indexes), :280-289 (gate STE + boolean-mask
+ *     compaction, which costs the reference two device->host syncs) and :227-237 (cords).
+ *
+ * sd    [B,4,Hw,Ww] sparse-discriminator output (channel 0 = scores), dtype sd_dtype
+ * sig   [B,3,Hw,Ww] sigmoid of channels 1..3 as torch computed it (gate, offset_h, offset_w),
+ *       same dtype; the comparisons and the offset arithmetic are done in that dtype with one
+ *       rounding per op, like the reference
+ * noise [B,Hw*Ww] fp32 Gumbel noise -log(Exp(1)) (training) or NULL (eval: softmax(s/tau))
+ * k     windows kept per image = int(Hw*Ww*num_win_selected), 1 <= k <= Hw*Ww
+ * outputs: probs [B,Hw*Ww] fp32; cand_idx [B,k] flat window index by descending probability
+ *   (equal logits: lower index first), cand_p [B,k] fp32 its probability; cand_pass [B,k] 0/1 =
+ *   gate > 0.5;
+ *   n_pass [1]; win_b / win_cell / win_h1 / win_w1 [B*k] for the passing windows in the
+ *   reference's order (image ascending, then top-k rank), entries >= n_pass untouched;
+ *   scores_delta / gates_delta [B*k] fp32 straight-through values ((1-p)+p and (1-g)+g);
+ *   cellmap [B,Hw,Ww] = compact window id of the window that started from that cell, or -1.
+ */
+int dsw_select_fwd(const void *sd, const void *sig, int sd_dtype, const float *noise, float tau,
+                   int B, int Hw, int Ww, int k, int w, int H, int W,
+                   float *probs, int *cand_idx, float *cand_p, int *cand_pass, int *n_pass,
+                   int *win_b, int *win_cell, int *win_h1, int *win_w1,
+                   float *scores_delta, float *gates_delta, int *cellmap, void *stream);
+
+/* Backward of (1): the straight-through gradients.  d_scores_delta / d_gates_delta [n_win]
+ * fp32 are the incoming gradients of the two straight-through values; d_scores [B,Hw*Ww] fp32
+ * receives the softmax-Jacobian product (probs*(dp - sum(probs*dp)))/tau, d_gate [B,Hw*Ww]
+ * fp32 the gradient of sig channel 0 (zero for windows that did not pass).  The offsets get no
+ * gradient, as in the reference (.long() at DSwinT_arch.py:232-233).  n_win is read on the
+ * host side by the caller (it sizes the saved tensors). */
+int dsw_select_bwd(const float *probs, const float *d_scores_delta, const float *d_gates_delta,
+                   const int *win_b, const int *win_cell, int n_win, float tau,
+                   int B, int Hw, int Ww, float *d_scores, float *d_gate, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) Bilinear window gather.  Replaces the NHWC->NCHW copy (DSwinT_arch.py:259),
+ *     torchvision.ops.roi_align(x, rois, (w,w)) (:297) and the NCHW->NHWC copy (:303):
+ *     out[n, i*w+j, :] = 2x2 box mean of x[b] at (h1+i, w1+j) with torchvision's border rule
+ *     (last row / column: 2x1 mean, corner: the pixel).
+ * x [B,H,W,C] x_dtype -> out [n_win, w*w, C] out_dtype.
+ */
+int dsw_gather_fwd(const void *x, int x_dtype, const int *win_b, const int *win_h1,
+                   const int *win_w1, int n_win, int B, int H, int W, int C, int w,
+                   void *out, int out_dtype, void *stream);
+
+/* Backward of (2), atomic-free and bitwise reproducible: every pixel gathers from the <= 4
+ * windows that cover each of its <= 4 sample positions (torchvision's roi_align backward
+ * scatters with atomicAdd).  dout [n_win, w*w, C] -> dx [B,H,W,C] (every element written). */
+int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellmap, const int *win_h1,
+                   const int *win_w1, int n_win, int B, int H, int W, int C, int w,
+                   void *dx, int dx_dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (4) Gated delta, mean of overlapping windows, residual add.  Replaces DSwinT_arch.py:308-315:
+ *     delta = after - roi_align(x); gated = delta * gates_delta * scores_delta;
+ *     y = x + scatter_reduce(mean) of gated at integer pixels (uncovered pixels: y = x).
+ *     Pixel-centric, no atomics: a pixel is covered by at most 4 windows (2 per axis), found
+ *     through cellmap; they are summed in ascending window id, then divided by their count.
+ * x [B,H,W,C]; after [n_win, w*w, C] (token-major, as out_proj leaves it) -> y [B,H,W,C].
+ */
+int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int after_dtype,
+                         const float *gates_delta, const float *scores_delta,
+                         const int *cellmap, const int *win_h1, const int *win_w1, int n_win,
+                         int B, int H, int W, int C, int w, void *y, int y_dtype, void *stream);
+
+/* Backward of (4).  dy [B,H,W,C] -> dx [B,H,W,C] (identity path + the -roi_align path),
+ * d_after [n_win, w*w, C], d_gates_delta / d_scores_delta [n_win] fp32.
+ * partial: caller-provided scratch of 2*n_win*w floats (per window-row partial sums, reduced
+ * in a fixed order). */
+int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype,
+                         const void *after, int after_dtype, const float *gates_delta,
+                         const float *scores_delta, const int *cellmap, const int *win_b,
+                         const int *win_h1, const int *win_w1, int n_win,
+                         int B, int H, int W, int C, int w,
+                         void *dx, int dx_dtype, void *d_after, int d_after_dtype,
+                         float *d_gates_delta, float *d_scores_delta, float *partial, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (3)+(5) Fused window attention on MFMA: softmax(q k^T * scale + bias) v per (window, head),
+ *     with window partition / headify / chunk / deheadify / reverse done as address arithmetic.
+ *     Replaces DSwinT_arch.py:135-172 + :122-125 (bias expansion) as used at :303-308 and
+ *     :333-337, and msft_arch.py:94-125 + :136 (SDPA + LePE) as used at :129-139.
+ *
+ * qkv    [rows, 3C]; rows = n_img*H*W tokens.  grid mode (H,W > 0): the tokens of image b are
+ *        its H*W pixels row-major and windows are cut out by address arithmetic; packed mode
+ *        (H = W = 0): n_img counts windows and each window's w*w tokens are contiguous.
+ * bias_table [(2w-1)^2, heads] fp32 relative-position table or NULL (msft: no bias).
+ * lepe_w [C,9] / lepe_b [C] fp32 depthwise 3x3 (zero padded at the window edge) applied to V
+ *        and added to the output (msft_arch.py:113-125, :136), or NULL.
+ * out    [rows, C] same token order as qkv, dtype = qkv dtype.
+ * lse    [n_windows, heads, w*w] fp32 log-sum-exp of every softmax row (saved for backward).
+ * Supported: w in {8,16}; head dim C/heads <= 64; dtype f32 (exact f32 MFMA) or bf16.
+ */
+int dsw_win_attn_fwd(const void *qkv, int dtype, int layout, int n_img, int H, int W, int w,
+                     int C, int heads, const float *bias_table, float scale,
+                     const float *lepe_w, const float *lepe_b, void *out, float *lse,
+                     void *stream);
+
+/* bytes of scratch dsw_win_attn_bwd needs (per-(window,head) partial bias-table and LePE
+ * weight gradients, reduced in a fixed order by a second kernel inside the call). */
+size_t dsw_win_attn_bwd_workspace(int n_img, int H, int W, int w, int C, int heads,
+                                  int has_bias, int has_lepe);
+
+/* Backward of (3).  dout [rows, C] -> dqkv [rows, 3C] (same layout as qkv), d_bias_table
+ * [(2w-1)^2, heads] fp32 (NULL if no bias), d_lepe_w [C,9] / d_lepe_b [C] fp32 (NULL if no
+ * LePE).  `out` is the forward result WITHOUT the LePE term when LePE is used it is not
+ * needed: pass the forward output as it was returned. */
+int dsw_win_attn_bwd(const void *qkv, const void *out, const void *dout, int dtype, int layout,
+                     int n_img, int H, int W, int w, int C, int heads, const float *bias_table,
+                     float scale, const float *lepe_w, const float *lepe_b, const float *lse,
+                     void *dqkv, float *d_bias_table, float *d_lepe_w, float *d_lepe_b,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (5) MSFT multi-scale reshapes, one pass each, no intermediate copies.
+ *
+ * dsw_unshuffle_nhwc_ln_fwd: PixelUnshuffle(s) + NCHW->NHWC copy + LayerNorm
+ *   (msft_arch.py:45-50; with s = 1 also the NCHW->token copy + LayerNorm of
+ *   msft_arch.py:68-70 and :160-162).  x [B,c,H,W] x_dtype -> y [B,H/s,W/s,c*s*s] y_dtype,
+ *   normalised over the last dim with gamma/beta (fp32) and eps; mean / rstd
+ *   [B*(H/s)*(W/s)] fp32 are saved for the backward.
+ * dsw_unshuffle_nhwc_fwd: the same reshape without the LayerNorm.
+ * dsw_shuffle_nchw_fwd: NHWC->NCHW copy + PixelShuffle(s) (msft_arch.py:54, :74-76, :166):
+ *   t [B,H,W,C] -> y [B,C/(s*s),H*s,W*s].
+ * The two reshapes are each other's adjoint, so the backward of one is the forward of the
+ * other; dsw_unshuffle_nhwc_ln_bwd adds the LayerNorm backward: dy [B,H/s,W/s,c*s*s] and the
+ * forward input x -> dx [B,c,H,W], d_gamma / d_beta [c*s*s] fp32.  partial: caller scratch of
+ * dsw_unshuffle_blocks(B,H,W,s) * 2 * c*s*s floats (per-block sums, reduced in a fixed order).
+ */
+int dsw_unshuffle_nhwc_ln_fwd(const void *x, int x_dtype, int B, int c, int H, int W, int s,
+                              const float *gamma, const float *beta, float eps, void *y,
+                              int y_dtype, float *mean, float *rstd, void *stream);
+int dsw_unshuffle_nhwc_ln_bwd(const void *dy, const void *x, int dtype, int B, int c, int H,
+                              int W, int s, const float *gamma, const float *mean,
+                              const float *rstd, void *dx, float *d_gamma, float *d_beta,
+                              float *partial, void *stream);
+int dsw_unshuffle_blocks(int B, int H, int W, int s);
+int dsw_shuffle_nchw_fwd(const void *t, int dtype, int B, int H, int W, int C, int s, void *y,
+                         void *stream);
+int dsw_unshuffle_nhwc_fwd(const void *x, int dtype, int B, int c, int H, int W, int s, void *y,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSWIN_HIP_H */

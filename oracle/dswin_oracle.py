@@ -188,10 +188,12 @@ def candidate_indexes(scores, num_win_selected, temperature, training, noise=Non
     B, _, Hw, Ww = scores.shape
     k = int((Hw * Ww) * num_win_selected)
     flat = scores.view(B, -1)
+    # softmax is on CUDA autocast's fp32 list, so under the trainer's autocast it runs in
+    # fp32 whatever the activation dtype; with fp32 inputs the casts below change nothing.
     if training:
-        probs = ((flat + noise) / temperature).softmax(dim=-1)    # gumbel_softmax, hard=False
+        probs = ((flat + noise) / temperature).float().softmax(dim=-1)    # gumbel_softmax, hard=False
     else:
-        probs = F.softmax(flat / temperature, dim=-1)
+        probs = F.softmax((flat / temperature).float(), dim=-1)
     top_p, top_i = torch.topk(probs, k, dim=1)
     scores_delta = (torch.ones_like(top_p) - top_p).detach() + top_p
     b_idx = torch.arange(B).view(-1, 1).expand(-1, k).reshape(-1)

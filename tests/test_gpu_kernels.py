@@ -1,0 +1,261 @@
+"""GPU parity tests, kernel by kernel: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Bars: integer decisions (selected windows, gate decisions, corners)
+bit-exact; values and gradients within 1e-3 relative error for fp32 and 2e-2 for bf16
+(relative error = ||a-b|| / ||b||)."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import dswin_oracle as D
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+
+
+def _K():
+    from visiontransformer_amd import functional as K
+    return K
+
+
+def _selection_from(b_idx, h1, w1, cell, B, Hw, Ww, gd, sdl, dev):
+    """build the kernels' window tables from explicit CPU lists"""
+    K = _K()
+    n = b_idx.numel()
+    cellmap = torch.full((B, Hw * Ww), -1, dtype=torch.int32)
+    cellmap[b_idx.long(), cell.long()] = torch.arange(n, dtype=torch.int32)
+    i32 = lambda t: t.to(torch.int32).to(dev).contiguous()
+    return K.Selection(n=n, win_b=i32(b_idx), win_cell=i32(cell), win_h1=i32(h1), win_w1=i32(w1),
+                       cellmap=cellmap.view(B, Hw, Ww).to(dev), scores_delta=sdl, gates_delta=gd,
+                       cand_idx=None, cand_pass=None, probs=None)
+
+
+def _random_windows(gen, B, Hw, Ww, w, frac):
+    """random passing windows: distinct cells, corners shifted by up to w/2 and clamped"""
+    H, W = Hw * w, Ww * w
+    bs, cells, h1s, w1s = [], [], [], []
+    for b in range(B):
+        n = max(1, int(Hw * Ww * frac))
+        perm = torch.randperm(Hw * Ww, generator=gen)[:n]
+        for c in perm.tolist():
+            r, cc = divmod(c, Ww)
+            oh = int(torch.randint(-(w // 2), w // 2 + 1, (1,), generator=gen))
+            ow = int(torch.randint(-(w // 2), w // 2 + 1, (1,), generator=gen))
+            bs.append(b)
+            cells.append(c)
+            h1s.append(min(max(r * w + oh, 0), H - w))
+            w1s.append(min(max(cc * w + ow, 0), W - w))
+    t = lambda v: torch.tensor(v, dtype=torch.int64)
+    return t(bs), t(cells), t(h1s), t(w1s)
+
+
+# ----------------------------------------------------------------------------------------------
+# (1) selection
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("B,Hw,Ww,w,frac,tau", [(2, 4, 4, 16, 0.25, 1.0), (3, 4, 6, 8, 0.5, 0.7),
+                                                (1, 34, 60, 16, 0.25, 1.0), (2, 8, 8, 8, 1.0, 0.3)])
+def test_select(cuda0, dtype, training, B, Hw, Ww, w, frac, tau):
+    K = _K()
+    gen = torch.Generator().manual_seed(Hw * 100 + Ww + int(training))
+    n = Hw * Ww
+    sd = (torch.randn(B, 4, Hw, Ww, generator=gen) * 2.0).to(dtype)
+    sig = sd[:, 1:].sigmoid()
+    noise = D.gumbel_noise((B, n), gen) if training else None
+    k = int(n * frac)
+    ref = D.select_windows(sd.clone().requires_grad_(), sig.clone().requires_grad_(), w, Hw * w, Ww * w, frac, tau,
+                           training, noise)
+    sd_g = sd.to(cuda0).requires_grad_()
+    sig_g = sig.to(cuda0).requires_grad_()
+    sel = K.select_windows(sd_g, sig_g, None if noise is None else noise.to(cuda0), tau, k, w, Hw * w, Ww * w)
+    # bit-exact integer decisions.  torch.topk leaves the order of EQUAL probabilities unspecified
+    # (bf16 scores over thousands of windows do collide), so with ties among the selected values
+    # only the selected probabilities can be compared rank by rank; without ties the indices,
+    # gate decisions, compaction order and corners must all be identical.
+    cand = sel.cand_idx.cpu().long()
+    ref_flat = ref["cand_h"] * Ww + ref["cand_w"]
+    pr = ref["probs"].detach()
+    assert torch.equal(pr.gather(1, cand).reshape(-1), pr.gather(1, ref_flat.view(B, k)).reshape(-1))
+    top = torch.topk(pr, min(k + 1, n), dim=1).values
+    has_ties = bool((top[:, 1:] == top[:, :-1]).any())
+    assert rel_err(sel.probs, ref["probs"]) < 1e-5
+    if has_ties:
+        assert dtype == torch.bfloat16, "fp32 test inputs are not expected to tie"
+        return
+    assert torch.equal(cand.reshape(-1), ref_flat)
+    assert torch.equal(sel.cand_pass.cpu().bool().reshape(-1), ref["pass_mask"])
+    assert sel.n == ref["b_idx"].numel()
+    assert torch.equal(sel.win_b.cpu().long(), ref["b_idx"])
+    assert torch.equal(sel.win_cell.cpu().long(), ref["h_idx"] * Ww + ref["w_idx"])
+    assert torch.equal(sel.win_h1.cpu().long(), ref["h1"])
+    assert torch.equal(sel.win_w1.cpu().long(), ref["w1"])
+    # cellmap is the inverse of (win_b, win_cell)
+    cm = torch.full((B, n), -1, dtype=torch.int32)
+    cm[ref["b_idx"], ref["h_idx"] * Ww + ref["w_idx"]] = torch.arange(sel.n, dtype=torch.int32)
+    assert torch.equal(sel.cellmap.cpu().view(B, n), cm)
+    assert rel_err(sel.probs, ref["probs"]) < 1e-5
+    assert rel_err(sel.scores_delta, ref["scores_delta"]) < 1e-6
+    assert rel_err(sel.gates_delta, ref["gates_delta"]) < 1e-6
+    if sel.n == 0:
+        return
+    # straight-through gradients
+    r1 = torch.randn(sel.n, generator=gen)
+    r2 = torch.randn(sel.n, generator=gen)
+    sd_c = sd.clone().requires_grad_()
+    sig_c = sig.clone().requires_grad_()
+    ref2 = D.select_windows(sd_c, sig_c, w, Hw * w, Ww * w, frac, tau, training, noise)
+    ((ref2["scores_delta"] * r1).sum() + (ref2["gates_delta"] * r2).sum()).backward()
+    ((sel.scores_delta * r1.to(cuda0)).sum() + (sel.gates_delta * r2.to(cuda0)).sum()).backward()
+    tol = TOL[dtype]
+    assert rel_err(sd_g.grad, sd_c.grad) < tol
+    assert rel_err(sig_g.grad, sig_c.grad) < tol
+    assert torch.count_nonzero(sig_g.grad[:, 1:]) == 0  # offsets: no gradient, as in the reference
+
+
+def test_select_tie_rule(cuda0):
+    """equal logits: the lower window index ranks first (torch.topk leaves ties unspecified,
+    so exact ties are outside the bit-exact contract; this pins the kernel's own rule)."""
+    K = _K()
+    sd = torch.zeros(1, 4, 2, 4)
+    sd[0, 0] = torch.tensor([[1.0, 3.0, 3.0, 0.0], [3.0, -1.0, 1.0, 1.0]])
+    sd[0, 1] = 5.0
+    sig = sd[:, 1:].sigmoid()
+    sel = K.select_windows(sd.to(cuda0), sig.to(cuda0), None, 1.0, 5, 8, 16, 32)
+    assert sel.cand_idx.cpu().view(-1).tolist() == [1, 2, 4, 0, 6]
+
+
+# ----------------------------------------------------------------------------------------------
+# (2) gather and (4) scatter-mean
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Hw,Ww,w,C,frac", [(2, 3, 4, 8, 12, 0.5), (1, 4, 4, 16, 180, 1.0), (2, 2, 5, 16, 24, 1.0)])
+def test_gather_fwd_bwd(cuda0, dtype, B, Hw, Ww, w, C, frac):
+    K = _K()
+    gen = torch.Generator().manual_seed(7 + C)
+    H, W = Hw * w, Ww * w
+    b_idx, cell, h1, w1 = _random_windows(gen, B, Hw, Ww, w, frac)
+    n = b_idx.numel()
+    x = torch.randn(B, H, W, C, generator=gen)
+    r = torch.randn(n, w * w, C, generator=gen)
+    xc = x.clone().requires_grad_()
+    ref = D.gather_windows(xc.permute(0, 3, 1, 2).contiguous(), b_idx, h1, w1, w).permute(0, 2, 3, 1).reshape(n, w * w, C)
+    (ref * r).sum().backward()
+    sel = _selection_from(b_idx, h1, w1, cell, B, Hw, Ww, None, None, cuda0)
+    xg = x.to(cuda0).to(dtype).requires_grad_()
+    out = K.gather_windows(xg, sel, w)
+    (out.float() * r.to(cuda0)).sum().backward()
+    tol = TOL[dtype]
+    assert rel_err(out, ref) < tol
+    assert rel_err(xg.grad, xc.grad) < tol
+    if dtype == torch.float32:
+        assert (out.cpu() - ref).abs().max() < 1e-5
+    # fp32 input, bf16 output (the autocast case): one rounding of the fp32 result
+    if dtype == torch.float32:
+        out16 = K.gather_windows(x.to(cuda0), sel, w, out_dtype=torch.bfloat16)
+        assert torch.equal(out16.cpu(), out.detach().cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("after_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Hw,Ww,w,C,frac", [(2, 3, 4, 8, 12, 0.5), (1, 4, 4, 16, 180, 1.0), (2, 2, 5, 16, 24, 1.0),
+                                              (1, 1, 1, 8, 8, 1.0)])
+def test_scatter_fwd_bwd(cuda0, after_dtype, B, Hw, Ww, w, C, frac):
+    K = _K()
+    gen = torch.Generator().manual_seed(11 + C)
+    H, W = Hw * w, Ww * w
+    b_idx, cell, h1, w1 = _random_windows(gen, B, Hw, Ww, w, frac)
+    n = b_idx.numel()
+    x = torch.randn(B, H, W, C, generator=gen)
+    after = torch.randn(n, w * w, C, generator=gen).to(after_dtype)
+    gd = torch.rand(n, generator=gen) + 0.5
+    sdl = torch.rand(n, generator=gen) + 0.5
+    r = torch.randn(B, H, W, C, generator=gen)
+    leaves = [t.clone().float().requires_grad_() for t in (x, after, gd, sdl)]
+    ref = D.scatter_mean_residual(leaves[0], leaves[1], leaves[2], leaves[3], b_idx, h1, w1, w)
+    (ref * r).sum().backward()
+    gl = [t.to(cuda0).requires_grad_() for t in (x, after, gd, sdl)]
+    sel = _selection_from(b_idx, h1, w1, cell, B, Hw, Ww, gl[2], gl[3], cuda0)
+    y = K.scatter_mean_residual(gl[0], gl[1], sel, w)
+    (y * r.to(cuda0)).sum().backward()
+    tol = TOL[after_dtype]
+    assert rel_err(y, ref) < (1e-6 if after_dtype == torch.float32 else tol)
+    for got, want, name in zip(gl, leaves, ("x", "after", "gates", "scores")):
+        assert rel_err(got.grad, want.grad) < tol, name
+    # atomic-free => bitwise reproducible
+    y2 = K.scatter_mean_residual(gl[0].detach(), gl[1].detach(), sel, w)
+    assert torch.equal(y2, y.detach())
+
+
+# ----------------------------------------------------------------------------------------------
+# (3) fused window attention
+# ----------------------------------------------------------------------------------------------
+ATTN_CASES = [
+    # w, C, heads, layout, grid (B,H,W) or number of packed windows
+    (16, 180, 6, "interleaved", (1, 32, 48)),
+    (16, 180, 6, "chunked", 5),
+    (8, 180, 6, "interleaved", (2, 16, 24)),
+    (8, 24, 2, "chunked", 3),
+    (16, 48, 3, "chunked", 2),      # head dim 16
+    (8, 108, 2, "chunked", (1, 16, 8)),  # head dim 54 -> padded to 64
+    (16, 21, 3, "interleaved", 2),  # odd head dim 7
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bias", [True, False])
+@pytest.mark.parametrize("w,C,heads,layout,grid", ATTN_CASES)
+def test_window_attention(cuda0, dtype, bias, w, C, heads, layout, grid):
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
+    gen = torch.Generator().manual_seed(C + w)
+    L = w * w
+    shape = (grid[0], grid[1], grid[2], 3 * C) if isinstance(grid, tuple) else (grid, L, 3 * C)
+    qkv = torch.randn(shape, generator=gen).to(dtype)
+    table = (torch.randn((2 * w - 1) ** 2, heads, generator=gen) * 0.5) if bias else None
+    r = torch.randn(shape[:-1] + (C,), generator=gen)
+    q_ref = qkv.float().clone().requires_grad_()
+    t_ref = None if table is None else table.clone().requires_grad_()
+    ref = D.window_attention_core(q_ref, t_ref, w, heads, layout, grid=grid if isinstance(grid, tuple) else None)
+    ref = ref.reshape(r.shape)
+    (ref * r).sum().backward()
+    q_g = qkv.to(cuda0).requires_grad_()
+    t_g = None if table is None else table.to(cuda0).requires_grad_()
+    out = K.window_attention(q_g, t_g, w, heads, QKV_CHUNKED if layout == "chunked" else QKV_INTERLEAVED,
+                             grid=grid if isinstance(grid, tuple) else None)
+    assert out.dtype == dtype and out.shape == r.shape
+    (out.float() * r.to(cuda0)).sum().backward()
+    tol = TOL[dtype]
+    assert rel_err(out, ref) < tol
+    assert rel_err(q_g.grad, q_ref.grad) < tol
+    if bias:
+        assert rel_err(t_g.grad, t_ref.grad) < tol
+    # bitwise reproducible backward (no unordered float atomics)
+    q2 = qkv.to(cuda0).requires_grad_()
+    t2 = None if table is None else table.to(cuda0).requires_grad_()
+    out2 = K.window_attention(q2, t2, w, heads, QKV_CHUNKED if layout == "chunked" else QKV_INTERLEAVED,
+                              grid=grid if isinstance(grid, tuple) else None)
+    (out2.float() * r.to(cuda0)).sum().backward()
+    assert torch.equal(out2, out) and torch.equal(q2.grad, q_g.grad)
+    if bias:
+        assert torch.equal(t2.grad, t_g.grad)
+
+
+def test_window_attention_large_logits(cuda0):
+    """softmax stability: logits of a few hundred must not overflow (row max is subtracted)."""
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED
+    gen = torch.Generator().manual_seed(5)
+    qkv = torch.randn(2, 64, 3 * 32, generator=gen) * 12.0
+    ref = D.window_attention_core(qkv, None, 8, 2, "chunked")
+    out = K.window_attention(qkv.to(cuda0), None, 8, 2, QKV_CHUNKED)
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 1e-3
+
+
+def test_unsupported_arguments_fail_loudly(cuda0):
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED
+    with pytest.raises(RuntimeError, match="window size"):
+        K.window_attention(torch.zeros(1, 16, 3 * 8, device=cuda0), None, 4, 2, QKV_CHUNKED)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        K.window_attention(torch.zeros(1, 64, 3 * 8), None, 8, 2, QKV_CHUNKED)

@@ -1,0 +1,96 @@
+"""GPU parity tests at module level: the drop-in modules (same constructors, forward signatures
+and state_dict keys as the reference) against the golden vectors the reference produced.
+Window indices / gate decisions bit-exact, values and gradients within 1e-3 (fp32)."""
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, params_of, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _load_into(mod, g, dev):
+    sd = params_of(g)
+    missing, unexpected = mod.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return mod.to(dev)
+
+
+def _check_grads(mod, g, x, y, dev):
+    (y * g["r"].to(dev)).sum().backward()
+    assert rel_err(x.grad, g["dx"]) < TOL
+    for n, p in mod.named_parameters():
+        ref = g["grad." + n]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        if ref.abs().max() == 0:
+            assert got.abs().max() == 0, n
+        else:
+            assert rel_err(got, ref) < TOL, n
+
+
+@pytest.mark.parametrize("name", golden_names("dswt_wmsa"))
+def test_dswt_wmsa_golden(cuda0, name):
+    from visiontransformer_amd.dswin import WindowedMSA
+    g, m = load_golden(name)
+    mod = _load_into(WindowedMSA(m["w"], m["C"], m["heads"]), g, cuda0)
+    x = g["x"].to(cuda0).requires_grad_()
+    y = mod(x)
+    assert rel_err(y, g["y"]) < TOL
+    _check_grads(mod, g, x, y, cuda0)
+
+
+@pytest.mark.parametrize("name", golden_names("dswt_dsmsa"))
+def test_dswt_dsmsa_golden(cuda0, name):
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    g, m = load_golden(name)
+    mod = _load_into(DeformableSparseWindowAttention(m["w"], m["C"], m["heads"]), g, cuda0)
+    mod.num_win_selected = m["num_win_selected"]
+    mod.temperature = m["temperature"]
+    mod.train(m["training"])
+    mod.gumbel_noise = g["noise"].to(cuda0)
+    x = g["x"].to(cuda0).requires_grad_()
+    y = mod(x)
+    sel = mod.last_selection
+    if m["n_candidates"] == 0:
+        assert sel is None
+    else:
+        Ww = m["W"] // m["w"]
+        cand = sel.cand_idx.cpu().long().reshape(-1)
+        assert torch.equal(cand // Ww, g["aux.cand_h"])
+        assert torch.equal(cand % Ww, g["aux.cand_w"])
+        assert sel.n == m["n_pass"]
+        if sel.n:
+            assert torch.equal(sel.win_b.cpu().long(), g["aux.b_idx"])
+            assert torch.equal(sel.win_cell.cpu().long(), g["aux.h_idx"] * Ww + g["aux.w_idx"])
+            assert torch.equal(sel.win_h1.cpu().long(), g["aux.h1"])
+            assert torch.equal(sel.win_w1.cpu().long(), g["aux.w1"])
+    assert rel_err(y, g["y"]) < TOL
+    _check_grads(mod, g, x, y, cuda0)
+
+
+def test_dsmsa_bf16_autocast_against_fp32(cuda0):
+    """the trainer's mode: bf16 autocast.  Same module, same weights: selection must be a valid
+    selection (k candidates per image, distinct cells) and values within 2e-2 of the fp32 run
+    whenever both runs picked the same windows."""
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    torch.manual_seed(0)
+    mod = DeformableSparseWindowAttention(16, 180, 6).to(cuda0)
+    with torch.no_grad():
+        mod.sparse_discriminator[4].weight.mul_(8.0)
+        mod.sparse_discriminator[4].bias[1] += 1.0
+        mod.pe.relative_position_bias_table.normal_(0, 0.5)
+    mod.train()
+    x = torch.randn(4, 64, 64, 180, device=cuda0)
+    mod.gumbel_noise = -torch.empty(4, 16, device=cuda0).exponential_().log()
+    y32 = mod(x)
+    s32 = mod.last_selection
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y16 = mod(x)
+    s16 = mod.last_selection
+    assert s16.cand_idx.shape == (4, 4)
+    assert all(len(set(r.tolist())) == 4 for r in s16.cand_idx.cpu())
+    assert y16.dtype == torch.bfloat16
+    if s32.n == s16.n and torch.equal(s32.win_cell, s16.win_cell) and torch.equal(s32.win_h1, s16.win_h1) \
+            and torch.equal(s32.win_w1, s16.win_w1):
+        assert rel_err(y16, y32) < 2e-2

@@ -1,0 +1,104 @@
+"""ctypes binding of libdswin_hip.so (the C ABI declared in include/dswin_hip.h).
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdswin_hip.so")
+
+DSW_F32, DSW_BF16 = 0, 1
+QKV_CHUNKED, QKV_INTERLEAVED = 0, 1
+
+_lib = None
+_lock = threading.Lock()
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/dswin_hip.h declares
+SIGNATURES = {
+    "dswin_version": (_I, []),
+    "dswin_last_error_string": (ctypes.c_char_p, []),
+    "dsw_select_fwd": (_I, [_P, _P, _I, _P, _F] + [_I] * 7 + [_P] * 12 + [_P]),
+    "dsw_select_bwd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
+    "dsw_gather_fwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _P]),
+    "dsw_gather_bwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _P]),
+    "dsw_scatter_mean_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 6 + [_P, _I, _P]),
+    "dsw_scatter_mean_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 6 +
+                             [_P, _I, _P, _I, _P, _P, _P, _P]),
+    "dsw_win_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
+    "dsw_win_attn_bwd_workspace": (_Z, [_I] * 8),
+    "dsw_win_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P,
+                              _P, _P, _P, _P, _P, _Z, _P]),
+    "dsw_unshuffle_nhwc_ln_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
+    "dsw_unshuffle_blocks": (_I, [_I, _I, _I, _I]),
+    "dsw_unshuffle_nhwc_ln_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dsw_shuffle_nchw_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dsw_unshuffle_nhwc_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+}
+
+
+def load():
+    """dlopen the library once and attach the signatures; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "visiontransformer_amd: %s is missing - build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return DSW_F32
+    if t == torch.bfloat16:
+        return DSW_BF16
+    raise RuntimeError("visiontransformer_amd: unsupported dtype %s (float32 and bfloat16 are built)" % t)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL); the tensor must be contiguous"""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise RuntimeError("visiontransformer_amd: non-contiguous tensor passed to the C ABI")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def call(name, *args):
+    """invoke an int-returning entry point and turn a nonzero status into RuntimeError"""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.dswin_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (code %d): %s" % (name, rc, msg))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "visiontransformer_amd kernels run on the GPU only (got a %s tensor); "
+                "there is no CPU path" % t.device)

@@ -1,0 +1,488 @@
+// Fused window attention, backward: dq, dk, dv, d(bias table) (+ LePE gradients) for one
+// (window, head) per workgroup, on the gfx950 matrix cores.
+// Reference ops differentiated: DSwinT_arch.py:122-125, :171-172; msft_arch.py:113-136.
+//
+// Structure.  Each wave owns 32-key tiles of the window and keeps dK^T and dV^T of those keys
+// in accumulators for the whole sweep, with its K and V fragments in registers.  The workgroup
+// walks the window's 32-query blocks; a block's Q and dO rows are staged in LDS (row-major, and
+// transposed for the bf16 operand reads).  With the KEY on the MFMA lane, S = Q K^T and
+// dP = dO V^T come out as (query = row = register, key = column = lane), which is already the
+// B operand of dV^T += dO^T P and dK^T += Q^T dS (they sum over the accumulator's row index).
+// Only dS crosses LDS, once per block, for dQ = dS K (16x16 output tiles, one per wave, summed
+// over all keys - no cross-wave reduction).  P is recomputed from the forward's log-sum-exp;
+// delta = rowsum(dO * O) comes from the saved output.  The bias-table gradient is accumulated
+// with LDS float adds into one private table per wave (program order inside a wave => bitwise
+// reproducible), summed in wave order and written as a per-(window, head) partial that a second
+// kernel reduces over windows in a fixed order.
+#include "attn_common.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace dsw {
+
+template <typename T, int WS, int DP> struct BwdCfg {
+    static constexpr bool BF = sizeof(T) == 2;
+    static constexpr int L = WS * WS;
+    static constexpr int NT = L / 32;                 // key tiles = query blocks
+    static constexpr int NW = NT < 4 ? NT : 4;        // waves
+    static constexpr int KT = NT / NW;                // key tiles per wave
+    static constexpr int THREADS = NW * 64;
+    static constexpr int QS = DP + lds_traits<T>::RPAD;  // row-major stride of Qb / dOb / Ks
+    static constexpr int TQS = 32 + 4;                    // stride of the transposed block tiles (bf16)
+    static constexpr int KTS = L + 8;                     // stride of Kt (bf16) [DP][L]
+    static constexpr int SS = BF ? L + 8 : L + 4;         // stride of the dS block [32][L]
+    static constexpr int QTILES = (32 / 16) * (DP / 16);  // 16x16 dQ tiles per block
+    static constexpr int QT_PER_WAVE = QTILES / NW;
+    // element counts (in T) of the LDS regions
+    static constexpr int N_K = BF ? DP * KTS : L * QS;
+    static constexpr int N_DS = 32 * SS;
+    static constexpr int N_QB = 32 * QS;
+    static constexpr int N_QBT = BF ? DP * TQS : 0;
+    static constexpr size_t lds_bytes(bool bias) {
+        return (size_t)(N_K + N_DS + 2 * N_QB + 2 * N_QBT) * sizeof(T) + (size_t)2 * L * sizeof(float) +
+               (bias ? (size_t)(1 + NW) * bias_lds<WS>::FLOATS * sizeof(float) : 0);
+    }
+    static constexpr int MIN_WAVES = (BF && !(WS == 16 && DP == 64)) ? 2 : 1;
+};
+
+// 8 consecutive bf16 (or DP/2 floats handled by the caller) of a global row, zero past d
+__device__ __forceinline__ uint4 load_bf16x8_masked(const bf16_t *row, int e0, int d) {
+    uint32_t v[4];
+    if ((d & 1) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (e0 + 2 * i < d) ? *reinterpret_cast<const uint32_t *>(row + e0 + 2 * i) : 0u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = (e0 + 2 * i < d) ? row[e0 + 2 * i] : 0u;
+            const uint32_t hi = (e0 + 2 * i + 1 < d) ? row[e0 + 2 * i + 1] : 0u;
+            v[i] = lo | (hi << 16);
+        }
+    }
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+template <typename T, int WS, int DP, bool BIAS, bool LEPE>
+__global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::MIN_WAVES)) void win_attn_bwd_kernel(
+    AttnGeom g, const T *__restrict__ qkv, const T *__restrict__ out, const T *__restrict__ dout,
+    const float *__restrict__ table, float scale, const float *__restrict__ lepe_w,
+    const float *__restrict__ lepe_b, const float *__restrict__ lse, T *__restrict__ dqkv,
+    float *__restrict__ ws_table, float *__restrict__ ws_lepe) {
+    using Cfg = BwdCfg<T, WS, DP>;
+    constexpr bool BF = Cfg::BF;
+    constexpr int L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, KT = Cfg::KT, THREADS = Cfg::THREADS;
+    constexpr int QS = Cfg::QS, TQS = Cfg::TQS, KTS = Cfg::KTS, SS = Cfg::SS;
+    constexpr int TS = bias_lds<WS>::TS, TBF = bias_lds<WS>::FLOATS, TR = bias_lds<WS>::ROWS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *Kl = reinterpret_cast<T *>(smem);   // bf16: K^T [DP][KTS];  f32: K [L][QS]
+    T *dSs = Kl + Cfg::N_K;                // [32][SS]
+    T *Qb = dSs + Cfg::N_DS;               // [32][QS]
+    T *dOb = Qb + Cfg::N_QB;               // [32][QS]
+    T *Qbt = dOb + Cfg::N_QB;              // bf16 only: [DP][TQS]
+    T *dObt = Qbt + Cfg::N_QBT;            // bf16 only: [DP][TQS]
+    float *delta_s = reinterpret_cast<float *>(dObt + Cfg::N_QBT);  // [L]
+    float *lse_s = delta_s + L;                                     // [L], already times log2(e)
+    float *tb = lse_s + L;                                          // BIAS: [TBF]
+    float *dtb = tb + TBF;                                          // BIAS: [NW][TBF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
+    const int win = id / g.heads, head = id - win * g.heads;
+    const int d = g.d, C = g.C, C3 = 3 * g.C;
+    int qoff, koff, voff;
+    qkv_offsets(g, head, qoff, koff, voff);
+    size_t origin;
+    int pitch;
+    if (g.H == 0) {
+        origin = (size_t)win * L;
+        pitch = WS;
+    } else {
+        const int per = g.nWh * g.nWw;
+        const int b = win / per, r = win - b * per;
+        const int wr = r / g.nWw, wc = r - wr * g.nWw;
+        origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
+        pitch = g.W;
+    }
+    auto trow = [&](int l) -> size_t { return origin + (size_t)(l / WS) * pitch + (l % WS); };
+
+    // ---- prologue: K into LDS, delta / lse, bias tables ----------------------------------------
+    if constexpr (BF) {
+        for (int it = tid; it < L * DP; it += THREADS) {  // K^T[e][row]
+            const int row = it / DP, e = it - row * DP;
+            Kl[e * KTS + row] = (e < d) ? qkv[trow(row) * C3 + koff + e] : (T)0;
+        }
+    } else {
+        for (int it = tid; it < L * DP; it += THREADS) {  // K[row][e]
+            const int row = it / DP, e = it - row * DP;
+            Kl[row * QS + e] = (e < d) ? qkv[trow(row) * C3 + koff + e] : (T)0;
+        }
+    }
+    for (int row = tid; row < L; row += THREADS) {
+        const T *orow = out + trow(row) * C + head * d;
+        const T *grow = dout + trow(row) * C + head * d;
+        float acc = 0.f;
+        for (int e = 0; e < d; ++e) acc += io<T>::ld(orow + e) * io<T>::ld(grow + e);
+        delta_s[row] = acc;
+        lse_s[row] = lse[((size_t)win * g.heads + head) * L + row] * LOG2E;
+    }
+    if constexpr (BIAS) {
+        for (int it = tid; it < TR * TR; it += THREADS) {
+            const int di = it / TR, dj = it - di * TR;
+            tb[di * TS + dj] = table[(size_t)it * g.heads + head] * LOG2E;
+        }
+        for (int it = tid; it < NW * TBF; it += THREADS) dtb[it] = 0.f;
+    }
+
+    // this wave's K and V fragments (B operands: k-dim = head dim, column = key on the lane)
+    uint4 kfb[BF ? KT : 1][DP / 16], vfb[BF ? KT : 1][DP / 16];
+    float kff[BF ? 1 : KT][BF ? 1 : DP / 2], vff[BF ? 1 : KT][BF ? 1 : DP / 2];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int key = 32 * (wave * KT + kt) + l31;
+        const T *krow = qkv + trow(key) * C3 + koff;
+        const T *vrow = qkv + trow(key) * C3 + voff;
+        if constexpr (BF) {
+#pragma unroll
+            for (int s = 0; s < DP / 16; ++s) {
+                kfb[kt][s] = load_bf16x8_masked(krow, 16 * s + 8 * hh, d);
+                vfb[kt][s] = load_bf16x8_masked(vrow, 16 * s + 8 * hh, d);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < DP / 2; ++s) {
+                const int e = hh * (DP / 2) + s;
+                kff[kt][s] = (e < d) ? krow[e] : 0.f;
+                vff[kt][s] = (e < d) ? vrow[e] : 0.f;
+            }
+        }
+    }
+
+    f32x16 dKacc[KT][DP / 32], dVacc[KT][DP / 32];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < DP / 32; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dKacc[kt][u][r] = 0.f;
+                dVacc[kt][u][r] = 0.f;
+            }
+
+    const float sc2 = scale * LOG2E;
+
+    for (int qb = 0; qb < NT; ++qb) {
+        __syncthreads();  // previous block's LDS reads are done (first pass: prologue writes land)
+        // ---- stage the block's Q and dO rows ----------------------------------------------------
+        if constexpr (BF) {
+            if ((d & 1) == 0) {
+                constexpr int DW = DP / 2;
+                for (int it = tid; it < 32 * DW; it += THREADS) {
+                    const int row = it / DW, e = (it - row * DW) * 2;
+                    const size_t tr = trow(qb * 32 + row);
+                    uint32_t qv = 0, gv = 0;
+                    if (e < d) {
+                        qv = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + qoff + e);
+                        gv = *reinterpret_cast<const uint32_t *>(dout + tr * C + head * d + e);
+                    }
+                    *reinterpret_cast<uint32_t *>(Qb + row * QS + e) = qv;
+                    *reinterpret_cast<uint32_t *>(dOb + row * QS + e) = gv;
+                    Qbt[e * TQS + row] = (T)(qv & 0xffffu);
+                    Qbt[(e + 1) * TQS + row] = (T)(qv >> 16);
+                    dObt[e * TQS + row] = (T)(gv & 0xffffu);
+                    dObt[(e + 1) * TQS + row] = (T)(gv >> 16);
+                }
+            } else {
+                for (int it = tid; it < 32 * DP; it += THREADS) {
+                    const int row = it / DP, e = it - row * DP;
+                    const size_t tr = trow(qb * 32 + row);
+                    T qv = 0, gv = 0;
+                    if (e < d) {
+                        qv = qkv[tr * C3 + qoff + e];
+                        gv = dout[tr * C + head * d + e];
+                    }
+                    Qb[row * QS + e] = qv;
+                    dOb[row * QS + e] = gv;
+                    Qbt[e * TQS + row] = qv;
+                    dObt[e * TQS + row] = gv;
+                }
+            }
+        } else {
+            for (int it = tid; it < 32 * DP; it += THREADS) {
+                const int row = it / DP, e = it - row * DP;
+                const size_t tr = trow(qb * 32 + row);
+                T qv = 0, gv = 0;
+                if (e < d) {
+                    qv = qkv[tr * C3 + qoff + e];
+                    gv = dout[tr * C + head * d + e];
+                }
+                Qb[row * QS + e] = qv;
+                dOb[row * QS + e] = gv;
+            }
+        }
+        __syncthreads();
+
+        // per-row constants of this lane's 16 accumulator rows: q = qb*32 + rho(r) + 4hh
+        float lrow[16], drow[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            lrow[r] = lse_s[qb * 32 + rho(r) + 4 * hh];
+            drow[r] = delta_s[qb * 32 + rho(r) + 4 * hh];
+        }
+
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int tile = wave * KT + kt;
+            const int key = 32 * tile + l31;
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.f;
+                pacc[r] = 0.f;
+            }
+            // ---- S = Q K^T and dP = dO V^T (rows = queries, lane = key) ---------------------------
+            if constexpr (BF) {
+#pragma unroll
+                for (int s = 0; s < DP / 16; ++s) {
+                    const uint4 qa = *reinterpret_cast<const uint4 *>(Qb + l31 * QS + 16 * s + 8 * hh);
+                    const uint4 ga = *reinterpret_cast<const uint4 *>(dOb + l31 * QS + 16 * s + 8 * hh);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(qa), as_bf16x8(kfb[kt][s]), sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ga), as_bf16x8(vfb[kt][s]), pacc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s4 = 0; s4 < DP / 8; ++s4) {
+                    const float4 qa = *reinterpret_cast<const float4 *>(Qb + l31 * QS + hh * (DP / 2) + 4 * s4);
+                    const float4 ga = *reinterpret_cast<const float4 *>(dOb + l31 * QS + hh * (DP / 2) + 4 * s4);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kff[kt][4 * s4 + 0], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kff[kt][4 * s4 + 1], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kff[kt][4 * s4 + 2], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kff[kt][4 * s4 + 3], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vff[kt][4 * s4 + 0], pacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.y, vff[kt][4 * s4 + 1], pacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.z, vff[kt][4 * s4 + 2], pacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vff[kt][4 * s4 + 3], pacc, 0, 0, 0);
+                }
+            }
+            // ---- P = exp2(S*sc2 + bias2 - lse2), dS = P * (dP - delta) -----------------------------
+            // table entry of (q, key): (qi-ki+w-1)*TS + (qj-kj+w-1); q = qb*32 + rho(r) + 4hh
+            const int ki = key / WS, kj = key - ki * WS;
+            const int lane_base = (WS - 1) * (TS + 1) - ki * TS - kj + 4 * hh + (qb * 32 / WS) * TS;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q_c = rho(r);  // compile-time part of the query index inside the block
+                const int tix = lane_base + (q_c / WS) * TS + (q_c % WS);
+                float v = sacc[r] * sc2 - lrow[r];
+                if constexpr (BIAS) v += tb[tix];
+                const float p = __builtin_amdgcn_exp2f(v);
+                const float ds = p * (pacc[r] - drow[r]);
+                sacc[r] = p;
+                pacc[r] = ds;
+                if constexpr (BIAS) atomicAdd(&dtb[wave * TBF + tix], ds);
+            }
+            // ---- dS block to LDS for dQ ---------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (BF) dSs[(rho(r) + 4 * hh) * SS + key] = f32_to_bf16(pacc[r]);
+                else dSs[(rho(r) + 4 * hh) * SS + key] = pacc[r];
+            }
+            // ---- dV^T += dO^T P,  dK^T += Q^T dS  (sum over the accumulator rows = queries) -----------
+            if constexpr (BF) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint4 pb = make_uint4(pack_bf16(sacc[8 * s + 0], sacc[8 * s + 1]), pack_bf16(sacc[8 * s + 2], sacc[8 * s + 3]),
+                                                pack_bf16(sacc[8 * s + 4], sacc[8 * s + 5]), pack_bf16(sacc[8 * s + 6], sacc[8 * s + 7]));
+                    const uint4 db = make_uint4(pack_bf16(pacc[8 * s + 0], pacc[8 * s + 1]), pack_bf16(pacc[8 * s + 2], pacc[8 * s + 3]),
+                                                pack_bf16(pacc[8 * s + 4], pacc[8 * s + 5]), pack_bf16(pacc[8 * s + 6], pacc[8 * s + 7]));
+#pragma unroll
+                    for (int u = 0; u < DP / 32; ++u) {
+                        const T *gr = dObt + (32 * u + l31) * TQS + 16 * s + 4 * hh;
+                        const T *qr = Qbt + (32 * u + l31) * TQS + 16 * s + 4 * hh;
+                        const uint2 g0 = *reinterpret_cast<const uint2 *>(gr), g1 = *reinterpret_cast<const uint2 *>(gr + 8);
+                        const uint2 q0 = *reinterpret_cast<const uint2 *>(qr), q1 = *reinterpret_cast<const uint2 *>(qr + 8);
+                        dVacc[kt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(g0.x, g0.y, g1.x, g1.y)), as_bf16x8(pb), dVacc[kt][u], 0, 0, 0);
+                        dKacc[kt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(q0.x, q0.y, q1.x, q1.y)), as_bf16x8(db), dKacc[kt][u], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                    for (int u = 0; u < DP / 32; ++u) {
+                        const float ga = dOb[(rho(r) + 4 * hh) * QS + 32 * u + l31];
+                        const float qa = Qb[(rho(r) + 4 * hh) * QS + 32 * u + l31];
+                        dVacc[kt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, sacc[r], dVacc[kt][u], 0, 0, 0);
+                        dKacc[kt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, pacc[r], dKacc[kt][u], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the whole dS block is in LDS
+
+        // ---- dQ block = dS K * scale: 16x16 output tiles, one (or more) per wave, K-dim = all keys ---
+#pragma unroll
+        for (int tq = 0; tq < Cfg::QT_PER_WAVE; ++tq) {
+            const int tile = wave * Cfg::QT_PER_WAVE + tq;
+            const int mq = tile / (DP / 16), nd = tile - mq * (DP / 16);
+            const int l15 = lane & 15, l4 = lane >> 4;
+            f32x4 qacc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {
+#pragma unroll 4
+                for (int s = 0; s < L / 32; ++s) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(dSs + (16 * mq + l15) * SS + 32 * s + 8 * l4);
+                    const uint4 b = *reinterpret_cast<const uint4 *>(Kl + (16 * nd + l15) * KTS + 32 * s + 8 * l4);
+                    qacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), qacc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll 4
+                for (int s = 0; s < L / 4; ++s) {
+                    const float a = dSs[(16 * mq + l15) * SS + 4 * s + l4];
+                    const float b = Kl[(4 * s + l4) * QS + 16 * nd + l15];
+                    qacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, qacc, 0, 0, 0);
+                }
+            }
+            // C layout: column (head dim) = lane & 15, row (query) = 4*(lane>>4) + reg
+            const int e = 16 * nd + l15;
+            if (e < d) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qb * 32 + 16 * mq + 4 * l4 + r;
+                    io<T>::st(dqkv + trow(q) * C3 + qoff + e, qacc[r] * scale);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: dK^T, dV^T (rows = head dim in registers, lane = key) ------------------------
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int key = 32 * (wave * KT + kt) + l31;
+        T *dkrow = dqkv + trow(key) * C3 + koff;
+        T *dvrow = dqkv + trow(key) * C3 + voff;
+#pragma unroll
+        for (int u = 0; u < DP / 32; ++u) {
+            if (BF && (d & 1) == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int e = 32 * u + rho(r) + 4 * hh;
+                    if (e < d) {
+                        *reinterpret_cast<uint32_t *>(dkrow + e) = pack_bf16(dKacc[kt][u][r] * scale, dKacc[kt][u][r + 1] * scale);
+                        *reinterpret_cast<uint32_t *>(dvrow + e) = pack_bf16(dVacc[kt][u][r], dVacc[kt][u][r + 1]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = 32 * u + rho(r) + 4 * hh;
+                    if (e < d) {
+                        io<T>::st(dkrow + e, dKacc[kt][u][r] * scale);
+                        io<T>::st(dvrow + e, dVacc[kt][u][r]);
+                    }
+                }
+            }
+        }
+    }
+
+    if constexpr (BIAS) {
+        __syncthreads();
+        // natural-log gradient: the table was used times log2(e) inside exp2, d/dtable is dS itself
+        float *dst = ws_table + ((size_t)win * g.heads + head) * (TR * TR);
+        for (int it = tid; it < TR * TR; it += THREADS) {
+            const int di = it / TR, dj = it - di * TR;
+            float acc = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) acc += dtb[wv * TBF + di * TS + dj];
+            dst[it] = acc;
+        }
+    }
+}
+
+// d_table[t][h] = sum over windows (ascending) of ws[(win*heads + h)*T + t]
+__global__ void bias_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int heads, int T, float *__restrict__ d_table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * heads) return;
+    const int t = i / heads, h = i - t * heads;
+    float acc = 0.f;
+    for (int wdx = 0; wdx < n_win; ++wdx) acc += ws[((size_t)wdx * heads + h) * T + t];
+    d_table[i] = acc;
+}
+
+template <typename T, int WS, int DP>
+static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const void *dout, const float *table,
+                      float scale, const float *lepe_w, const float *lepe_b, const float *lse, void *dqkv,
+                      float *d_table, float *ws_table, float *ws_lepe, hipStream_t st) {
+    using Cfg = BwdCfg<T, WS, DP>;
+    const bool bias = table != nullptr, lepe = lepe_w != nullptr;
+    if (lepe) return fail(DSW_EUNSUPPORTED, "win_attn_bwd: LePE gradients are built in a separate kernel");
+    const size_t lds = Cfg::lds_bytes(bias);
+    if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "win_attn_bwd: w=%d head dim %d needs %zu B of LDS", WS, g.d, lds);
+    const dim3 grid(g.n_win * g.heads), block(Cfg::THREADS);
+#define DSW_BWD_LAUNCH(B_)                                                                                       \
+    do {                                                                                                         \
+        auto kern = win_attn_bwd_kernel<T, WS, DP, B_, false>;                                                   \
+        if (lds > 48 * 1024) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const T *)qkv, (const T *)out, (const T *)dout, table, \
+                           scale, lepe_w, lepe_b, lse, (T *)dqkv, ws_table, ws_lepe);                            \
+    } while (0)
+    if (bias) DSW_BWD_LAUNCH(true);
+    else DSW_BWD_LAUNCH(false);
+#undef DSW_BWD_LAUNCH
+    int rc = check_launch("win_attn_bwd_kernel");
+    if (rc) return rc;
+    if (bias) {
+        const int T2 = (2 * WS - 1) * (2 * WS - 1);
+        hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((T2 * g.heads + 255) / 256), dim3(256), 0, st, ws_table,
+                           g.n_win, g.heads, T2, d_table);
+        rc = check_launch("bias_grad_reduce_kernel");
+    }
+    return rc;
+}
+
+int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads, int layout, AttnGeom &g);
+
+}  // namespace dsw
+
+using namespace dsw;
+
+static size_t table_ws_floats(const AttnGeom &g, int w) { return (size_t)g.n_win * g.heads * (2 * w - 1) * (2 * w - 1); }
+static size_t lepe_ws_floats(const AttnGeom &g) { return (size_t)g.n_win * g.C * 10; }
+
+extern "C" size_t dsw_win_attn_bwd_workspace(int n_img, int H, int W, int w, int C, int heads, int has_bias,
+                                             int has_lepe) {
+    AttnGeom g;
+    if (make_geom("dsw_win_attn_bwd_workspace", n_img, H, W, w, C, heads, DSW_QKV_CHUNKED, g)) return 0;
+    size_t fl = 0;
+    if (has_bias) fl += table_ws_floats(g, w);
+    if (has_lepe) fl += lepe_ws_floats(g);
+    return fl * sizeof(float);
+}
+
+extern "C" int dsw_win_attn_bwd(const void *qkv, const void *out, const void *dout, int dtype, int layout,
+                                int n_img, int H, int W, int w, int C, int heads, const float *bias_table,
+                                float scale, const float *lepe_w, const float *lepe_b, const float *lse,
+                                void *dqkv, float *d_bias_table, float *d_lepe_w, float *d_lepe_b,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    AttnGeom g;
+    int rc = make_geom("dsw_win_attn_bwd", n_img, H, W, w, C, heads, layout, g);
+    if (rc) return rc;
+    DSW_REQUIRE(qkv && out && dout && lse && dqkv, "dsw_win_attn_bwd: null pointer");
+    DSW_REQUIRE((bias_table == nullptr) == (d_bias_table == nullptr), "dsw_win_attn_bwd: bias_table and d_bias_table go together");
+    DSW_REQUIRE((lepe_w == nullptr) == (d_lepe_w == nullptr) && (lepe_w == nullptr) == (lepe_b == nullptr) &&
+                    (lepe_w == nullptr) == (d_lepe_b == nullptr),
+                "dsw_win_attn_bwd: the four LePE pointers go together");
+    const size_t need = dsw_win_attn_bwd_workspace(n_img, H, W, w, C, heads, bias_table != nullptr, lepe_w != nullptr);
+    DSW_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), "dsw_win_attn_bwd: workspace %zu B < %zu B", workspace_bytes, need);
+    float *ws_table = reinterpret_cast<float *>(workspace);
+    float *ws_lepe = ws_table + (bias_table ? table_ws_floats(g, w) : 0);
+    hipStream_t st = as_stream(stream);
+    const bool big = g.d > 32;
+    DSW_DISPATCH_DTYPE(dtype, T, {
+        if (w == 16) return big ? launch_bwd<T, 16, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, ws_table, ws_lepe, st)
+                                : launch_bwd<T, 16, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, ws_table, ws_lepe, st);
+        return big ? launch_bwd<T, 8, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, ws_table, ws_lepe, st)
+                   : launch_bwd<T, 8, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, ws_table, ws_lepe, st);
+    });
+    return DSW_OK;
+}

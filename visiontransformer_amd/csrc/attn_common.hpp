@@ -1,0 +1,76 @@
+// Shared pieces of the fused window-attention kernels (forward and backward).
+#pragma once
+#include "common.hpp"
+
+namespace dsw {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnGeom {
+    int n_win;       // total windows
+    int H, W;        // image size in tokens (0,0 = packed windows)
+    int nWh, nWw;    // windows per image column / row (grid mode)
+    int C, heads, d; // channels, heads, head dim
+    int layout;      // DSW_QKV_*
+};
+
+// Row of the C layout of a 32x32 MFMA result held in register r by lane half hh.
+__device__ __forceinline__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// token (window, l) -> row of the [rows, 3C] / [rows, C] matrices
+template <int WS>
+__device__ __forceinline__ size_t token_row(const AttnGeom &g, int win, int l) {
+    if (g.H == 0) return (size_t)win * (WS * WS) + l;
+    const int per = g.nWh * g.nWw;
+    const int b = win / per, r = win - b * per;
+    const int wr = r / g.nWw, wc = r - wr * g.nWw;
+    const int i = l / WS, j = l - i * WS;
+    return ((size_t)b * g.H + wr * WS + i) * g.W + wc * WS + j;
+}
+
+__device__ __forceinline__ void qkv_offsets(const AttnGeom &g, int head, int &qoff, int &koff, int &voff) {
+    if (g.layout == DSW_QKV_CHUNKED) {
+        qoff = head * g.d;
+        koff = g.C + head * g.d;
+        voff = 2 * g.C + head * g.d;
+    } else {
+        qoff = head * 3 * g.d;
+        koff = qoff + g.d;
+        voff = qoff + 2 * g.d;
+    }
+}
+
+// Blocks that share blockIdx % 8 run on one XCD and share its L2: hand the heads of one window
+// (which read the same 128-byte lines of the qkv rows) to such a group.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// LDS element type and strides (in elements) chosen conflict-free for the reads below:
+//   row-major [tokens][DP + RPAD]  read 16 B per lane, rows on lanes
+//   transposed [DP][L + 4]         read 8 B (bf16) / 16 B (f32) per lane, rows on lanes
+template <typename T> struct lds_traits;
+template <> struct lds_traits<bf16_t> { static constexpr int RPAD = 8; };
+template <> struct lds_traits<float> { static constexpr int RPAD = 4; };
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// relative-position table in LDS: [(2w-1)][TS] with TS = 3w, which makes the per-lane lookups of
+// one wave-instruction fall on distinct banks (w = 16: two runs of 16 that are 48 apart; w = 8:
+// four runs of 8 that are 24 apart).
+template <int WS> struct bias_lds {
+    static constexpr int TS = 3 * WS;
+    static constexpr int ROWS = 2 * WS - 1;
+    static constexpr int FLOATS = ROWS * TS;
+};
+
+}  // namespace dsw

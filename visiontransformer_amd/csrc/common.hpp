@@ -1,0 +1,122 @@
+// Shared helpers for the gfx950 kernels of libdswin_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/dswin_hip.h"
+
+namespace dsw {
+
+// ---- error plumbing: one message per host thread, nothing shared ---------------------------
+char *tls_error_buffer();
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tls_error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DSW_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return DSW_OK;
+}
+#define DSW_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return ::dsw::fail(DSW_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+// ---- bf16 <-> f32 -----------------------------------------------------------------------------
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct io;
+template <> struct io<float> {
+    static constexpr int dtype = DSW_F32;
+    __device__ static __forceinline__ float ld(const float *p) { return *p; }
+    __device__ static __forceinline__ void st(float *p, float v) { *p = v; }
+    // 4 consecutive elements, 16-byte aligned
+    __device__ static __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    __device__ static __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct io<bf16_t> {
+    static constexpr int dtype = DSW_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t *p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+    // 4 consecutive elements, 8-byte aligned
+    __device__ static __forceinline__ float4 ld4(const bf16_t *p) {
+        uint2 u = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    __device__ static __forceinline__ void st4(bf16_t *p, float4 v) {
+        uint2 u;
+        u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2 *>(p) = u;
+    }
+};
+
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 operator/(float4 a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---- wave / block reductions (wave = 64 lanes) ----------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// fixed-order block reduction (the same tree on every launch => bitwise reproducible);
+// red must hold blockDim.x/64 floats; every thread gets the result.
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float *red) {
+    v = wave_max(v);
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// dispatch a functor template on a runtime dtype code
+#define DSW_DISPATCH_DTYPE(code, T, ...)                                           \
+    do {                                                                           \
+        if ((code) == DSW_F32) { using T = float; __VA_ARGS__; }                   \
+        else if ((code) == DSW_BF16) { using T = ::dsw::bf16_t; __VA_ARGS__; }     \
+        else return ::dsw::fail(DSW_EUNSUPPORTED, "dtype code %d", (int)(code));   \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace dsw

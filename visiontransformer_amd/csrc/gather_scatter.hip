@@ -1,0 +1,397 @@
+// Bilinear window gather (roi_align specialised to integer-aligned w x w windows) and the
+// gated scatter-mean write-back of DS-MSA, forward and backward, NHWC, atomic-free.
+// Reference: DSwinT_arch.py:239-253, :259, :295-297, :303, :308-315.
+//
+// Geometry both directions rely on: a window that starts from grid cell (r, c) has its corner
+// h1 in [r*w - w/2, r*w + w/2] (the offset is trunc(sigmoid*w - w/2), and the clamp to [0, H-w]
+// only moves border windows inwards), so pixel row y can only be covered by windows of cell rows
+// floor((y + w/2)/w) - 1 and floor((y + w/2)/w); the same holds per column.  With one window per
+// cell at most, a pixel has <= 4 covering windows, found through cellmap.
+#include "common.hpp"
+
+namespace dsw {
+
+constexpr int GS_THREADS = 256;
+constexpr int TILE_PIX = 32;  // pixels of one image row handled by a block
+
+struct Cover {
+    int id[4];   // covering window ids, ascending
+    int tok[4];  // token index inside that window: (y - h1) * w + (x - w1)
+    int n;
+};
+
+__device__ __forceinline__ Cover find_cover(const int *__restrict__ cellmap, const int *__restrict__ win_h1,
+                                            const int *__restrict__ win_w1, int b, int y, int x, int Hw,
+                                            int Ww, int w) {
+    Cover cv;
+    cv.n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cv.id[i] = 0x7fffffff; cv.tok[i] = 0; }
+    const int r_hi = min((y + (w >> 1)) / w, Hw - 1);
+    const int c_hi = min((x + (w >> 1)) / w, Ww - 1);
+#pragma unroll
+    for (int dr = 1; dr >= 0; --dr) {
+        const int r = r_hi - dr;
+        if (r < 0) continue;
+#pragma unroll
+        for (int dc = 1; dc >= 0; --dc) {
+            const int c = c_hi - dc;
+            if (c < 0) continue;
+            const int id = cellmap[((size_t)b * Hw + r) * Ww + c];
+            if (id < 0) continue;
+            const int h1 = win_h1[id], w1 = win_w1[id];
+            const int ly = y - h1, lx = x - w1;
+            if (ly < 0 || ly >= w || lx < 0 || lx >= w) continue;
+            // insertion into the ascending list (<= 4 entries)
+            int pos = cv.n;
+#pragma unroll
+            for (int s = 3; s > 0; --s) {
+                if (s <= pos && cv.id[s - 1] > id) {
+                    cv.id[s] = cv.id[s - 1];
+                    cv.tok[s] = cv.tok[s - 1];
+                    pos = s - 1;
+                }
+            }
+            cv.id[pos] = id;
+            cv.tok[pos] = ly * w + lx;
+            cv.n += 1;
+        }
+    }
+    return cv;
+}
+
+// torchvision's bilinear sample at (y + .5, x + .5): taps (y, x), (y, xh), (yh, x), (yh, xh)
+// with weights hy*hx, hy*lx, ly*hx, ly*lx; on the last row/column the high tap folds onto the
+// low one with weight 0.
+struct Taps {
+    int yh, xh;
+    float w00, w01, w10, w11;
+};
+__device__ __forceinline__ Taps make_taps(int y, int x, int H, int W) {
+    Taps t;
+    const float ly = (y < H - 1) ? 0.5f : 0.f, lx = (x < W - 1) ? 0.5f : 0.f;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    t.yh = (y < H - 1) ? y + 1 : y;
+    t.xh = (x < W - 1) ? x + 1 : x;
+    t.w00 = hy * hx;
+    t.w01 = hy * lx;
+    t.w10 = ly * hx;
+    t.w11 = ly * lx;
+    return t;
+}
+
+template <typename T>
+__device__ __forceinline__ float4 box_sample(const T *__restrict__ img, int y, int x, int H, int W, int C, int c) {
+    const Taps t = make_taps(y, x, H, W);
+    const float4 v00 = io<T>::ld4(img + ((size_t)y * W + x) * C + c);
+    const float4 v01 = io<T>::ld4(img + ((size_t)y * W + t.xh) * C + c);
+    const float4 v10 = io<T>::ld4(img + ((size_t)t.yh * W + x) * C + c);
+    const float4 v11 = io<T>::ld4(img + ((size_t)t.yh * W + t.xh) * C + c);
+    return ((v00 * t.w00 + v01 * t.w01) + v10 * t.w10) + v11 * t.w11;
+}
+
+// ---- gather forward: one block per (window, window row) -------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(GS_THREADS) void gather_fwd_kernel(
+    const TI *__restrict__ x, const int *__restrict__ win_b, const int *__restrict__ win_h1,
+    const int *__restrict__ win_w1, int H, int W, int C, int w, TO *__restrict__ out) {
+    const int n = blockIdx.x / w, i = blockIdx.x - n * w;
+    const int b = win_b[n], y = win_h1[n] + i, x0 = win_w1[n];
+    const TI *img = x + (size_t)b * H * W * C;
+    TO *dst = out + ((size_t)n * w * w + (size_t)i * w) * C;
+    const int CV = C >> 2;
+    for (int it = threadIdx.x; it < w * CV; it += GS_THREADS) {
+        const int j = it / CV, c = (it - j * CV) << 2;
+        io<TO>::st4(dst + (size_t)j * C + c, box_sample<TI>(img, y, x0 + j, H, W, C, c));
+    }
+}
+
+// ---- gather backward: one block per TILE_PIX pixels of an image row -------------------------------
+// dx(y,x) = sum over the sample positions (y',x') in {y-1,y} x {x-1,x} whose taps include (y,x) of
+//           weight * sum over windows covering (y',x') of dout[window, token(y',x')].
+template <typename TG, typename TO>
+__global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
+    const TG *__restrict__ dout, const int *__restrict__ cellmap, const int *__restrict__ win_h1,
+    const int *__restrict__ win_w1, int H, int W, int C, int w, int tiles_per_row, TO *__restrict__ dx) {
+    __shared__ Cover cov[2][TILE_PIX + 1];
+    const int Hw = H / w, Ww = W / w;
+    const int tile = blockIdx.x % tiles_per_row;
+    const int y = (blockIdx.x / tiles_per_row) % H;
+    const int b = blockIdx.x / (tiles_per_row * H);
+    const int x0 = tile * TILE_PIX;
+    const int npix = min(TILE_PIX, W - x0);
+    for (int t = threadIdx.x; t < 2 * (TILE_PIX + 1); t += GS_THREADS) {
+        const int row = t / (TILE_PIX + 1), col = t - row * (TILE_PIX + 1);
+        const int yy = y - 1 + row, xx = x0 - 1 + col;
+        Cover cv;
+        cv.n = 0;
+        if (yy >= 0 && xx >= 0 && xx < W) cv = find_cover(cellmap, win_h1, win_w1, b, yy, xx, Hw, Ww, w);
+        cov[row][col] = cv;
+    }
+    __syncthreads();
+    const int CV = C >> 2, L = w * w;
+    const float wy_self = (y < H - 1) ? 0.5f : 1.0f;
+    for (int it = threadIdx.x; it < npix * CV; it += GS_THREADS) {
+        const int p = it / CV, c = (it - p * CV) << 2;
+        const int x = x0 + p;
+        const float wx_self = (x < W - 1) ? 0.5f : 1.0f;
+        float4 acc = f4zero();
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+#pragma unroll
+            for (int col = 0; col < 2; ++col) {
+                const Cover &cv = cov[row][p + col];
+                const float wt = (row ? wy_self : 0.5f) * (col ? wx_self : 0.5f);
+                for (int s = 0; s < cv.n; ++s)
+                    acc = acc + io<TG>::ld4(dout + ((size_t)cv.id[s] * L + cv.tok[s]) * C + c) * wt;
+            }
+        }
+        io<TO>::st4(dx + (((size_t)b * H + y) * W + x) * C + c, acc);
+    }
+}
+
+// ---- scatter-mean + residual forward ----------------------------------------------------------------
+template <typename TX, typename TA, typename TY>
+__global__ __launch_bounds__(GS_THREADS) void scatter_fwd_kernel(
+    const TX *__restrict__ x, const TA *__restrict__ after, const float *__restrict__ gates_delta,
+    const float *__restrict__ scores_delta, const int *__restrict__ cellmap, const int *__restrict__ win_h1,
+    const int *__restrict__ win_w1, int H, int W, int C, int w, int tiles_per_row, TY *__restrict__ yout) {
+    __shared__ Cover cov[TILE_PIX];
+    const int Hw = H / w, Ww = W / w;
+    const int tile = blockIdx.x % tiles_per_row;
+    const int y = (blockIdx.x / tiles_per_row) % H;
+    const int b = blockIdx.x / (tiles_per_row * H);
+    const int x0 = tile * TILE_PIX;
+    const int npix = min(TILE_PIX, W - x0);
+    if (threadIdx.x < npix) cov[threadIdx.x] = find_cover(cellmap, win_h1, win_w1, b, y, x0 + threadIdx.x, Hw, Ww, w);
+    __syncthreads();
+    const int CV = C >> 2, L = w * w;
+    const TX *img = x + (size_t)b * H * W * C;
+    for (int it = threadIdx.x; it < npix * CV; it += GS_THREADS) {
+        const int p = it / CV, c = (it - p * CV) << 2;
+        const int xx = x0 + p;
+        const Cover &cv = cov[p];
+        const size_t off = ((size_t)y * W + xx) * C + c;
+        float4 v = io<TX>::ld4(img + off);
+        if (cv.n > 0) {
+            const float4 before = box_sample<TX>(img, y, xx, H, W, C, c);
+            float4 acc = f4zero();
+            for (int s = 0; s < cv.n; ++s) {
+                const int id = cv.id[s];
+                const float4 a = io<TA>::ld4(after + ((size_t)id * L + cv.tok[s]) * C + c);
+                acc = acc + ((a - before) * gates_delta[id]) * scores_delta[id];
+            }
+            v = v + acc / (float)cv.n;
+        }
+        io<TY>::st4(yout + (size_t)b * H * W * C + off, v);
+    }
+}
+
+// ---- scatter backward, pixel side: dx = dy - boxT( dy/count * sum_n(s_n*g_n) ) --------------------
+template <typename TG, typename TO>
+__global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
+    const TG *__restrict__ dy, const float *__restrict__ gates_delta, const float *__restrict__ scores_delta,
+    const int *__restrict__ cellmap, const int *__restrict__ win_h1, const int *__restrict__ win_w1, int H,
+    int W, int C, int w, int tiles_per_row, TO *__restrict__ dx) {
+    __shared__ float fac[2][TILE_PIX + 1];  // sum_n(s_n*g_n)/count at the sample position, 0 if uncovered
+    const int Hw = H / w, Ww = W / w;
+    const int tile = blockIdx.x % tiles_per_row;
+    const int y = (blockIdx.x / tiles_per_row) % H;
+    const int b = blockIdx.x / (tiles_per_row * H);
+    const int x0 = tile * TILE_PIX;
+    const int npix = min(TILE_PIX, W - x0);
+    for (int t = threadIdx.x; t < 2 * (TILE_PIX + 1); t += GS_THREADS) {
+        const int row = t / (TILE_PIX + 1), col = t - row * (TILE_PIX + 1);
+        const int yy = y - 1 + row, xx = x0 - 1 + col;
+        float f = 0.f;
+        if (yy >= 0 && xx >= 0 && xx < W) {
+            const Cover cv = find_cover(cellmap, win_h1, win_w1, b, yy, xx, Hw, Ww, w);
+            for (int s = 0; s < cv.n; ++s) f += scores_delta[cv.id[s]] * gates_delta[cv.id[s]];
+            if (cv.n > 0) f = f / (float)cv.n;
+        }
+        fac[row][col] = f;
+    }
+    __syncthreads();
+    const int CV = C >> 2;
+    const float wy_self = (y < H - 1) ? 0.5f : 1.0f;
+    const TG *gimg = dy + (size_t)b * H * W * C;
+    for (int it = threadIdx.x; it < npix * CV; it += GS_THREADS) {
+        const int p = it / CV, c = (it - p * CV) << 2;
+        const int x = x0 + p;
+        const float wx_self = (x < W - 1) ? 0.5f : 1.0f;
+        float4 acc = io<TG>::ld4(gimg + ((size_t)y * W + x) * C + c);
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+#pragma unroll
+            for (int col = 0; col < 2; ++col) {
+                const float f = fac[row][p + col];
+                if (f != 0.f) {
+                    const float wt = (row ? wy_self : 0.5f) * (col ? wx_self : 0.5f);
+                    const int yy = y - 1 + row, xx = x - 1 + col;
+                    acc = acc - io<TG>::ld4(gimg + ((size_t)yy * W + xx) * C + c) * (wt * f);
+                }
+            }
+        }
+        io<TO>::st4(dx + (((size_t)b * H + y) * W + x) * C + c, acc);
+    }
+}
+
+// ---- scatter backward, window side: d_after and per-row partials of d_gates / d_scores -----------
+// one block per (window, window row)
+template <typename TG, typename TX, typename TA, typename TO>
+__global__ __launch_bounds__(GS_THREADS) void scatter_bwd_win_kernel(
+    const TG *__restrict__ dy, const TX *__restrict__ x, const TA *__restrict__ after,
+    const float *__restrict__ gates_delta, const float *__restrict__ scores_delta,
+    const int *__restrict__ cellmap, const int *__restrict__ win_b, const int *__restrict__ win_h1,
+    const int *__restrict__ win_w1, int H, int W, int C, int w, TO *__restrict__ d_after,
+    float *__restrict__ partial) {
+    __shared__ float inv_cnt[64];
+    __shared__ float red[GS_THREADS / 64];
+    const int Hw = H / w, Ww = W / w;
+    const int n = blockIdx.x / w, i = blockIdx.x - n * w;
+    const int b = win_b[n], y = win_h1[n] + i, x0 = win_w1[n];
+    if (threadIdx.x < w) {
+        const Cover cv = find_cover(cellmap, win_h1, win_w1, b, y, x0 + threadIdx.x, Hw, Ww, w);
+        inv_cnt[threadIdx.x] = (float)cv.n;  // >= 1: this window covers the pixel
+    }
+    __syncthreads();
+    const float g = gates_delta[n], s = scores_delta[n];
+    const TX *img = x + (size_t)b * H * W * C;
+    const TG *gimg = dy + (size_t)b * H * W * C;
+    const size_t tok0 = ((size_t)n * w * w + (size_t)i * w);
+    const int CV = C >> 2;
+    float pg = 0.f, ps = 0.f;
+    for (int it = threadIdx.x; it < w * CV; it += GS_THREADS) {
+        const int j = it / CV, c = (it - j * CV) << 2;
+        const float4 dgated = io<TG>::ld4(gimg + ((size_t)y * W + x0 + j) * C + c) / inv_cnt[j];
+        const float4 u = dgated * s;  // d(delta*g)
+        io<TO>::st4(d_after + (tok0 + j) * C + c, u * g);
+        const float4 before = box_sample<TX>(img, y, x0 + j, H, W, C, c);
+        const float4 delta = io<TA>::ld4(after + (tok0 + j) * C + c) - before;
+        pg += (u.x * delta.x + u.y * delta.y) + (u.z * delta.z + u.w * delta.w);
+        const float4 dg = delta * g;
+        ps += (dgated.x * dg.x + dgated.y * dg.y) + (dgated.z * dg.z + dgated.w * dg.w);
+    }
+    const float tg = block_sum(pg, red);
+    const float ts = block_sum(ps, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)n * w + i) * 2 + 0] = tg;
+        partial[((size_t)n * w + i) * 2 + 1] = ts;
+    }
+}
+
+__global__ void scatter_bwd_reduce_kernel(const float *__restrict__ partial, int n_win, int w,
+                                          float *__restrict__ d_gates_delta, float *__restrict__ d_scores_delta) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_win) return;
+    float tg = 0.f, ts = 0.f;
+    for (int i = 0; i < w; ++i) {
+        tg += partial[((size_t)n * w + i) * 2 + 0];
+        ts += partial[((size_t)n * w + i) * 2 + 1];
+    }
+    d_gates_delta[n] = tg;
+    d_scores_delta[n] = ts;
+}
+
+inline int check_geometry(const char *who, int B, int H, int W, int C, int w) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || w <= 0) return fail(DSW_EINVAL, "%s: bad sizes B=%d H=%d W=%d C=%d w=%d", who, B, H, W, C, w);
+    if (H % w || W % w) return fail(DSW_EINVAL, "%s: H,W (%d,%d) must be multiples of the window size %d", who, H, W, w);
+    if (C % 4) return fail(DSW_EUNSUPPORTED, "%s: channel count %d must be a multiple of 4", who, C);
+    if (w > 64) return fail(DSW_EUNSUPPORTED, "%s: window size %d > 64", who, w);
+    return DSW_OK;
+}
+
+}  // namespace dsw
+
+using namespace dsw;
+
+extern "C" int dsw_gather_fwd(const void *x, int x_dtype, const int *win_b, const int *win_h1,
+                              const int *win_w1, int n_win, int B, int H, int W, int C, int w,
+                              void *out, int out_dtype, void *stream) {
+    int rc = check_geometry("dsw_gather_fwd", B, H, W, C, w);
+    if (rc) return rc;
+    DSW_REQUIRE(n_win >= 0, "dsw_gather_fwd: n_win < 0");
+    if (n_win == 0) return DSW_OK;
+    DSW_REQUIRE(x && win_b && win_h1 && win_w1 && out, "dsw_gather_fwd: null pointer");
+    DSW_DISPATCH_DTYPE(x_dtype, TI, DSW_DISPATCH_DTYPE(out_dtype, TO, {
+        hipLaunchKernelGGL((gather_fwd_kernel<TI, TO>), dim3(n_win * w), dim3(GS_THREADS), 0, as_stream(stream),
+                           (const TI *)x, win_b, win_h1, win_w1, H, W, C, w, (TO *)out);
+    }));
+    return check_launch("gather_fwd_kernel");
+}
+
+extern "C" int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellmap, const int *win_h1,
+                              const int *win_w1, int n_win, int B, int H, int W, int C, int w,
+                              void *dx, int dx_dtype, void *stream) {
+    int rc = check_geometry("dsw_gather_bwd", B, H, W, C, w);
+    if (rc) return rc;
+    DSW_REQUIRE(cellmap && dx && (n_win == 0 || (dout && win_h1 && win_w1)), "dsw_gather_bwd: null pointer");
+    const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
+    DSW_DISPATCH_DTYPE(dout_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
+        hipLaunchKernelGGL((gather_bwd_kernel<TG, TO>), dim3(B * H * tiles), dim3(GS_THREADS), 0, as_stream(stream),
+                           (const TG *)dout, cellmap, win_h1, win_w1, H, W, C, w, tiles, (TO *)dx);
+    }));
+    return check_launch("gather_bwd_kernel");
+}
+
+extern "C" int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int after_dtype,
+                                    const float *gates_delta, const float *scores_delta,
+                                    const int *cellmap, const int *win_h1, const int *win_w1, int n_win,
+                                    int B, int H, int W, int C, int w, void *y, int y_dtype, void *stream) {
+    int rc = check_geometry("dsw_scatter_mean_fwd", B, H, W, C, w);
+    if (rc) return rc;
+    DSW_REQUIRE(x && y && cellmap && (n_win == 0 || (after && gates_delta && scores_delta && win_h1 && win_w1)),
+                "dsw_scatter_mean_fwd: null pointer");
+    const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
+    DSW_DISPATCH_DTYPE(x_dtype, TX, DSW_DISPATCH_DTYPE(after_dtype, TA, DSW_DISPATCH_DTYPE(y_dtype, TY, {
+        hipLaunchKernelGGL((scatter_fwd_kernel<TX, TA, TY>), dim3(B * H * tiles), dim3(GS_THREADS), 0,
+                           as_stream(stream), (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
+                           win_h1, win_w1, H, W, C, w, tiles, (TY *)y);
+    })));
+    return check_launch("scatter_fwd_kernel");
+}
+
+extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype,
+                                    const void *after, int after_dtype, const float *gates_delta,
+                                    const float *scores_delta, const int *cellmap, const int *win_b,
+                                    const int *win_h1, const int *win_w1, int n_win, int B, int H, int W,
+                                    int C, int w, void *dx, int dx_dtype, void *d_after, int d_after_dtype,
+                                    float *d_gates_delta, float *d_scores_delta, float *partial,
+                                    void *stream) {
+    int rc = check_geometry("dsw_scatter_mean_bwd", B, H, W, C, w);
+    if (rc) return rc;
+    DSW_REQUIRE(dy && dx && cellmap, "dsw_scatter_mean_bwd: null pointer");
+    DSW_REQUIRE(n_win == 0 || (x && after && gates_delta && scores_delta && win_b && win_h1 && win_w1 && d_after &&
+                               d_gates_delta && d_scores_delta && partial),
+                "dsw_scatter_mean_bwd: null window arrays");
+    DSW_REQUIRE(x_dtype == dy_dtype || true, "unused");
+    const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
+    hipStream_t st = as_stream(stream);
+    DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
+        hipLaunchKernelGGL((scatter_bwd_dx_kernel<TG, TO>), dim3(B * H * tiles), dim3(GS_THREADS), 0, st,
+                           (const TG *)dy, gates_delta, scores_delta, cellmap, win_h1, win_w1, H, W, C, w, tiles,
+                           (TO *)dx);
+    }));
+    rc = check_launch("scatter_bwd_dx_kernel");
+    if (rc || n_win == 0) return rc;
+    // the window-side kernel is instantiated for dy dtype == d_after dtype pairs that occur:
+    // fp32 gradients everywhere, or bf16 'after' with fp32 dy.
+    DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(x_dtype, TX, DSW_DISPATCH_DTYPE(after_dtype, TA, {
+        if (d_after_dtype == DSW_F32) {
+            hipLaunchKernelGGL((scatter_bwd_win_kernel<TG, TX, TA, float>), dim3(n_win * w), dim3(GS_THREADS), 0, st,
+                               (const TG *)dy, (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
+                               win_b, win_h1, win_w1, H, W, C, w, (float *)d_after, partial);
+        } else if (d_after_dtype == DSW_BF16) {
+            hipLaunchKernelGGL((scatter_bwd_win_kernel<TG, TX, TA, bf16_t>), dim3(n_win * w), dim3(GS_THREADS), 0, st,
+                               (const TG *)dy, (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
+                               win_b, win_h1, win_w1, H, W, C, w, (bf16_t *)d_after, partial);
+        } else {
+            return fail(DSW_EUNSUPPORTED, "dsw_scatter_mean_bwd: d_after dtype %d", d_after_dtype);
+        }
+    })));
+    rc = check_launch("scatter_bwd_win_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(scatter_bwd_reduce_kernel, dim3((n_win + 255) / 256), dim3(256), 0, st, partial, n_win, w,
+                       d_gates_delta, d_scores_delta);
+    return check_launch("scatter_bwd_reduce_kernel");
+}

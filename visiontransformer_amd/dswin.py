@@ -1,0 +1,179 @@
+"""DSWT attention modules backed by the HIP kernels.
+
+Same class names, constructor arguments, forward signatures and state_dict keys as
+DSwinT_arch.py:95-338 of the reference, so a reference checkpoint loads unchanged and the
+reference's ViTBlock / MSFTransformer can hold these modules instead of their own.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import functional as K
+from ._lib import QKV_CHUNKED, QKV_INTERLEAVED
+
+
+class RelativePositionalEncoding(nn.Module):
+    """Bias table [(2k-1)^2, heads] + int64 lookup buffer (DSwinT_arch.py:95-125).
+
+    forward() still returns the expanded [1, heads, Lq, Lk] bias for callers that want it; the
+    attention kernels read the table itself and never materialise that tensor."""
+
+    def __init__(self, q_size, k_size, num_heads=1, scale=1):
+        super().__init__()
+        assert q_size <= k_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * k_size - 1) * (2 * k_size - 1), num_heads))
+        self.scale = scale
+        ii, jj = torch.meshgrid(torch.arange(k_size), torch.arange(k_size), indexing="ij")
+        grid = torch.stack([ii, jj])
+        lo = (k_size - q_size) // 2
+        cq = grid[:, lo:lo + q_size, lo:lo + q_size].reshape(2, -1)
+        ck = grid.reshape(2, -1)
+        rel = (cq[:, :, None] - ck[:, None, :]).permute(1, 2, 0).contiguous() + (k_size - 1)
+        self.register_buffer("relative_position_index", rel[..., 0] * (2 * k_size - 1) + rel[..., 1])
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02, a=-2., b=2.)
+
+    def table(self):
+        t = self.relative_position_bias_table
+        return t if self.scale == 1 else self.scale * t
+
+    def forward(self):
+        bias = self.scale * self.relative_position_bias_table[self.relative_position_index]
+        return bias.permute(2, 0, 1).contiguous().unsqueeze(0)
+
+
+class WindowedAttention(nn.Module):
+    """Base class with the reference's reshaping helpers (DSwinT_arch.py:128-172).  The helpers
+    are kept for API compatibility; the subclasses' forward never calls them - partition,
+    headify, de-headify and reverse are address arithmetic inside the attention kernel."""
+
+    def __init__(self, window_size, dim, num_heads=4):
+        super().__init__()
+        self.win = window_size
+        self.num_heads = num_heads
+        assert dim % num_heads == 0, f"dim ({dim}) must be divisible by num_heads ({num_heads})"
+
+    def window_partition(self, x, win, keep_batch=False):
+        B, H, W, C = x.shape
+        x = x.view(B, H // win, win, W // win, win, C).permute(0, 1, 3, 2, 4, 5).contiguous()
+        nw = (H // win) * (W // win)
+        return x.view(B, nw, win ** 2, C) if keep_batch else x.view(B * nw, win ** 2, C)
+
+    def reverse_window_partition(self, x, win, H, W, with_batch=False):
+        if with_batch:
+            x = x.reshape(-1, win ** 2, x.shape[-1])
+        N, _, C = x.shape
+        x = x.view(N, win, win, C).view(-1, H // win, W // win, win, win, C)
+        return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, H, W, C)
+
+    def headify(self, *xs):
+        outs = []
+        for x in xs:
+            N, win, C = x.shape
+            outs.append(x.view(N, win, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3).contiguous())
+        return outs if len(outs) > 1 else outs[0]
+
+    def deheadify(self, *xs):
+        outs = []
+        for x in xs:
+            N, _, win, _ = x.shape
+            outs.append(x.permute(0, 2, 1, 3).contiguous().view(N, win, -1))
+        return outs if len(outs) > 1 else outs[0]
+
+    def attention(self, q, k, v, C, attn_drop=0., pe=0):
+        """Stock-torch attention on explicit [N,h,L,d] tensors (API compatibility only)."""
+        p = ((q @ k.transpose(-2, -1)) * (C // self.num_heads) ** -0.5 + pe).softmax(dim=-1)
+        return F.dropout(p, p=attn_drop, training=self.training) @ v
+
+
+def _check_no_attn_dropout(p, training):
+    if p and training:
+        raise NotImplementedError(
+            "attention dropout inside the fused window-attention kernel is not built; "
+            "set attn_drop = 0 (the reference's DSWT blocks use 0, DSwinT_arch.py:321)")
+
+
+class WindowedMSA(WindowedAttention):
+    """DSwinT_arch.py:320-338.  qkv Linear on the un-partitioned [B,H,W,C] tensor (a Linear is
+    per token, so it commutes with the partition), one fused attention kernel that cuts the
+    windows by address arithmetic (per-head interleaved q|k|v layout, :335), out_proj."""
+
+    def __init__(self, window_size, dim, num_heads=4, attn_drop=0., proj_drop=0.):
+        super().__init__(window_size, dim, num_heads)
+        self.win = window_size
+        self.num_heads = num_heads
+        self.attn_drop = attn_drop
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.pe = RelativePositionalEncoding(q_size=self.win, k_size=self.win, num_heads=num_heads)
+        self.out_proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, H, W, C = x.shape
+        _check_no_attn_dropout(self.attn_drop, self.training)
+        qkv = self.qkv(x)
+        z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W))
+        return self.out_proj(z)
+
+
+class DeformableSparseWindowAttention(WindowedAttention):
+    """DSwinT_arch.py:174-317, NHWC throughout (the reference's NCHW round trip at :259/:317
+    is gone).  Kernels: window selection, bilinear window gather, fused attention, gated
+    scatter-mean write-back.  The sparse discriminator, the two Linears and out_conv stay torch
+    ops on channels-last views."""
+
+    def __init__(self, window_size, dim, num_heads):
+        super().__init__(window_size, dim, num_heads)
+        self.temperature = 1.0
+        self.w = window_size
+        self.num_win_selected = 0.25
+        self.sparse_discriminator = nn.Sequential(
+            nn.Conv2d(dim, 4, 3, 1, 1),
+            nn.SiLU(),
+            nn.Conv2d(4, 4, self.w, stride=self.w),
+            nn.SiLU(),
+            nn.Conv2d(4, 4, 3, 1, 1),
+        )
+        gh, gw = torch.meshgrid(torch.arange(window_size), torch.arange(window_size), indexing="ij")
+        self.register_buffer("win_grid", torch.stack([gh, gw], dim=0), persistent=False)
+        self.in_proj = nn.Linear(dim, 3 * dim)
+        self.pe = RelativePositionalEncoding(q_size=self.w, k_size=self.w, num_heads=num_heads)
+        self.out_proj = nn.Linear(dim, dim)
+        self.out_conv = nn.Conv2d(dim, dim, 3, 1, 1, groups=dim)
+        # explicit Gumbel noise [B, Hw*Ww] for the next training forward (tests / reproducible
+        # runs); None = draw it the way F.gumbel_softmax does (DSwinT_arch.py:211)
+        self.gumbel_noise = None
+        self.last_selection = None
+
+    def _noise(self, scores_flat):
+        if not self.training:
+            return None
+        if self.gumbel_noise is not None:
+            return self.gumbel_noise.to(scores_flat.device)
+        return -torch.empty_like(scores_flat, memory_format=torch.legacy_contiguous_format).exponential_().log()
+
+    def forward(self, x):
+        B, H, W, C = x.shape
+        w = self.w
+        x = x.contiguous()
+        x_nchw = x.permute(0, 3, 1, 2)  # channels-last view, no copy
+        sd = self.sparse_discriminator(x_nchw).contiguous()
+        Hw, Ww = sd.shape[2], sd.shape[3]
+        k = int((Hw * Ww) * self.num_win_selected)
+        self.last_selection = None
+        if k == 0:  # DSwinT_arch.py:273-274
+            return x
+        sig = sd[:, 1:].sigmoid()
+        noise = self._noise(sd[:, 0].reshape(B, -1))
+        sel = K.select_windows(sd, sig, noise, self.temperature, k, w, H, W)
+        self.last_selection = sel
+        if sel.n == 0:  # DSwinT_arch.py:291-292
+            return x
+        act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if act not in (torch.float32, torch.bfloat16):
+            act = x.dtype
+        before = K.gather_windows(x, sel, w, out_dtype=act)              # [n, L, C]
+        qkv = self.in_proj(before)
+        z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED)
+        after = self.out_proj(z)
+        y = K.scatter_mean_residual(x, after, sel, w)                     # [B,H,W,C]
+        out = self.out_conv(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        return out.contiguous()

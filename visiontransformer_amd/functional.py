@@ -1,0 +1,247 @@
+"""torch.autograd Functions over the C ABI of libdswin_hip.so.
+
+Each Function allocates its outputs with torch (so memory stays in the caching allocator),
+passes raw device pointers and the current HIP stream to the library, and saves for backward
+exactly what the backward kernels read.  Nothing here computes on the CPU.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import call, dtype_code, ptr, stream
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+
+
+@dataclass
+class Selection:
+    """Outcome of the window selection for one DS-MSA call (all tensors on the GPU).
+
+    n            number of windows that passed the hard gate (host int)
+    win_b/cell/h1/w1  int32 [n]: image, source grid cell (flat), top-left corner
+    cellmap      int32 [B,Hw,Ww]: window id started from that cell, or -1
+    scores_delta, gates_delta  fp32 [n] straight-through values (differentiable)
+    cand_idx, cand_pass  int32 [B,k]: top-k cells by descending probability, gate decision
+    probs        fp32 [B,Hw*Ww]
+    """
+    n: int
+    win_b: torch.Tensor
+    win_cell: torch.Tensor
+    win_h1: torch.Tensor
+    win_w1: torch.Tensor
+    cellmap: torch.Tensor
+    scores_delta: torch.Tensor
+    gates_delta: torch.Tensor
+    cand_idx: torch.Tensor
+    cand_pass: torch.Tensor
+    probs: torch.Tensor
+
+
+class _SelectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sd, sig, noise, tau, k, w, H, W):
+        _lib.require_cuda(sd, sig, noise)
+        B, four, Hw, Ww = sd.shape
+        assert four == 4 and sig.shape == (B, 3, Hw, Ww) and sig.dtype == sd.dtype
+        sd = sd.contiguous()
+        sig = sig.contiguous()
+        n = Hw * Ww
+        dev = sd.device
+        if noise is not None:
+            noise = noise.to(torch.float32).contiguous()
+            assert noise.shape == (B, n)
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        probs = torch.empty(B, n, **f32)
+        cand_idx = torch.empty(B, k, **i32)
+        cand_p = torch.empty(B, k, **f32)
+        cand_pass = torch.empty(B, k, **i32)
+        n_pass = torch.empty(1, **i32)
+        win = torch.empty(4, B * k, **i32)
+        deltas = torch.empty(2, B * k, **f32)
+        cellmap = torch.empty(B, Hw, Ww, **i32)
+        call("dsw_select_fwd", ptr(sd), ptr(sig), dtype_code(sd.dtype), ptr(noise), _c_float(tau),
+             B, Hw, Ww, k, w, H, W, ptr(probs), ptr(cand_idx), ptr(cand_p), ptr(cand_pass), ptr(n_pass),
+             ptr(win[0]), ptr(win[1]), ptr(win[2]), ptr(win[3]), ptr(deltas[0]), ptr(deltas[1]),
+             ptr(cellmap), stream(dev))
+        npass = int(n_pass.item())  # the one host sync of a DS-MSA call (the reference has two)
+        win_b, win_cell, win_h1, win_w1 = (win[i, :npass].contiguous() for i in range(4))
+        scores_delta = deltas[0, :npass].contiguous()
+        gates_delta = deltas[1, :npass].contiguous()
+        ctx.save_for_backward(probs, win_b, win_cell)
+        ctx.meta = (tau, B, Hw, Ww, npass, sd.dtype)
+        ctx.mark_non_differentiable(win_b, win_cell, win_h1, win_w1, cellmap, cand_idx, cand_pass, probs)
+        ctx.set_materialize_grads(True)
+        return scores_delta, gates_delta, win_b, win_cell, win_h1, win_w1, cellmap, cand_idx, cand_pass, probs
+
+    @staticmethod
+    def backward(ctx, d_scores_delta, d_gates_delta, *unused):
+        probs, win_b, win_cell = ctx.saved_tensors
+        tau, B, Hw, Ww, npass, dt = ctx.meta
+        dev = probs.device
+        n = Hw * Ww
+        grads = torch.empty(2, B, n, dtype=torch.float32, device=dev)
+        dsd = d_scores_delta.to(torch.float32).contiguous()
+        dgd = d_gates_delta.to(torch.float32).contiguous()
+        call("dsw_select_bwd", ptr(probs), ptr(dsd), ptr(dgd), ptr(win_b), ptr(win_cell), npass, _c_float(tau),
+             B, Hw, Ww, ptr(grads[0]), ptr(grads[1]), stream(dev))
+        d_sd = torch.zeros(B, 4, Hw, Ww, dtype=dt, device=dev)
+        d_sd[:, 0] = grads[0].view(B, Hw, Ww).to(dt)
+        d_sig = torch.zeros(B, 3, Hw, Ww, dtype=dt, device=dev)  # offsets (channels 1, 2) get no gradient
+        d_sig[:, 0] = grads[1].view(B, Hw, Ww).to(dt)
+        return d_sd, d_sig, None, None, None, None, None, None
+
+
+def select_windows(sd, sig, noise, tau, k, w, H, W):
+    """Top-k + hard gate + compaction + corners (DSwinT_arch.py:201-237, :280-295)."""
+    out = _SelectFn.apply(sd, sig, noise, float(tau), int(k), int(w), int(H), int(W))
+    sdl, gdl, win_b, win_cell, win_h1, win_w1, cellmap, cand_idx, cand_pass, probs = out
+    return Selection(n=win_b.numel(), win_b=win_b, win_cell=win_cell, win_h1=win_h1, win_w1=win_w1,
+                     cellmap=cellmap, scores_delta=sdl, gates_delta=gdl, cand_idx=cand_idx,
+                     cand_pass=cand_pass, probs=probs)
+
+
+class _GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, win_b, win_h1, win_w1, cellmap, w, out_dtype):
+        _lib.require_cuda(x)
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        n = win_b.numel()
+        out = torch.empty(n, w * w, C, dtype=out_dtype, device=x.device)
+        call("dsw_gather_fwd", ptr(x), dtype_code(x.dtype), ptr(win_b), ptr(win_h1), ptr(win_w1), n,
+             B, H, W, C, w, ptr(out), dtype_code(out_dtype), stream(x.device))
+        ctx.save_for_backward(cellmap, win_h1, win_w1)
+        ctx.meta = (B, H, W, C, w, n, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cellmap, win_h1, win_w1 = ctx.saved_tensors
+        B, H, W, C, w, n, xdt = ctx.meta
+        dout = dout.contiguous()
+        dx = torch.empty(B, H, W, C, dtype=xdt, device=dout.device)
+        call("dsw_gather_bwd", ptr(dout), dtype_code(dout.dtype), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
+             B, H, W, C, w, ptr(dx), dtype_code(xdt), stream(dout.device))
+        return dx, None, None, None, None, None, None
+
+
+def gather_windows(x, sel, w, out_dtype=None):
+    """roi_align of the selected windows straight from NHWC to [n, w*w, C]
+    (DSwinT_arch.py:259, :297, :303)."""
+    return _GatherFn.apply(x, sel.win_b, sel.win_h1, sel.win_w1, sel.cellmap, int(w), out_dtype or x.dtype)
+
+
+class _ScatterMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, w):
+        _lib.require_cuda(x, after)
+        x = x.contiguous()
+        after = after.contiguous()
+        gates_delta = gates_delta.to(torch.float32).contiguous()
+        scores_delta = scores_delta.to(torch.float32).contiguous()
+        B, H, W, C = x.shape
+        n = win_b.numel()
+        y = torch.empty_like(x)
+        call("dsw_scatter_mean_fwd", ptr(x), dtype_code(x.dtype), ptr(after), dtype_code(after.dtype),
+             ptr(gates_delta), ptr(scores_delta), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
+             B, H, W, C, w, ptr(y), dtype_code(y.dtype), stream(x.device))
+        ctx.save_for_backward(x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1)
+        ctx.w = w
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1 = ctx.saved_tensors
+        w = ctx.w
+        B, H, W, C = x.shape
+        n = win_b.numel()
+        dy = dy.contiguous()
+        dev = dy.device
+        dx = torch.empty_like(x)
+        d_after = torch.empty_like(after)
+        dg = torch.empty(2, n, dtype=torch.float32, device=dev)
+        partial = torch.empty(2 * n * w, dtype=torch.float32, device=dev)
+        call("dsw_scatter_mean_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype),
+             ptr(after), dtype_code(after.dtype), ptr(gates_delta), ptr(scores_delta), ptr(cellmap),
+             ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, ptr(dx), dtype_code(dx.dtype),
+             ptr(d_after), dtype_code(d_after.dtype), ptr(dg[0]), ptr(dg[1]), ptr(partial), stream(dev))
+        return dx, d_after, dg[0], dg[1], None, None, None, None, None
+
+
+def scatter_mean_residual(x, after, sel, w):
+    """x + mean over covering windows of (after - roi_align(x)) * gates * scores
+    (DSwinT_arch.py:308-315), NHWC in and out."""
+    return _ScatterMeanFn.apply(x, after, sel.gates_delta, sel.scores_delta, sel.cellmap, sel.win_b,
+                                sel.win_h1, sel.win_w1, int(w))
+
+
+class _WinAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, table, lepe_w, lepe_b, layout, n_img, H, W, w, heads, scale):
+        _lib.require_cuda(qkv)
+        qkv = qkv.contiguous()
+        C3 = qkv.shape[-1]
+        C = C3 // 3
+        rows = qkv.numel() // C3
+        L = w * w
+        n_win = n_img * (H // w) * (W // w) if H else n_img
+        assert rows == n_win * L, "qkv rows %d != windows %d * %d" % (rows, n_win, L)
+        dev = qkv.device
+        tab = None if table is None else table.detach().to(torch.float32).contiguous()
+        lw = None if lepe_w is None else lepe_w.detach().to(torch.float32).reshape(C, 9).contiguous()
+        lb = None if lepe_b is None else lepe_b.detach().to(torch.float32).contiguous()
+        out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=dev)
+        lse = torch.empty(n_win, heads, L, dtype=torch.float32, device=dev)
+        call("dsw_win_attn_fwd", ptr(qkv), dtype_code(qkv.dtype), layout, n_img, H, W, w, C, heads, ptr(tab),
+             _c_float(scale), ptr(lw), ptr(lb), ptr(out), ptr(lse), stream(dev))
+        ctx.save_for_backward(qkv, out, lse, tab, lw, lb)
+        ctx.meta = (layout, n_img, H, W, w, C, heads, scale,
+                    None if table is None else (table.shape, table.dtype),
+                    None if lepe_w is None else (lepe_w.shape, lepe_w.dtype, lepe_b.dtype))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, tab, lw, lb = ctx.saved_tensors
+        layout, n_img, H, W, w, C, heads, scale, tmeta, lmeta = ctx.meta
+        dev = qkv.device
+        dout = dout.contiguous()
+        if dout.dtype != qkv.dtype:
+            dout = dout.to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        d_tab = None if tab is None else torch.empty_like(tab)
+        d_lw = None if lw is None else torch.empty_like(lw)
+        d_lb = None if lb is None else torch.empty_like(lb)
+        lib = _lib.load()
+        nbytes = lib.dsw_win_attn_bwd_workspace(n_img, H, W, w, C, heads, int(tab is not None), int(lw is not None))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        call("dsw_win_attn_bwd", ptr(qkv), ptr(out), ptr(dout), dtype_code(qkv.dtype), layout, n_img, H, W, w, C,
+             heads, ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(lse), ptr(dqkv), ptr(d_tab), ptr(d_lw),
+             ptr(d_lb), ptr(ws), ctypes.c_size_t(int(nbytes)), stream(dev))
+        g_tab = None if tab is None else d_tab.view(tmeta[0]).to(tmeta[1])
+        g_lw = None if lw is None else d_lw.view(lmeta[0]).to(lmeta[1])
+        g_lb = None if lb is None else d_lb.to(lmeta[2])
+        return dqkv, g_tab, g_lw, g_lb, None, None, None, None, None, None, None
+
+
+def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w=None, lepe_b=None):
+    """softmax(q k^T * scale + bias) v per (window, head), de-headified.
+
+    qkv [..., 3C].  grid=(B, H, W): tokens are the pixels of B images, windows are cut out by
+    address arithmetic and the result keeps the image layout.  grid=None: qkv is [n, w*w, 3C],
+    windows already contiguous.  table: [(2w-1)^2, heads] relative-position bias or None.
+    lepe_w/lepe_b: depthwise 3x3 conv [C,1,3,3]/[C] applied to V inside each window and added.
+    """
+    C = qkv.shape[-1] // 3
+    if scale is None:
+        scale = float((C // heads) ** -0.5)
+    if grid is None:
+        n_img, H, W = qkv.shape[0], 0, 0
+    else:
+        n_img, H, W = grid
+    return _WinAttnFn.apply(qkv, table, lepe_w, lepe_b, int(layout), int(n_img), int(H), int(W), int(w),
+                            int(heads), float(scale))
