@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Benchmark of the DS-MSA / windowed-MSA hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "config B"): one DSWT attention pair - WindowedMSA followed
+by DeformableSparseWindowAttention, default model config (C=180, 6 heads, 16x16 windows) - forward
+and backward under bf16 autocast on a batch of 32 LR patches of 64x64 (activations [32,64,64,180]
+fp32, as the reference's ViTBlock feeds them).  A step = one forward + backward of that pair.
+value = patches/s over all ranks.  Synthetic inputs, random-init weights (gates biased open so
+that the selected windows pass), explicit Gumbel noise.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, the pair wrapped in DistributedDataParallel over RCCL
+(backend "nccl"), per-GPU batch fixed (weak scaling).
+
+The JSON line also carries
+  roofline     - the dominant kernel (fused window-attention backward at the WMSA shape),
+                 algorithmic FLOPs / its measured launch time against the dense bf16 MFMA peak;
+  kernels      - the same measurement for every kernel of the path (GB/s or TFLOP/s);
+  cpu_baseline - the CPU oracle (a PyTorch restatement of the reference) timed on this host's
+                 cores on a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+B_PER_GPU, HW, C, HEADS, WIN = 32, 64, 180, 6, 16
+
+
+def build_pair(device, seed=0):
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention, WindowedMSA
+    torch.manual_seed(seed)
+
+    class Pair(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.wmsa = WindowedMSA(WIN, C, HEADS)
+            self.sdwa = DeformableSparseWindowAttention(WIN, C, HEADS)
+
+        def forward(self, x):
+            # residual form of the reference's ViTBlock (DSwinT_arch.py:355-356): the fp32 stream
+            # feeds both attentions
+            x = x + self.wmsa(x)
+            return x + self.sdwa(x)
+
+    m = Pair()
+    with torch.no_grad():
+        for mod in (m.wmsa, m.sdwa):
+            mod.pe.relative_position_bias_table.normal_(0, 0.02)
+        m.sdwa.sparse_discriminator[4].bias[1] += 1.0   # "dense" run: gates open
+        m.sdwa.sparse_discriminator[4].weight.mul_(4.0)  # spread offsets over the window
+    return m.to(device).train()
+
+
+def time_calls(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per call
+
+
+def kernel_rooflines(device, iters=20):
+    """Per-kernel achieved rate at config B shapes, measured with events on the launch stream."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
+    torch.manual_seed(1)
+    L = WIN * WIN
+    T = B_PER_GPU * HW * HW
+    out = {}
+    bf = torch.bfloat16
+    table = torch.randn((2 * WIN - 1) ** 2, HEADS, device=device) * 0.02
+    # windowed MSA shape: all 512 windows, image grid addressing
+    qkv = torch.randn(B_PER_GPU, HW, HW, 3 * C, device=device).to(bf).requires_grad_()
+    tab = table.clone().requires_grad_()
+    o = K.window_attention(qkv, tab, WIN, HEADS, QKV_INTERLEAVED, grid=(B_PER_GPU, HW, HW))
+    do = torch.randn_like(o)
+    t_f = time_calls(lambda: K.window_attention(qkv.detach(), table, WIN, HEADS, QKV_INTERLEAVED,
+                                                grid=(B_PER_GPU, HW, HW)), iters)
+    t_b = time_calls(lambda: torch.autograd.grad(o, (qkv, tab), do, retain_graph=True), iters)
+    flops_f, flops_b = 4.0 * T * L * C, 8.0 * T * L * C
+    out["win_attn_fwd"] = dict(bound="mfma", achieved=flops_f / t_f / 1e12, peak=MFMA_BF16_PEAK_TFLOPS,
+                               unit="TFLOP/s", us=t_f * 1e6, algorithmic=flops_f)
+    out["win_attn_bwd"] = dict(bound="mfma", achieved=flops_b / t_b / 1e12, peak=MFMA_BF16_PEAK_TFLOPS,
+                               unit="TFLOP/s", us=t_b * 1e6, algorithmic=flops_b)
+    # DS-MSA side: 128 windows (k = 4 per image, all passing), random corners
+    x = torch.randn(B_PER_GPU, HW, HW, C, device=device)
+    sd = torch.randn(B_PER_GPU, 4, HW // WIN, HW // WIN, device=device)
+    sd[:, 1] = 4.0
+    sig = sd[:, 1:].sigmoid()
+    sel = K.select_windows(sd, sig, None, 1.0, 4, WIN, HW, HW)
+    n = sel.n
+    t_s = time_calls(lambda: K.select_windows(sd, sig, None, 1.0, 4, WIN, HW, HW), iters)
+    out["select"] = dict(bound="latency", us=t_s * 1e6)
+    xs = x.clone().requires_grad_()
+    g = K.gather_windows(xs, sel, WIN, out_dtype=bf)
+    t_g = time_calls(lambda: K.gather_windows(x, sel, WIN, out_dtype=bf), iters)
+    dg = torch.randn_like(g)
+    t_gb = time_calls(lambda: torch.autograd.grad(g, xs, dg, retain_graph=True), iters)
+    by_g = n * C * ((WIN + 1) ** 2 * 4 + L * 2)
+    by_gb = n * C * L * 2 + B_PER_GPU * HW * HW * C * 4
+    out["gather_fwd"] = dict(bound="hbm", achieved=by_g / t_g / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t_g * 1e6,
+                             algorithmic=by_g)
+    out["gather_bwd"] = dict(bound="hbm", achieved=by_gb / t_gb / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t_gb * 1e6,
+                             algorithmic=by_gb)
+    after = torch.randn(n, L, C, device=device).to(bf).requires_grad_()
+    y = K.scatter_mean_residual(xs, after, sel, WIN)
+    t_sc = time_calls(lambda: K.scatter_mean_residual(x, after.detach(), sel, WIN), iters)
+    dy = torch.randn_like(y)
+    t_scb = time_calls(lambda: torch.autograd.grad(y, (xs, after), dy, retain_graph=True), iters)
+    by_sc = n * C * L * 2 + 2 * B_PER_GPU * HW * HW * C * 4
+    by_scb = 2 * B_PER_GPU * HW * HW * C * 4 + n * C * L * (2 + 2) + n * C * (WIN + 1) ** 2 * 4
+    out["scatter_mean_fwd"] = dict(bound="hbm", achieved=by_sc / t_sc / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                   us=t_sc * 1e6, algorithmic=by_sc)
+    out["scatter_mean_bwd"] = dict(bound="hbm", achieved=by_scb / t_scb / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                   us=t_scb * 1e6, algorithmic=by_scb)
+    for v in out.values():
+        if "achieved" in v:
+            v["frac"] = v["achieved"] / v["peak"]
+    return out
+
+
+def cpu_baseline(sample_batch=4, iters=3):
+    """The CPU oracle on this host's cores: the same pair, fp32, forward + backward, on a
+    bounded sample (a fraction of the batch) so that the default run stays within minutes."""
+    from oracle import dswin_oracle as D
+    cores = os.cpu_count() or 1
+    threads = min(cores, 16)
+    torch.set_num_threads(threads)
+    m = build_pair(torch.device("cpu"))
+    Pw = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.wmsa.state_dict().items()}
+    Ps = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.sdwa.state_dict().items()}
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(sample_batch, HW, HW, C, generator=gen).requires_grad_()
+    noise = D.gumbel_noise((sample_batch, (HW // WIN) ** 2), gen)
+
+    def step():
+        y = D.dsmsa_forward(Ps, D.wmsa_forward(Pw, x, WIN, HEADS), WIN, HEADS, training=True, noise=noise)
+        y.sum().backward()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return dict(value=sample_batch / dt, unit="patches/s", cores=threads, kind="port",
+                sample="CPU oracle (PyTorch restatement of DSwinT_arch.py WindowedMSA + DS-MSA), fp32, fwd+bwd, "
+                       "batch %d of 64x64x180, %d iters, %.2f s/iter" % (sample_batch, iters, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from visiontransformer_amd import _lib
+    _lib.load()
+    model = build_pair(device)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+    pair = model.module if world > 1 else model
+    gen = torch.Generator(device=device).manual_seed(100 + rank)
+    x = torch.randn(B_PER_GPU, HW, HW, C, device=device, generator=gen).requires_grad_()
+    pair.sdwa.gumbel_noise = -torch.empty(B_PER_GPU, (HW // WIN) ** 2, device=device).exponential_(generator=gen).log()
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(x)
+        y.float().sum().backward()
+        model.zero_grad(set_to_none=True)
+        x.grad = None
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_pass = pair.sdwa.last_selection.n if pair.sdwa.last_selection is not None else 0
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        line = {
+            "metric": "training patches/sec (DSWT WindowedMSA + DS-MSA attention pair, fwd+bwd)",
+            "value": world * B_PER_GPU * args.steps / dt,
+            "unit": "patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "B: DSWT WindowedMSA+DS-MSA fwd+bwd, batch 32 x 64x64 LR patches, C=180, 6 heads, "
+                                   "16x16 windows, bf16 autocast, k=4 windows/image (num_win_selected 0.25), "
+                                   "%d of %d candidate windows passed the gate" % (n_pass, B_PER_GPU * 4),
+                       "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world},
+        }
+        if not args.no_kernels:
+            ks = kernel_rooflines(device)
+            dom = ks["win_attn_bwd"]
+            line["roofline"] = {"bound": "mfma", "kernel": "win_attn_bwd_kernel<bf16,w16,d32>", "achieved": dom["achieved"],
+                                "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                                "us_per_launch": dom["us"]}
+            line["kernels"] = ks
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,8 +154,9 @@ class DeformableSparseWindowAttention(WindowedAttention):
         B, H, W, C = x.shape
         w = self.w
         x = x.contiguous()
-        x_nchw = x.permute(0, 3, 1, 2)  # channels-last view, no copy
-        sd = self.sparse_discriminator(x_nchw).contiguous()
+        # MIOpen's channels-last convolutions fall back to naive kernels for these shapes (tens of
+        # ms per call on MI355X), so the two torch convolutions get NCHW copies like the reference
+        sd = self.sparse_discriminator(x.permute(0, 3, 1, 2).contiguous()).contiguous()
         Hw, Ww = sd.shape[2], sd.shape[3]
         k = int((Hw * Ww) * self.num_win_selected)
         self.last_selection = None
@@ -175,5 +176,5 @@ class DeformableSparseWindowAttention(WindowedAttention):
         z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED)
         after = self.out_proj(z)
         y = K.scatter_mean_residual(x, after, sel, w)                     # [B,H,W,C]
-        out = self.out_conv(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        out = self.out_conv(y.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1)
         return out.contiguous()
