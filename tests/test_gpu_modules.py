@@ -94,3 +94,72 @@ def test_dsmsa_bf16_autocast_against_fp32(cuda0):
     if s32.n == s16.n and torch.equal(s32.win_cell, s16.win_cell) and torch.equal(s32.win_h1, s16.win_h1) \
             and torch.equal(s32.win_w1, s16.win_w1):
         assert rel_err(y16, y32) < 2e-2
+
+
+# ----------------------------------------------------------------------------------------------
+# MSFT
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("msft_wmsa"))
+def test_msft_wmsa_golden(cuda0, name):
+    from visiontransformer_amd.msft import WindowedMSA
+    g, m = load_golden(name)
+    mod = _load_into(WindowedMSA(m["w"], m["C"], m["heads"], attn_drop=0.0), g, cuda0)
+    x = g["x"].to(cuda0).requires_grad_()
+    y = mod(x, m["H"], m["W"])
+    assert rel_err(y, g["y"]) < TOL
+    _check_grads(mod, g, x, y, cuda0)
+
+
+@pytest.mark.parametrize("name", ["msft_patch_merging", "msft_patch_unmerging"])
+def test_msft_patch_golden(cuda0, name):
+    from visiontransformer_amd import msft
+    g, m = load_golden(name)
+    cls = msft.PatchMerging if m["kind"].endswith("PatchMerging") else msft.PatchUnMerging
+    mod = _load_into(cls(m["dim"], m["scale"]), g, cuda0)
+    x = g["x"].to(cuda0).requires_grad_()
+    y = mod(x)
+    assert y.shape == g["y"].shape
+    assert rel_err(y, g["y"]) < TOL
+    _check_grads(mod, g, x, y, cuda0)
+
+
+def test_msft_vitblock_golden(cuda0):
+    from visiontransformer_amd.msft import ViTBlock
+    g, m = load_golden("msft_vitblock")
+    mod = _load_into(ViTBlock(m["w"], m["C"], n_heads=m["heads"]), g, cuda0).eval()
+    x = g["x"].to(cuda0).requires_grad_()
+    y = mod(x)
+    assert rel_err(y, g["y"]) < TOL
+    _check_grads(mod, g, x, y, cuda0)
+
+
+def test_msft_wmsa_bf16(cuda0):
+    """bf16 run of the msft attention against its own fp32 run (2e-2)."""
+    from visiontransformer_amd.msft import WindowedMSA
+    torch.manual_seed(3)
+    mod = WindowedMSA(8, 96, 6, attn_drop=0.0).to(cuda0)
+    x = torch.randn(2, 32 * 32, 96, device=cuda0, requires_grad=True)
+    y32 = mod(x, 32, 32)
+    g32, = torch.autograd.grad(y32.sum(), x)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y16 = mod(x, 32, 32)
+    g16, = torch.autograd.grad(y16.float().sum(), x)
+    assert y16.dtype == torch.bfloat16
+    assert rel_err(y16, y32) < 2e-2
+    assert rel_err(g16, g32) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("s", [1, 2, 4])
+def test_reshape_kernels_exact(cuda0, dtype, s):
+    """pure data movement: bit-exact against torch's PixelUnshuffle / PixelShuffle + permute"""
+    import torch.nn.functional as F
+    from visiontransformer_amd import functional as K
+    gen = torch.Generator().manual_seed(s)
+    x = torch.randn(2, 6, 16 * s, 20 * s, generator=gen).to(dtype).to(cuda0)
+    ref = F.pixel_unshuffle(x, s).permute(0, 2, 3, 1).contiguous()
+    got = K.unshuffle_nhwc(x, s)
+    assert torch.equal(got, ref)
+    t = torch.randn(2, 16, 20, 6 * s * s, generator=gen).to(dtype).to(cuda0)
+    ref2 = F.pixel_shuffle(t.permute(0, 3, 1, 2).contiguous(), s)
+    assert torch.equal(K.shuffle_nchw(t, s), ref2)

@@ -40,7 +40,7 @@ template <typename T, int WS, int DP> struct BwdCfg {
     static constexpr int N_QBT = BF ? DP * TQS : 0;
     static constexpr size_t lds_bytes(bool bias) {
         return (size_t)(N_K + N_DS + 2 * N_QB + 2 * N_QBT) * sizeof(T) + (size_t)2 * L * sizeof(float) +
-               (bias ? (size_t)(1 + NW) * bias_lds<WS>::FLOATS * sizeof(float) : 0);
+               (bias ? (size_t)bias_lds<WS>::FLOATS * sizeof(float) : 0);
     }
     static constexpr int MIN_WAVES = (BF && !(WS == 16 && DP == 64)) ? 2 : 1;
 };
@@ -67,7 +67,7 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     AttnGeom g, const T *__restrict__ qkv, const T *__restrict__ out, const T *__restrict__ dout,
     const float *__restrict__ table, float scale, const float *__restrict__ lepe_w,
     const float *__restrict__ lepe_b, const float *__restrict__ lse, T *__restrict__ dqkv,
-    float *__restrict__ ws_table, float *__restrict__ ws_lepe) {
+    float *__restrict__ ws_table, const float *__restrict__ delta_in) {
     using Cfg = BwdCfg<T, WS, DP>;
     constexpr bool BF = Cfg::BF;
     constexpr int L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, KT = Cfg::KT, THREADS = Cfg::THREADS;
@@ -83,7 +83,6 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     float *delta_s = reinterpret_cast<float *>(dObt + Cfg::N_QBT);  // [L]
     float *lse_s = delta_s + L;                                     // [L], already times log2(e)
     float *tb = lse_s + L;                                          // BIAS: [TBF]
-    float *dtb = tb + TBF;                                          // BIAS: [NW][TBF]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
@@ -105,32 +104,91 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     }
     auto trow = [&](int l) -> size_t { return origin + (size_t)(l / WS) * pitch + (l % WS); };
 
-    // ---- prologue: K into LDS, delta / lse, bias tables ----------------------------------------
-    if constexpr (BF) {
-        for (int it = tid; it < L * DP; it += THREADS) {  // K^T[e][row]
-            const int row = it / DP, e = it - row * DP;
-            Kl[e * KTS + row] = (e < d) ? qkv[trow(row) * C3 + koff + e] : (T)0;
+    // Loads are issued in batches before any of them is consumed (a load-use-per-trip loop pays a
+    // full memory round trip per trip); the "pair" path moves two bf16 per lane and needs an even
+    // head dim, the "element" path is the general one (f32, odd head dims).
+    constexpr int DW = DP / 2;
+    const bool pair_path = BF && ((d & 1) == 0);  // uniform
+    const float sc2 = scale * LOG2E;
+    auto tof = [](T v) -> float {
+        if constexpr (BF) return bf16_to_f32(v);
+        else return v;
+    };
+    auto bits = [](T v) -> uint32_t {
+        if constexpr (BF) return (uint32_t)v;
+        else return __float_as_uint(v);
+    };
+
+    // ---- prologue: K into LDS, delta = rowsum(dO * O), lse, bias tables -------------------------
+    if (pair_path) {
+        if constexpr (BF) {
+            constexpr int ITER = L * DW / THREADS, BATCH = ITER < 8 ? ITER : 8;
+            for (int i0 = 0; i0 < ITER; i0 += BATCH) {
+                uint32_t kv[BATCH], ov[BATCH], gv[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int it = tid + (i0 + i) * THREADS;
+                    const int row = it / DW, ec = min((it - row * DW) * 2, d - 2);
+                    const size_t tr = trow(row);
+                    kv[i] = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + koff + ec);
+                    ov[i] = *reinterpret_cast<const uint32_t *>(out + tr * C + head * d + ec);
+                    gv[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + head * d + ec);
+                }
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int it = tid + (i0 + i) * THREADS;
+                    const int row = it / DW, e = (it - row * DW) * 2;
+                    const bool ok = e < d;
+                    const uint32_t k2 = ok ? kv[i] : 0u;
+                    Kl[e * KTS + row] = (T)(k2 & 0xffffu);
+                    Kl[(e + 1) * KTS + row] = (T)(k2 >> 16);
+                    float part = ok ? __uint_as_float(ov[i] << 16) * __uint_as_float(gv[i] << 16) +
+                                          __uint_as_float(ov[i] & 0xffff0000u) * __uint_as_float(gv[i] & 0xffff0000u)
+                                    : 0.f;
+#pragma unroll
+                    for (int o = 1; o < DW; o <<= 1) part += __shfl_xor(part, o, 64);
+                    if (e == 0) delta_s[row] = part;
+                }
+            }
         }
     } else {
-        for (int it = tid; it < L * DP; it += THREADS) {  // K[row][e]
-            const int row = it / DP, e = it - row * DP;
-            Kl[row * QS + e] = (e < d) ? qkv[trow(row) * C3 + koff + e] : (T)0;
+        constexpr int ITER = L * DP / THREADS, BATCH = 8;
+        for (int i0 = 0; i0 < ITER; i0 += BATCH) {
+            T kv[BATCH], ov[BATCH], gv[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int it = tid + (i0 + i) * THREADS;
+                const int row = it / DP, ec = min(it - row * DP, d - 1);
+                const size_t tr = trow(row);
+                kv[i] = qkv[tr * C3 + koff + ec];
+                ov[i] = out[tr * C + head * d + ec];
+                gv[i] = dout[tr * C + head * d + ec];
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int it = tid + (i0 + i) * THREADS;
+                const int row = it / DP, e = it - row * DP;
+                const bool ok = e < d;
+                if constexpr (BF) Kl[e * KTS + row] = ok ? kv[i] : (T)0;
+                else Kl[row * QS + e] = ok ? kv[i] : (T)0;
+                float part = ok ? tof(ov[i]) * tof(gv[i]) : 0.f;
+#pragma unroll
+                for (int o = 1; o < DP; o <<= 1) part += __shfl_xor(part, o, 64);
+                if (e == 0) delta_s[row] = part;
+            }
         }
     }
-    for (int row = tid; row < L; row += THREADS) {
-        const T *orow = out + trow(row) * C + head * d;
-        const T *grow = dout + trow(row) * C + head * d;
-        float acc = 0.f;
-        for (int e = 0; e < d; ++e) acc += io<T>::ld(orow + e) * io<T>::ld(grow + e);
-        delta_s[row] = acc;
-        lse_s[row] = lse[((size_t)win * g.heads + head) * L + row] * LOG2E;
+    for (int row = tid; row < L; row += THREADS) lse_s[row] = lse[((size_t)win * g.heads + head) * L + row] * LOG2E;
+    if (delta_in != nullptr) {
+        // LePE: `out` holds SDPA + LePE, so rowsum(dO * O_sdpa) was computed by the LePE pre-pass
+        __syncthreads();
+        for (int row = tid; row < L; row += THREADS) delta_s[row] = delta_in[((size_t)win * g.heads + head) * L + row];
     }
     if constexpr (BIAS) {
         for (int it = tid; it < TR * TR; it += THREADS) {
             const int di = it / TR, dj = it - di * TR;
             tb[di * TS + dj] = table[(size_t)it * g.heads + head] * LOG2E;
         }
-        for (int it = tid; it < NW * TBF; it += THREADS) dtb[it] = 0.f;
     }
 
     // this wave's K and V fragments (B operands: k-dim = head dim, column = key on the lane)
@@ -168,58 +226,82 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                 dVacc[kt][u][r] = 0.f;
             }
 
-    const float sc2 = scale * LOG2E;
-
-    for (int qb = 0; qb < NT; ++qb) {
-        __syncthreads();  // previous block's LDS reads are done (first pass: prologue writes land)
-        // ---- stage the block's Q and dO rows ----------------------------------------------------
-        if constexpr (BF) {
-            if ((d & 1) == 0) {
-                constexpr int DW = DP / 2;
-                for (int it = tid; it < 32 * DW; it += THREADS) {
+    // ---- the next block's Q and dO rows travel in registers while the current block computes ----
+    constexpr int NI_P = 32 * DW / THREADS, NI_E = 32 * DP / THREADS;
+    uint32_t nq[NI_E], ng[NI_E];
+    auto load_block = [&](int qb) {
+        if (pair_path) {
+#pragma unroll
+            for (int i = 0; i < NI_P; ++i) {
+                const int it = tid + i * THREADS;
+                const int row = it / DW, ec = min((it - row * DW) * 2, d - 2);
+                const size_t tr = trow(qb * 32 + row);
+                nq[i] = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + qoff + ec);
+                ng[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + head * d + ec);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI_E; ++i) {
+                const int it = tid + i * THREADS;
+                const int row = it / DP, ec = min(it - row * DP, d - 1);
+                const size_t tr = trow(qb * 32 + row);
+                nq[i] = bits(qkv[tr * C3 + qoff + ec]);
+                ng[i] = bits(dout[tr * C + head * d + ec]);
+            }
+        }
+    };
+    // Q is stored times scale*log2(e): S comes out of the MFMA in the base-2 domain, and dK picks
+    // up the inverse factor once, in the epilogue.
+    auto store_block = [&]() {
+        if (pair_path) {
+            if constexpr (BF) {
+#pragma unroll
+                for (int i = 0; i < NI_P; ++i) {
+                    const int it = tid + i * THREADS;
                     const int row = it / DW, e = (it - row * DW) * 2;
-                    const size_t tr = trow(qb * 32 + row);
-                    uint32_t qv = 0, gv = 0;
-                    if (e < d) {
-                        qv = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + qoff + e);
-                        gv = *reinterpret_cast<const uint32_t *>(dout + tr * C + head * d + e);
-                    }
-                    *reinterpret_cast<uint32_t *>(Qb + row * QS + e) = qv;
-                    *reinterpret_cast<uint32_t *>(dOb + row * QS + e) = gv;
-                    Qbt[e * TQS + row] = (T)(qv & 0xffffu);
-                    Qbt[(e + 1) * TQS + row] = (T)(qv >> 16);
-                    dObt[e * TQS + row] = (T)(gv & 0xffffu);
-                    dObt[(e + 1) * TQS + row] = (T)(gv >> 16);
+                    const bool ok = e < d;
+                    const uint32_t q2 = ok ? pack_bf16(__uint_as_float(nq[i] << 16) * sc2, __uint_as_float(nq[i] & 0xffff0000u) * sc2) : 0u;
+                    const uint32_t g2 = ok ? ng[i] : 0u;
+                    *reinterpret_cast<uint32_t *>(Qb + row * QS + e) = q2;
+                    *reinterpret_cast<uint32_t *>(dOb + row * QS + e) = g2;
+                    Qbt[e * TQS + row] = (T)(q2 & 0xffffu);
+                    Qbt[(e + 1) * TQS + row] = (T)(q2 >> 16);
+                    dObt[e * TQS + row] = (T)(g2 & 0xffffu);
+                    dObt[(e + 1) * TQS + row] = (T)(g2 >> 16);
                 }
-            } else {
-                for (int it = tid; it < 32 * DP; it += THREADS) {
-                    const int row = it / DP, e = it - row * DP;
-                    const size_t tr = trow(qb * 32 + row);
-                    T qv = 0, gv = 0;
-                    if (e < d) {
-                        qv = qkv[tr * C3 + qoff + e];
-                        gv = dout[tr * C + head * d + e];
-                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI_E; ++i) {
+                const int it = tid + i * THREADS;
+                const int row = it / DP, e = it - row * DP;
+                const bool ok = e < d;
+                if constexpr (BF) {
+                    const T qv = ok ? f32_to_bf16(bf16_to_f32((T)nq[i]) * sc2) : (T)0;
+                    const T gv = ok ? (T)ng[i] : (T)0;
                     Qb[row * QS + e] = qv;
                     dOb[row * QS + e] = gv;
                     Qbt[e * TQS + row] = qv;
                     dObt[e * TQS + row] = gv;
+                } else {
+                    Qb[row * QS + e] = ok ? __uint_as_float(nq[i]) * sc2 : 0.f;
+                    dOb[row * QS + e] = ok ? __uint_as_float(ng[i]) : 0.f;
                 }
-            }
-        } else {
-            for (int it = tid; it < 32 * DP; it += THREADS) {
-                const int row = it / DP, e = it - row * DP;
-                const size_t tr = trow(qb * 32 + row);
-                T qv = 0, gv = 0;
-                if (e < d) {
-                    qv = qkv[tr * C3 + qoff + e];
-                    gv = dout[tr * C + head * d + e];
-                }
-                Qb[row * QS + e] = qv;
-                dOb[row * QS + e] = gv;
             }
         }
+    };
+
+    constexpr int BG_N = (2 * WS - 1 + 7) / 8;  // bias-gradient entries (di values) per thread
+    float bgacc[BG_N];
+#pragma unroll
+    for (int n = 0; n < BG_N; ++n) bgacc[n] = 0.f;
+
+    load_block(0);
+    for (int qb = 0; qb < NT; ++qb) {
+        __syncthreads();  // previous block's LDS reads are done (first pass: prologue writes land)
+        store_block();
         __syncthreads();
+        if (qb + 1 < NT) load_block(qb + 1);
 
         // per-row constants of this lane's 16 accumulator rows: q = qb*32 + rho(r) + 4hh
         float lrow[16], drow[16];
@@ -233,11 +315,18 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         for (int kt = 0; kt < KT; ++kt) {
             const int tile = wave * KT + kt;
             const int key = 32 * tile + l31;
+            // table entry of (q, key): (qi-ki+w-1)*TS + (qj-kj+w-1); q = qb*32 + rho(r) + 4hh
+            const int ki = key / WS, kj = key - ki * WS;
+            const int lane_base = (WS - 1) * (TS + 1) - ki * TS - kj + 4 * hh + (qb * 32 / WS) * TS;
+            // accumulators start from the row constants: S' = S*log2e + bias - lse, dP' = dP - delta
             f32x16 sacc, pacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sacc[r] = 0.f;
-                pacc[r] = 0.f;
+                const int q_c = rho(r);
+                float v0 = -lrow[r];
+                if constexpr (BIAS) v0 += tb[lane_base + (q_c / WS) * TS + (q_c % WS)];
+                sacc[r] = v0;
+                pacc[r] = -drow[r];
             }
             // ---- S = Q K^T and dP = dO V^T (rows = queries, lane = key) ---------------------------
             if constexpr (BF) {
@@ -263,21 +352,13 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                     pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vff[kt][4 * s4 + 3], pacc, 0, 0, 0);
                 }
             }
-            // ---- P = exp2(S*sc2 + bias2 - lse2), dS = P * (dP - delta) -----------------------------
-            // table entry of (q, key): (qi-ki+w-1)*TS + (qj-kj+w-1); q = qb*32 + rho(r) + 4hh
-            const int ki = key / WS, kj = key - ki * WS;
-            const int lane_base = (WS - 1) * (TS + 1) - ki * TS - kj + 4 * hh + (qb * 32 / WS) * TS;
+            // ---- P = exp2(S'), dS = P * dP' ------------------------------------------------------------
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int q_c = rho(r);  // compile-time part of the query index inside the block
-                const int tix = lane_base + (q_c / WS) * TS + (q_c % WS);
-                float v = sacc[r] * sc2 - lrow[r];
-                if constexpr (BIAS) v += tb[tix];
-                const float p = __builtin_amdgcn_exp2f(v);
-                const float ds = p * (pacc[r] - drow[r]);
+                const float p = __builtin_amdgcn_exp2f(sacc[r]);
+                const float ds = p * pacc[r];
                 sacc[r] = p;
                 pacc[r] = ds;
-                if constexpr (BIAS) atomicAdd(&dtb[wave * TBF + tix], ds);
             }
             // ---- dS block to LDS for dQ ---------------------------------------------------------------
 #pragma unroll
@@ -317,6 +398,35 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             }
         }
         __syncthreads();  // the whole dS block is in LDS
+
+        // ---- d(bias table): every thread owns a few table entries (di, dj) and sums the dS elements
+        // of this block that map to them, straight from the dS tile - a gather in a fixed order,
+        // so no atomics and bitwise reproducible.  Lanes that differ in dj read neighbouring keys.
+        if constexpr (BIAS) {
+            const int dj = (tid % (2 * WS)) - (WS - 1);   // lane WS*2-1 of each group is idle
+            const int dig = tid / (2 * WS);                // 8 groups of di values
+            if (dj < WS) {
+#pragma unroll
+                for (int n = 0; n < BG_N; ++n) {
+                    const int di = dig + 8 * n - (WS - 1);
+                    if (di < WS) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int qr = 0; qr < 32 / WS; ++qr) {
+                            const int ki = qb * (32 / WS) + qr - di;
+                            if (ki >= 0 && ki < WS) {
+#pragma unroll
+                                for (int qj = 0; qj < WS; ++qj) {
+                                    const int kj = qj - dj;
+                                    if (kj >= 0 && kj < WS) acc += tof(dSs[(qr * WS + qj) * SS + ki * WS + kj]);
+                                }
+                            }
+                        }
+                        bgacc[n] += acc;
+                    }
+                }
+            }
+        }
 
         // ---- dQ block = dS K * scale: 16x16 output tiles, one (or more) per wave, K-dim = all keys ---
 #pragma unroll
@@ -365,8 +475,14 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                 for (int r = 0; r < 16; r += 2) {
                     const int e = 32 * u + rho(r) + 4 * hh;
                     if (e < d) {
-                        *reinterpret_cast<uint32_t *>(dkrow + e) = pack_bf16(dKacc[kt][u][r] * scale, dKacc[kt][u][r + 1] * scale);
-                        *reinterpret_cast<uint32_t *>(dvrow + e) = pack_bf16(dVacc[kt][u][r], dVacc[kt][u][r + 1]);
+                        float v0 = dVacc[kt][u][r], v1 = dVacc[kt][u][r + 1];
+                        if (delta_in != nullptr) {  // add the LePE share of dV left there by the pre-pass
+                            const uint32_t old = *reinterpret_cast<const uint32_t *>(dvrow + e);
+                            v0 += __uint_as_float(old << 16);
+                            v1 += __uint_as_float(old & 0xffff0000u);
+                        }
+                        *reinterpret_cast<uint32_t *>(dkrow + e) = pack_bf16(dKacc[kt][u][r] * LN2, dKacc[kt][u][r + 1] * LN2);
+                        *reinterpret_cast<uint32_t *>(dvrow + e) = pack_bf16(v0, v1);
                     }
                 }
             } else {
@@ -374,8 +490,10 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                 for (int r = 0; r < 16; ++r) {
                     const int e = 32 * u + rho(r) + 4 * hh;
                     if (e < d) {
-                        io<T>::st(dkrow + e, dKacc[kt][u][r] * scale);
-                        io<T>::st(dvrow + e, dVacc[kt][u][r]);
+                        float v0 = dVacc[kt][u][r];
+                        if (delta_in != nullptr) v0 += io<T>::ld(dvrow + e);
+                        io<T>::st(dkrow + e, dKacc[kt][u][r] * LN2);
+                        io<T>::st(dvrow + e, v0);
                     }
                 }
             }
@@ -383,15 +501,16 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     }
 
     if constexpr (BIAS) {
-        __syncthreads();
-        // natural-log gradient: the table was used times log2(e) inside exp2, d/dtable is dS itself
+        // the table entered the logits times log2(e) inside exp2, so d/dtable is dS itself
         float *dst = ws_table + ((size_t)win * g.heads + head) * (TR * TR);
-        for (int it = tid; it < TR * TR; it += THREADS) {
-            const int di = it / TR, dj = it - di * TR;
-            float acc = 0.f;
+        const int dj = (tid % (2 * WS)) - (WS - 1);
+        const int dig = tid / (2 * WS);
+        if (dj < WS) {
 #pragma unroll
-            for (int wv = 0; wv < NW; ++wv) acc += dtb[wv * TBF + di * TS + dj];
-            dst[it] = acc;
+            for (int n = 0; n < BG_N; ++n) {
+                const int di = dig + 8 * n - (WS - 1);
+                if (di < WS) dst[(di + WS - 1) * TR + dj + WS - 1] = bgacc[n];
+            }
         }
     }
 }
@@ -418,16 +537,135 @@ __global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float *__re
     }
 }
 
+// ---- LePE backward pre-pass (msft_arch.py:113-125, :136): one block per (window, head) -------------
+// With out = SDPA(q,k,v) + LePE(v):  delta = rowsum(dO * (out - LePE(v)))   (for the main kernel),
+// dV_lepe = conv^T(dO) written into the v slots of dqkv (the main kernel adds its dV on top),
+// and per-window partial sums of the depthwise weight / bias gradients.
+template <typename T, int WS>
+__global__ __launch_bounds__(256) void lepe_bwd_pre_kernel(AttnGeom g, const T *__restrict__ qkv, const T *__restrict__ out,
+                                                           const T *__restrict__ dout, const float *__restrict__ lepe_w,
+                                                           const float *__restrict__ lepe_b, T *__restrict__ dqkv,
+                                                           float *__restrict__ delta_out, float *__restrict__ ws_lepe) {
+    constexpr int L = WS * WS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int d = g.d, C = g.C, C3 = 3 * g.C;
+    T *Vs = reinterpret_cast<T *>(smem);  // [L][d]
+    T *Gs = Vs + L * d;                   // dO
+    T *Os = Gs + L * d;                   // out
+    float *wl = reinterpret_cast<float *>(Os + L * d + ((L * d) & 1));  // [d][10]: 9 taps + bias
+    const int tid = threadIdx.x;
+    const int win = blockIdx.x / g.heads, head = blockIdx.x - win * g.heads;
+    int qoff, koff, voff;
+    qkv_offsets(g, head, qoff, koff, voff);
+    size_t origin;
+    int pitch;
+    if (g.H == 0) {
+        origin = (size_t)win * L;
+        pitch = WS;
+    } else {
+        const int per = g.nWh * g.nWw;
+        const int b = win / per, r = win - b * per;
+        const int wr = r / g.nWw, wc = r - wr * g.nWw;
+        origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
+        pitch = g.W;
+    }
+    auto trow = [&](int l) -> size_t { return origin + (size_t)(l / WS) * pitch + (l % WS); };
+    for (int it = tid; it < L * d; it += 256) {
+        const int row = it / d, e = it - row * d;
+        const size_t tr = trow(row);
+        Vs[it] = qkv[tr * C3 + voff + e];
+        Gs[it] = dout[tr * C + head * d + e];
+        Os[it] = out[tr * C + head * d + e];
+    }
+    for (int it = tid; it < d * 10; it += 256) {
+        const int e = it / 10, k = it - e * 10;
+        wl[it] = k < 9 ? lepe_w[(size_t)(head * d + e) * 9 + k] : lepe_b[head * d + e];
+    }
+    __syncthreads();
+    // delta
+    for (int q = tid; q < L; q += 256) {
+        const int qi = q / WS, qj = q - qi * WS;
+        float acc = 0.f;
+        for (int e = 0; e < d; ++e) {
+            float lp = wl[e * 10 + 9];
+#pragma unroll
+            for (int a = -1; a <= 1; ++a)
+#pragma unroll
+                for (int bb = -1; bb <= 1; ++bb) {
+                    const int ni = qi + a, nj = qj + bb;
+                    if (ni >= 0 && ni < WS && nj >= 0 && nj < WS) lp += wl[e * 10 + (a + 1) * 3 + bb + 1] * io<T>::ld(Vs + (ni * WS + nj) * d + e);
+                }
+            acc += io<T>::ld(Gs + q * d + e) * (io<T>::ld(Os + q * d + e) - lp);
+        }
+        delta_out[((size_t)win * g.heads + head) * L + q] = acc;
+    }
+    // dV_lepe[k][e] = sum_taps W[e][tap] * dO[k - tap][e]
+    for (int it = tid; it < L * d; it += 256) {
+        const int k = it / d, e = it - k * d;
+        const int ki = k / WS, kj = k - ki * WS;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = -1; a <= 1; ++a)
+#pragma unroll
+            for (int bb = -1; bb <= 1; ++bb) {
+                const int ni = ki - a, nj = kj - bb;
+                if (ni >= 0 && ni < WS && nj >= 0 && nj < WS) acc += wl[e * 10 + (a + 1) * 3 + bb + 1] * io<T>::ld(Gs + (ni * WS + nj) * d + e);
+            }
+        io<T>::st(dqkv + trow(k) * C3 + voff + e, acc);
+    }
+    // weight / bias gradient partials of this window
+    for (int it = tid; it < d * 10; it += 256) {
+        const int e = it / 10, k = it - e * 10;
+        float acc = 0.f;
+        if (k == 9) {
+            for (int q = 0; q < L; ++q) acc += io<T>::ld(Gs + q * d + e);
+        } else {
+            const int a = k / 3 - 1, bb = k - (k / 3) * 3 - 1;
+            for (int q = 0; q < L; ++q) {
+                const int ni = q / WS + a, nj = q % WS + bb;
+                if (ni >= 0 && ni < WS && nj >= 0 && nj < WS) acc += io<T>::ld(Gs + q * d + e) * io<T>::ld(Vs + (ni * WS + nj) * d + e);
+            }
+        }
+        ws_lepe[((size_t)win * C + head * d + e) * 10 + k] = acc;
+    }
+}
+
+// d_lepe_w[c][tap], d_lepe_b[c] = sum over windows (ascending) of the partials
+__global__ void lepe_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int C, float *__restrict__ d_w,
+                                        float *__restrict__ d_b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 10) return;
+    float acc = 0.f;
+    for (int wdx = 0; wdx < n_win; ++wdx) acc += ws[(size_t)wdx * C * 10 + i];
+    const int c = i / 10, k = i - c * 10;
+    if (k < 9) d_w[c * 9 + k] = acc;
+    else d_b[c] = acc;
+}
+
 template <typename T, int WS, int DP>
 static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const void *dout, const float *table,
                       float scale, const float *lepe_w, const float *lepe_b, const float *lse, void *dqkv,
-                      float *d_table, float *ws_table, float *ws_lepe, hipStream_t st) {
+                      float *d_table, float *d_lepe_w, float *d_lepe_b, float *ws_table, float *ws_lepe,
+                      float *ws_delta, hipStream_t st) {
     using Cfg = BwdCfg<T, WS, DP>;
     const bool bias = table != nullptr, lepe = lepe_w != nullptr;
-    if (lepe) return fail(DSW_EUNSUPPORTED, "win_attn_bwd: LePE gradients are built in a separate kernel");
     const size_t lds = Cfg::lds_bytes(bias);
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "win_attn_bwd: w=%d head dim %d needs %zu B of LDS", WS, g.d, lds);
     const dim3 grid(g.n_win * g.heads), block(Cfg::THREADS);
+    int rc;
+    if (lepe) {
+        const size_t l2 = (size_t)(3 * Cfg::L * g.d + 1) * sizeof(T) + (size_t)g.d * 10 * sizeof(float) + 16;
+        if (l2 > 160 * 1024) return fail(DSW_EUNSUPPORTED, "win_attn_bwd: LePE with w=%d head dim %d needs %zu B of LDS", WS, g.d, l2);
+        auto pre = lepe_bwd_pre_kernel<T, WS>;
+        if (l2 > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_bwd: LDS attribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(pre, grid, dim3(256), l2, st, g, (const T *)qkv, (const T *)out, (const T *)dout, lepe_w, lepe_b,
+                           (T *)dqkv, ws_delta, ws_lepe);
+        rc = check_launch("lepe_bwd_pre_kernel");
+        if (rc) return rc;
+    }
 #define DSW_BWD_LAUNCH(B_)                                                                                       \
     do {                                                                                                         \
         auto kern = win_attn_bwd_kernel<T, WS, DP, B_, false>;                                                   \
@@ -436,18 +674,24 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
             if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); \
         }                                                                                                        \
         hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const T *)qkv, (const T *)out, (const T *)dout, table, \
-                           scale, lepe_w, lepe_b, lse, (T *)dqkv, ws_table, ws_lepe);                            \
+                           scale, lepe_w, lepe_b, lse, (T *)dqkv, ws_table, lepe ? ws_delta : (const float *)nullptr); \
     } while (0)
     if (bias) DSW_BWD_LAUNCH(true);
     else DSW_BWD_LAUNCH(false);
 #undef DSW_BWD_LAUNCH
-    int rc = check_launch("win_attn_bwd_kernel");
+    rc = check_launch("win_attn_bwd_kernel");
     if (rc) return rc;
     if (bias) {
         const int T2 = (2 * WS - 1) * (2 * WS - 1);
         hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((T2 * g.heads + 15) / 16), dim3(256), 0, st, ws_table,
                            g.n_win, g.heads, T2, d_table);
         rc = check_launch("bias_grad_reduce_kernel");
+        if (rc) return rc;
+    }
+    if (lepe) {
+        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3((g.C * 10 + 255) / 256), dim3(256), 0, st, ws_lepe, g.n_win, g.C,
+                           d_lepe_w, d_lepe_b);
+        rc = check_launch("lepe_grad_reduce_kernel");
     }
     return rc;
 }
@@ -460,6 +704,7 @@ using namespace dsw;
 
 static size_t table_ws_floats(const AttnGeom &g, int w) { return (size_t)g.n_win * g.heads * (2 * w - 1) * (2 * w - 1); }
 static size_t lepe_ws_floats(const AttnGeom &g) { return (size_t)g.n_win * g.C * 10; }
+static size_t delta_ws_floats(const AttnGeom &g, int w) { return (size_t)g.n_win * g.heads * w * w; }
 
 extern "C" size_t dsw_win_attn_bwd_workspace(int n_img, int H, int W, int w, int C, int heads, int has_bias,
                                              int has_lepe) {
@@ -467,7 +712,7 @@ extern "C" size_t dsw_win_attn_bwd_workspace(int n_img, int H, int W, int w, int
     if (make_geom("dsw_win_attn_bwd_workspace", n_img, H, W, w, C, heads, DSW_QKV_CHUNKED, g)) return 0;
     size_t fl = 0;
     if (has_bias) fl += table_ws_floats(g, w);
-    if (has_lepe) fl += lepe_ws_floats(g);
+    if (has_lepe) fl += lepe_ws_floats(g) + delta_ws_floats(g, w);
     return fl * sizeof(float);
 }
 
@@ -488,13 +733,14 @@ extern "C" int dsw_win_attn_bwd(const void *qkv, const void *out, const void *do
     DSW_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), "dsw_win_attn_bwd: workspace %zu B < %zu B", workspace_bytes, need);
     float *ws_table = reinterpret_cast<float *>(workspace);
     float *ws_lepe = ws_table + (bias_table ? table_ws_floats(g, w) : 0);
+    float *ws_delta = ws_lepe + (lepe_w ? lepe_ws_floats(g) : 0);
     hipStream_t st = as_stream(stream);
     const bool big = g.d > 32;
     DSW_DISPATCH_DTYPE(dtype, T, {
-        if (w == 16) return big ? launch_bwd<T, 16, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, ws_table, ws_lepe, st)
-                                : launch_bwd<T, 16, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, ws_table, ws_lepe, st);
-        return big ? launch_bwd<T, 8, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, ws_table, ws_lepe, st)
-                   : launch_bwd<T, 8, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, ws_table, ws_lepe, st);
+        if (w == 16) return big ? launch_bwd<T, 16, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, st)
+                                : launch_bwd<T, 16, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, st);
+        return big ? launch_bwd<T, 8, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, st)
+                   : launch_bwd<T, 8, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, st);
     });
     return DSW_OK;
 }

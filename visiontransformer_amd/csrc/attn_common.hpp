@@ -60,9 +60,6 @@ template <> struct lds_traits<bf16_t> { static constexpr int RPAD = 8; };
 template <> struct lds_traits<float> { static constexpr int RPAD = 4; };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
 
 // relative-position table in LDS: [(2w-1)][TS] with TS = 3w, which makes the per-lane lookups of
 // one wave-instruction fall on distinct banks (w = 16: two runs of 16 that are 48 apart; w = 8:

@@ -24,8 +24,8 @@ template <typename T, int WS, int DP> struct FwdCfg {
     static constexpr int THREADS = NW * 64;
     static constexpr int QS = DP + lds_traits<T>::RPAD;  // row-major stride (elements)
     static constexpr int VS = L + 4;                      // transposed stride (elements)
-    // w = 16 keeps a 32 x 256 score block (128 accumulators) per lane: one wave per SIMD
-    static constexpr int MIN_WAVES = WS == 16 ? 1 : 2;
+    // two workgroups per CU wherever the LDS footprint allows it
+    static constexpr int MIN_WAVES = (WS == 16 && (DP == 64 || sizeof(T) == 4)) ? 1 : 2;
     static constexpr size_t lds_bytes(bool bias) {
         return (size_t)(2 * L * QS + DP * VS) * sizeof(T) + (bias ? bias_lds<WS>::FLOATS * sizeof(float) : 0);
     }
@@ -40,6 +40,7 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
     constexpr int L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, THREADS = Cfg::THREADS, QS = Cfg::QS, VS = Cfg::VS;
     constexpr int TS = bias_lds<WS>::TS;
     constexpr bool BF = sizeof(T) == 2;
+    constexpr int TP = NT < 4 ? NT : 4, NPASS = NT / TP;  // key tiles per softmax pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *Qs = reinterpret_cast<T *>(smem);
     T *Ks = Qs + L * QS;
@@ -66,31 +67,47 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
         pitch = g.W;
     }
 
-    // ---- stage Q, K (row-major) and V (transposed) -------------------------------------------
+    // ---- stage Q (times scale*log2(e)), K (row-major) and V (transposed) ----------------------
+    // When d < DP the first padding row of V^T is set to ones: row d of O^T = V^T P^T is then the
+    // softmax denominator, computed by the matrix core instead of 256 VALU adds per lane.
+    // Loads are issued in batches of 8 per thread before any of them is consumed: a loop that
+    // loads and stores one item per trip pays a full memory round trip per trip.
+    const float sc2 = scale * LOG2E;
+    auto rowbase = [&](int row) -> size_t { return (origin + (size_t)(row / WS) * pitch + (row % WS)) * C3; };
     if constexpr (BF) {
         if ((d & 1) == 0) {
-            constexpr int DW = DP / 2;
-            for (int it = tid; it < L * DW; it += THREADS) {
-                const int row = it / DW, e = (it - row * DW) * 2;
-                const size_t base = (origin + (size_t)(row / WS) * pitch + (row % WS)) * C3;
-                uint32_t qv = 0, kv = 0, vv = 0;
-                if (e < d) {
-                    qv = *reinterpret_cast<const uint32_t *>(qkv + base + qoff + e);
-                    kv = *reinterpret_cast<const uint32_t *>(qkv + base + koff + e);
-                    vv = *reinterpret_cast<const uint32_t *>(qkv + base + voff + e);
+            constexpr int DW = DP / 2, ITER = L * DW / THREADS, BATCH = ITER < 8 ? ITER : 8;
+            for (int i0 = 0; i0 < ITER; i0 += BATCH) {
+                uint32_t qv[BATCH], kv[BATCH], vv[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int it = tid + (i0 + i) * THREADS;
+                    const int row = it / DW, e = (it - row * DW) * 2;
+                    const T *src = qkv + rowbase(row) + min(e, d - 2);  // clamped: padding lanes re-read a valid pair
+                    qv[i] = *reinterpret_cast<const uint32_t *>(src + qoff);
+                    kv[i] = *reinterpret_cast<const uint32_t *>(src + koff);
+                    vv[i] = *reinterpret_cast<const uint32_t *>(src + voff);
                 }
-                *reinterpret_cast<uint32_t *>(Qs + row * QS + e) = qv;
-                *reinterpret_cast<uint32_t *>(Ks + row * QS + e) = kv;
-                Vt[e * VS + row] = (T)(vv & 0xffffu);
-                Vt[(e + 1) * VS + row] = (T)(vv >> 16);
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int it = tid + (i0 + i) * THREADS;
+                    const int row = it / DW, e = (it - row * DW) * 2;
+                    const bool ok = e < d;
+                    const uint32_t q2 = pack_bf16(__uint_as_float(qv[i] << 16) * sc2, __uint_as_float(qv[i] & 0xffff0000u) * sc2);
+                    const uint32_t v2 = ok ? vv[i] : (e == d ? 0x3f80u : 0u);  // bf16 1.0 in the low half
+                    *reinterpret_cast<uint32_t *>(Qs + row * QS + e) = ok ? q2 : 0u;
+                    *reinterpret_cast<uint32_t *>(Ks + row * QS + e) = ok ? kv[i] : 0u;
+                    Vt[e * VS + row] = (T)(v2 & 0xffffu);
+                    Vt[(e + 1) * VS + row] = (T)(v2 >> 16);
+                }
             }
         } else {
             for (int it = tid; it < L * DP; it += THREADS) {
                 const int row = it / DP, e = it - row * DP;
-                const size_t base = (origin + (size_t)(row / WS) * pitch + (row % WS)) * C3;
-                T qv = 0, kv = 0, vv = 0;
+                const size_t base = rowbase(row);
+                T qv = 0, kv = 0, vv = (e == d) ? (T)0x3f80u : (T)0;
                 if (e < d) {
-                    qv = qkv[base + qoff + e];
+                    qv = f32_to_bf16(bf16_to_f32(qkv[base + qoff + e]) * sc2);
                     kv = qkv[base + koff + e];
                     vv = qkv[base + voff + e];
                 }
@@ -100,18 +117,27 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
             }
         }
     } else {
-        for (int it = tid; it < L * DP; it += THREADS) {
-            const int row = it / DP, e = it - row * DP;
-            const size_t base = (origin + (size_t)(row / WS) * pitch + (row % WS)) * C3;
-            T qv = 0, kv = 0, vv = 0;
-            if (e < d) {
-                qv = qkv[base + qoff + e];
-                kv = qkv[base + koff + e];
-                vv = qkv[base + voff + e];
+        constexpr int ITER = L * DP / THREADS, BATCH = 8;
+        for (int i0 = 0; i0 < ITER; i0 += BATCH) {
+            float qv[BATCH], kv[BATCH], vv[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int it = tid + (i0 + i) * THREADS;
+                const int row = it / DP, e = it - row * DP;
+                const T *src = qkv + rowbase(row) + min(e, d - 1);
+                qv[i] = src[qoff];
+                kv[i] = src[koff];
+                vv[i] = src[voff];
             }
-            Qs[row * QS + e] = qv;
-            Ks[row * QS + e] = kv;
-            Vt[e * VS + row] = vv;
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int it = tid + (i0 + i) * THREADS;
+                const int row = it / DP, e = it - row * DP;
+                const bool ok = e < d;
+                Qs[row * QS + e] = ok ? qv[i] * sc2 : 0.f;
+                Ks[row * QS + e] = ok ? kv[i] : 0.f;
+                Vt[e * VS + row] = ok ? vv[i] : (e == d ? 1.f : 0.f);
+            }
         }
     }
     if constexpr (BIAS) {
@@ -124,125 +150,137 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const float sc2 = scale * LOG2E;
+    const bool ones_row = d < DP;  // uniform
 
     for (int qb = wave; qb < NT; qb += NW) {
         const int q = qb * 32 + l31;
         const int qi = q / WS, qj = q - qi * WS;
-        f32x16 sacc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
-
-        // ---- S^T = K Q^T ------------------------------------------------------------------------
+        // this lane's Q fragments (B operand of S^T = K Q^T), kept for the whole block
+        uint4 qfb[BF ? DP / 16 : 1];
+        float4 qff[BF ? 1 : DP / 8];
         if constexpr (BF) {
-            uint4 qf[DP / 16];
 #pragma unroll
-            for (int s = 0; s < DP / 16; ++s) qf[s] = *reinterpret_cast<const uint4 *>(Qs + q * QS + 16 * s + 8 * hh);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int s = 0; s < DP / 16; ++s) {
-                    const uint4 kf = *reinterpret_cast<const uint4 *>(Ks + (32 * t + l31) * QS + 16 * s + 8 * hh);
-                    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf), as_bf16x8(qf[s]), sacc[t], 0, 0, 0);
-                }
-            }
+            for (int s = 0; s < DP / 16; ++s) qfb[s] = *reinterpret_cast<const uint4 *>(Qs + q * QS + 16 * s + 8 * hh);
         } else {
             // lane half hh supplies the head-dim slice [hh*DP/2, (hh+1)*DP/2), one element per k-step
-            float4 qf[DP / 8];
 #pragma unroll
-            for (int s = 0; s < DP / 8; ++s) qf[s] = *reinterpret_cast<const float4 *>(Qs + q * QS + hh * (DP / 2) + 4 * s);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int s = 0; s < DP / 8; ++s) {
-                    const float4 kf = *reinterpret_cast<const float4 *>(Ks + (32 * t + l31) * QS + hh * (DP / 2) + 4 * s);
-                    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[s].x, sacc[t], 0, 0, 0);
-                    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[s].y, sacc[t], 0, 0, 0);
-                    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[s].z, sacc[t], 0, 0, 0);
-                    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[s].w, sacc[t], 0, 0, 0);
-                }
-            }
+            for (int s = 0; s < DP / 8; ++s) qff[s] = *reinterpret_cast<const float4 *>(Qs + q * QS + hh * (DP / 2) + 4 * s);
         }
-
-        // ---- softmax over the keys (registers + the other lane half), base 2 -----------------------
-        // element (t, r) of this lane is key 32t + rho(r) + 4hh; its table entry is
-        // (qi - ki + w-1)*TS + (qj - kj + w-1) = lane_base - (ki_c*TS + kj_c) with ki_c, kj_c
-        // the compile-time part of the key coordinates.
-        const int lane_base = qi * TS + qj + (WS - 1) * (TS + 1) - 4 * hh;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key_c = 32 * t + rho(r);
-                float v = sacc[t][r] * sc2;
-                if constexpr (BIAS) v += tb[lane_base - ((key_c / WS) * TS + (key_c % WS))];
-                sacc[t][r] = v;
-                mx = fmaxf(mx, v);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep one tile's table reads in flight, not all
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-        uint32_t pk[BF ? NT : 1][8];  // bf16 P^T, packed pairwise: the PV B operand
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[t][r] - mx);
-                sacc[t][r] = p;
-                sum += p;
-            }
-            if constexpr (BF) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) pk[t][r >> 1] = pack_bf16(sacc[t][r], sacc[t][r + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-        if (hh == 0) lse[((size_t)win * g.heads + head) * L + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
-
-        // ---- O^T = V^T P^T ------------------------------------------------------------------------
         f32x16 oacc[DP / 32];
 #pragma unroll
         for (int u = 0; u < DP / 32; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[u][r] = 0.f;
-        if constexpr (BF) {
+        // element (t, r) of this lane is key 32t + rho(r) + 4hh; its table entry is
+        // (qi - ki + w-1)*TS + (qj - kj + w-1) = lane_base - (ki_c*TS + kj_c), with ki_c, kj_c the
+        // compile-time part of the key coordinates
+        const int lane_base = qi * TS + qj + (WS - 1) * (TS + 1) - 4 * hh;
+        float mx = -INFINITY, sum = 0.f;
+
+        // The keys are walked in passes of TP tiles (128 keys) with an online softmax across passes,
+        // which keeps the live score block at 64 accumulators per lane.
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+        for (int pass = 0; pass < NPASS; ++pass) {
+            f32x16 sacc[TP];
+            // ---- accumulators start from the bias ------------------------------------------------
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint4 pb = make_uint4(pk[t][4 * s + 0], pk[t][4 * s + 1], pk[t][4 * s + 2], pk[t][4 * s + 3]);
+            for (int tt = 0; tt < TP; ++tt) {
 #pragma unroll
-                    for (int u = 0; u < DP / 32; ++u) {
-                        const T *vrow = Vt + (32 * u + l31) * VS + 32 * t + 16 * s + 4 * hh;
-                        const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
-                        const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 8);
-                        const uint4 va = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        oacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(va), as_bf16x8(pb), oacc[u], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) {
+                    const int key_c = 32 * (pass * TP + tt) + rho(r);
+                    if constexpr (BIAS) sacc[tt][r] = tb[lane_base - ((key_c / WS) * TS + (key_c % WS))];
+                    else sacc[tt][r] = 0.f;
+                }
+            }
+            // ---- S^T = K Q^T (+ bias), already in the base-2 domain ----------------------------------
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt) {
+                const int t = pass * TP + tt;
+                if constexpr (BF) {
+#pragma unroll
+                    for (int s = 0; s < DP / 16; ++s) {
+                        const uint4 kf = *reinterpret_cast<const uint4 *>(Ks + (32 * t + l31) * QS + 16 * s + 8 * hh);
+                        sacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf), as_bf16x8(qfb[s]), sacc[tt], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < DP / 8; ++s) {
+                        const float4 kf = *reinterpret_cast<const float4 *>(Ks + (32 * t + l31) * QS + hh * (DP / 2) + 4 * s);
+                        sacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qff[s].x, sacc[tt], 0, 0, 0);
+                        sacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qff[s].y, sacc[tt], 0, 0, 0);
+                        sacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qff[s].z, sacc[tt], 0, 0, 0);
+                        sacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qff[s].w, sacc[tt], 0, 0, 0);
                     }
                 }
             }
-        } else {
+            // ---- running max over registers + the other lane half; rescale what is accumulated ------
+            float pm = mx;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int tt = 0; tt < TP; ++tt)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
+                for (int r = 0; r < 16; ++r) pm = fmaxf(pm, sacc[tt][r]);
+            pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+            if (pass > 0) {
+                const float alpha = __builtin_amdgcn_exp2f(mx - pm);
+                sum *= alpha;
 #pragma unroll
-                    for (int u = 0; u < DP / 32; ++u) {
-                        const float4 va = *reinterpret_cast<const float4 *>(Vt + (32 * u + l31) * VS + 32 * t + 8 * g4 + 4 * hh);
-                        oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, sacc[t][4 * g4 + 0], oacc[u], 0, 0, 0);
-                        oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, sacc[t][4 * g4 + 1], oacc[u], 0, 0, 0);
-                        oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, sacc[t][4 * g4 + 2], oacc[u], 0, 0, 0);
-                        oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, sacc[t][4 * g4 + 3], oacc[u], 0, 0, 0);
+                for (int u = 0; u < DP / 32; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
+            }
+            mx = pm;
+            // ---- P^T = exp2(S^T - max) and O^T += V^T P^T ----------------------------------------------
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt) {
+                const int t = pass * TP + tt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[tt][r] = __builtin_amdgcn_exp2f(sacc[tt][r] - mx);
+                if (!ones_row) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += sacc[tt][r];
+                }
+                if constexpr (BF) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const uint4 pb = make_uint4(pack_bf16(sacc[tt][8 * s + 0], sacc[tt][8 * s + 1]),
+                                                    pack_bf16(sacc[tt][8 * s + 2], sacc[tt][8 * s + 3]),
+                                                    pack_bf16(sacc[tt][8 * s + 4], sacc[tt][8 * s + 5]),
+                                                    pack_bf16(sacc[tt][8 * s + 6], sacc[tt][8 * s + 7]));
+#pragma unroll
+                        for (int u = 0; u < DP / 32; ++u) {
+                            const T *vrow = Vt + (32 * u + l31) * VS + 32 * t + 16 * s + 4 * hh;
+                            const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
+                            const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 8);
+                            const uint4 va = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                            oacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(va), as_bf16x8(pb), oacc[u], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+                        for (int u = 0; u < DP / 32; ++u) {
+                            const float4 va = *reinterpret_cast<const float4 *>(Vt + (32 * u + l31) * VS + 32 * t + 8 * g4 + 4 * hh);
+                            oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, sacc[tt][4 * g4 + 0], oacc[u], 0, 0, 0);
+                            oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, sacc[tt][4 * g4 + 1], oacc[u], 0, 0, 0);
+                            oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, sacc[tt][4 * g4 + 2], oacc[u], 0, 0, 0);
+                            oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, sacc[tt][4 * g4 + 3], oacc[u], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
+
+        // ---- softmax denominator: row d of O^T (ones row of V^T), or the explicit sum ---------------
+        if (ones_row) {
+#pragma unroll
+            for (int u = 0; u < DP / 32; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += (32 * u + rho(r) + 4 * hh == d) ? oacc[u][r] : 0.f;
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (hh == 0) lse[((size_t)win * g.heads + head) * L + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
 
         // ---- epilogue: normalise, LePE, store (lane = query row, registers = head-dim) -------------
         T *orow = out + (origin + (size_t)qi * pitch + qj) * C + head * d;

@@ -33,12 +33,14 @@ typedef uint16_t bf16_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (quiet)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even through the hardware converter (v_cvt_pk_bf16_f32); NaN stays NaN
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    bf16x2_hw v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct io;
@@ -62,8 +64,8 @@ template <> struct io<bf16_t> {
     }
     __device__ static __forceinline__ void st4(bf16_t *p, float4 v) {
         uint2 u;
-        u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-        u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        u.x = pack_bf16(v.x, v.y);
+        u.y = pack_bf16(v.z, v.w);
         *reinterpret_cast<uint2 *>(p) = u;
     }
 };

@@ -245,3 +245,90 @@ def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w
         n_img, H, W = grid
     return _WinAttnFn.apply(qkv, table, lepe_w, lepe_b, int(layout), int(n_img), int(H), int(W), int(w),
                             int(heads), float(scale))
+
+
+# ---------------------------------------------------------------------------------------------
+# MSFT multi-scale reshapes (msft_arch.py:37-78, :156-167)
+# ---------------------------------------------------------------------------------------------
+class _UnshuffleLNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, s, eps, out_dtype):
+        _lib.require_cuda(x)
+        x = x.contiguous()
+        B, c, H, W = x.shape
+        Co = c * s * s
+        dev = x.device
+        g32 = gamma.detach().to(torch.float32).contiguous()
+        b32 = beta.detach().to(torch.float32).contiguous()
+        y = torch.empty(B, H // s, W // s, Co, dtype=out_dtype, device=dev)
+        stats = torch.empty(2, B * (H // s) * (W // s), dtype=torch.float32, device=dev)
+        call("dsw_unshuffle_nhwc_ln_fwd", ptr(x), dtype_code(x.dtype), B, c, H, W, s, ptr(g32), ptr(b32), _c_float(eps),
+             ptr(y), dtype_code(out_dtype), ptr(stats[0]), ptr(stats[1]), stream(dev))
+        ctx.save_for_backward(x, g32, stats)
+        ctx.meta = (s, gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32, stats = ctx.saved_tensors
+        s, gdt, bdt = ctx.meta
+        B, c, H, W = x.shape
+        Co = c * s * s
+        dev = x.device
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, Co, dtype=torch.float32, device=dev)
+        nblk = _lib.load().dsw_unshuffle_blocks(B, H, W, s)
+        partial = torch.empty(nblk * 2 * Co, dtype=torch.float32, device=dev)
+        call("dsw_unshuffle_nhwc_ln_bwd", ptr(dy), ptr(x), dtype_code(x.dtype), B, c, H, W, s, ptr(g32), ptr(stats[0]),
+             ptr(stats[1]), ptr(dx), ptr(dgb[0]), ptr(dgb[1]), ptr(partial), stream(dev))
+        return dx, dgb[0].to(gdt), dgb[1].to(bdt), None, None, None
+
+
+def unshuffle_nhwc_layernorm(x, gamma, beta, scale=1, eps=1e-5, out_dtype=None):
+    """PixelUnshuffle(scale) + NCHW->NHWC + LayerNorm over channels in one pass
+    (msft_arch.py:45-50; scale=1: :68-70 and :160-162).  x [B,c,H,W] -> [B,H/s,W/s,c*s*s]."""
+    return _UnshuffleLNFn.apply(x, gamma, beta, int(scale), float(eps), out_dtype or x.dtype)
+
+
+class _ShuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, s):
+        _lib.require_cuda(t)
+        t = t.contiguous()
+        B, H, W, C = t.shape
+        y = torch.empty(B, C // (s * s), H * s, W * s, dtype=t.dtype, device=t.device)
+        call("dsw_shuffle_nchw_fwd", ptr(t), dtype_code(t.dtype), B, H, W, C, s, ptr(y), stream(t.device))
+        ctx.s = s
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _UnshuffleFn.apply(dy, ctx.s), None
+
+
+class _UnshuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        _lib.require_cuda(x)
+        x = x.contiguous()
+        B, c, H, W = x.shape
+        y = torch.empty(B, H // s, W // s, c * s * s, dtype=x.dtype, device=x.device)
+        call("dsw_unshuffle_nhwc_fwd", ptr(x), dtype_code(x.dtype), B, c, H, W, s, ptr(y), stream(x.device))
+        ctx.s = s
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _ShuffleFn.apply(dy, ctx.s), None
+
+
+def shuffle_nchw(t, scale=1):
+    """NHWC->NCHW + PixelShuffle(scale) in one pass (msft_arch.py:54, :74-76, :166).
+    t [B,H,W,C] -> [B,C/s^2,H*s,W*s]."""
+    return _ShuffleFn.apply(t, int(scale))
+
+
+def unshuffle_nhwc(x, scale=1):
+    """PixelUnshuffle(scale) + NCHW->NHWC in one pass.  x [B,c,H,W] -> [B,H/s,W/s,c*s*s]."""
+    return _UnshuffleFn.apply(x, int(scale))

@@ -1,0 +1,113 @@
+"""MSFT attention and multi-scale modules backed by the HIP kernels.
+
+Same class names, constructor arguments, forward signatures and state_dict keys as
+msft_arch.py:37-143 of the reference.
+"""
+import torch
+from torch import nn
+
+from . import functional as K
+from ._lib import QKV_CHUNKED
+
+
+def _ln_out_dtype(x):
+    # LayerNorm is on CUDA autocast's fp32 list: under autocast its output is fp32
+    return torch.float32 if torch.is_autocast_enabled("cuda") else x.dtype
+
+
+class PatchMerging(nn.Module):
+    """msft_arch.py:37-56: PixelUnshuffle -> NHWC -> LayerNorm -> Linear(no bias) -> NCHW.
+    The unshuffle, the layout copy and the LayerNorm are one kernel; the copy back is another."""
+
+    def __init__(self, dim, scale):
+        super().__init__()
+        self.pixel_unshuffle = nn.PixelUnshuffle(scale)
+        self.scale = scale
+        self.norm = nn.LayerNorm(dim)
+        self.linear = nn.Linear(dim, dim, bias=False)
+
+    def forward(self, x):
+        t = K.unshuffle_nhwc_layernorm(x, self.norm.weight, self.norm.bias, self.scale, self.norm.eps,
+                                       out_dtype=_ln_out_dtype(x))
+        return K.shuffle_nchw(self.linear(t), 1)
+
+
+class PatchUnMerging(nn.Module):
+    """msft_arch.py:59-78: NHWC -> LayerNorm -> Linear(no bias) -> NCHW -> PixelShuffle."""
+
+    def __init__(self, dim, scale):
+        super().__init__()
+        self.pixel_shuffle = nn.PixelShuffle(scale)
+        self.scale = scale
+        self.norm = nn.LayerNorm(dim)
+        self.linear = nn.Linear(dim, dim, bias=False)
+
+    def forward(self, x):
+        t = K.unshuffle_nhwc_layernorm(x, self.norm.weight, self.norm.bias, 1, self.norm.eps,
+                                       out_dtype=_ln_out_dtype(x))
+        return K.shuffle_nchw(self.linear(t), self.scale)
+
+
+class WindowedMSA(nn.Module):
+    """msft_arch.py:80-143.  qkv Linear, then ONE kernel for window partition + head split +
+    SDPA (scale d^-0.5, no bias) + LePE (depthwise 3x3 of V inside each window) + reverse
+    partition, then out_proj.  The reference's eight layout copies are gone."""
+
+    def __init__(self, window_size, dim, num_heads=4, attn_drop=0.1, proj_drop=0.):
+        super().__init__()
+        self.window_size = window_size
+        self.num_heads = num_heads
+        assert dim % num_heads == 0, f"dim ({dim}) must be divisible by num_heads ({num_heads})"
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.pe_encoder = nn.Conv2d(dim, dim, 3, 1, 1, groups=dim)
+        self.out_proj = nn.Linear(dim, dim)
+        self.attn_drop = attn_drop
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x, H, W):
+        if self.attn_drop:
+            raise NotImplementedError(
+                "attention dropout inside the fused window-attention kernel is not built; set "
+                "attn_drop = 0 (the reference passes its default 0.1 to SDPA even in eval(), "
+                "msft_arch.py:136, so its outputs are random there)")
+        B, N, C = x.shape
+        assert N == H * W
+        qkv = self.qkv(x)
+        z = K.window_attention(qkv, None, self.window_size, self.num_heads, QKV_CHUNKED, grid=(B, H, W),
+                               lepe_w=self.pe_encoder.weight, lepe_b=self.pe_encoder.bias)
+        return self.proj_drop(self.out_proj(z))
+
+
+class MLP(nn.Module):
+    """msft_arch.py:19-33 (stock torch; not on the kernel path)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, ffn_scale=4, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or int(in_features * ffn_scale)
+        self.mlp = nn.Sequential(nn.Linear(in_features, hidden_features), nn.GELU(),
+                                 nn.Linear(hidden_features, out_features), nn.Dropout(drop))
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class ViTBlock(nn.Module):
+    """msft_arch.py:146-167, the caller of WindowedMSA: NCHW in and out.  The NCHW->token copy
+    is fused with ln1 and the token->NCHW copy is one kernel; attn_drop is 0 here (see above)."""
+
+    def __init__(self, window_size, dim, n_heads=4, ffn_scale=2, drop_path=0.0):
+        super().__init__()
+        self.msa = WindowedMSA(dim=dim, window_size=window_size, num_heads=n_heads, attn_drop=0.0)
+        self.mlp = MLP(dim, ffn_scale=ffn_scale)
+        self.ln1 = nn.LayerNorm(dim)
+        self.ln2 = nn.LayerNorm(dim)
+        self.drop_path = nn.Dropout(drop_path)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        t = K.unshuffle_nhwc(x, 1).view(B, H * W, C)
+        n1 = torch.nn.functional.layer_norm(t, (C,), self.ln1.weight, self.ln1.bias, self.ln1.eps)
+        t = self.drop_path(self.msa(n1, H, W)) + t
+        t = self.drop_path(self.mlp(self.ln2(t))) + t
+        return K.shuffle_nchw(t.view(B, H, W, C), 1)
