@@ -175,6 +175,52 @@ def msft_vitblock(M, name, B, C, H, W, heads, w, seed):
     _save(name, arrays, dict(kind="msft_vitblock", B=B, C=C, H=H, W=W, heads=heads, w=w))
 
 
+def dswt_model(D, name, seed, H, W):
+    """whole DSWT network, eval mode (the reference's training forward raises NameError at
+    DSwinT_arch.py:483); ReZero gates randomised, otherwise every attention branch is times 0."""
+    gen = torch.Generator().manual_seed(seed)
+    cfg = dict(block_type="default", n_blocks=1, n_sub_blocks=2, levels=1, window_size=8, dim=24, level_dim=12,
+               n_heads=2, n_heads_fuse=2, feature_dim=16, scale_factor=4)
+    mod = D.MSFTransformer(**cfg)
+    _randomise(mod, gen)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if "rezero" in n:
+                p.copy_(torch.rand(p.shape, generator=gen) + 0.5)
+            if n.endswith("sparse_discriminator.4.weight"):
+                p.mul_(6.0)
+            if n.endswith("sparse_discriminator.4.bias"):
+                p[1] += 0.6
+        for m in mod.modules():
+            if isinstance(m, D.DeformableSparseWindowAttention):
+                m.num_win_selected = 0.5
+    mod.eval()
+    x = (torch.randn(1, 3, H, W, generator=gen) * 0.5).clamp(-1, 1).requires_grad_()
+    y = mod(x)
+    arrays = {"x": x, "y": y, **_state(mod), **_grads(mod, x, y, gen)}
+    _save(name, arrays, dict(kind="dswt_model", cfg=cfg, H=H, W=W, num_win_selected=0.5))
+
+
+def msft_model(M, name, seed, H, W):
+    gen = torch.Generator().manual_seed(seed)
+    cfg = dict(block_type="default", n_blocks=1, n_sub_blocks=1, levels=2, window_size=8, dim=32, level_dim=16,
+               n_heads=2, n_heads_fuse=2, feature_dim=16, scale_factor=4)
+    mod = M.MSFTransformer(**cfg)
+    _randomise(mod, gen)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if "rezero" in n:
+                p.copy_(torch.rand(p.shape, generator=gen) + 0.5)
+    for m in mod.modules():
+        if isinstance(m, M.WindowedMSA):
+            m.attn_drop = 0.0
+    mod.eval()
+    x = (torch.randn(1, 3, H, W, generator=gen) * 0.5).clamp(-1, 1).requires_grad_()
+    y = mod(x)
+    arrays = {"x": x, "y": y, **_state(mod), **_grads(mod, x, y, gen)}
+    _save(name, arrays, dict(kind="msft_model", cfg=cfg, H=H, W=W))
+
+
 def main():
     torch.set_num_threads(4)
     D, M = _import_reference()
@@ -200,6 +246,9 @@ def main():
     msft_patch(M, "msft_patch_merging", "PatchMerging", B=2, c=6, H=16, W=24, scale=2, seed=23)
     msft_patch(M, "msft_patch_unmerging", "PatchUnMerging", B=2, c=24, H=8, W=12, scale=2, seed=24)
     msft_vitblock(M, "msft_vitblock", B=1, C=32, H=16, W=16, heads=2, w=8, seed=25)
+    # whole networks (the callers of the path), small configs, H/W that need reflect padding
+    dswt_model(D, "model_dswt", seed=31, H=20, W=28)
+    msft_model(M, "model_msft", seed=32, H=28, W=20)
 
 
 if __name__ == "__main__":

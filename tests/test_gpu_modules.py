@@ -163,3 +163,31 @@ def test_reshape_kernels_exact(cuda0, dtype, s):
     t = torch.randn(2, 16, 20, 6 * s * s, generator=gen).to(dtype).to(cuda0)
     ref2 = F.pixel_shuffle(t.permute(0, 3, 1, 2).contiguous(), s)
     assert torch.equal(K.shuffle_nchw(t, s), ref2)
+
+
+# ----------------------------------------------------------------------------------------------
+# whole networks (callers of the path) against the reference's own output
+# ----------------------------------------------------------------------------------------------
+def test_dswt_model_golden(cuda0):
+    from visiontransformer_amd import dswin, models
+    g, m = load_golden("model_dswt")
+    mod = _load_into(models.DSWTransformer(**m["cfg"]), g, cuda0).eval()
+    for sub in mod.modules():
+        if isinstance(sub, dswin.DeformableSparseWindowAttention):
+            sub.num_win_selected = m["num_win_selected"]
+    x = g["x"].to(cuda0).requires_grad_()
+    y = mod(x)
+    assert y.shape == g["y"].shape
+    assert rel_err(y, g["y"]) < TOL
+    _check_grads(mod, g, x, y, cuda0)
+
+
+def test_msft_model_golden(cuda0):
+    from visiontransformer_amd import models
+    g, m = load_golden("model_msft")
+    mod = _load_into(models.MSFTransformer(**m["cfg"]), g, cuda0).eval()
+    x = g["x"].to(cuda0).requires_grad_()
+    y = mod(x)
+    assert y.shape == g["y"].shape
+    assert rel_err(y, g["y"]) < TOL
+    _check_grads(mod, g, x, y, cuda0)

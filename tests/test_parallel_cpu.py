@@ -1,0 +1,106 @@
+"""The N > 1 host logic on CPU with the gloo backend, world_size 2: tile planning / stitching
+of sharded inference and the data-parallel gradient all-reduce.  The models here are stock
+torch stand-ins (the kernels need a GPU); what is tested is the sharding, not the kernels."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from visiontransformer_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _ToySR(torch.nn.Module):
+    """x2 SR stand-in with a 5x5 receptive field (two 3x3 convs)"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = torch.nn.Conv2d(3, 8, 3, 1, 1)
+        self.b = torch.nn.Conv2d(8, 12, 3, 1, 1)
+        self.up = torch.nn.PixelShuffle(2)
+
+    def forward(self, x):
+        return self.up(self.b(torch.relu(self.a(x))))
+
+
+def test_plan_tiles_cover_the_image_once():
+    H, W = 70, 45
+    cover = torch.zeros(H, W, dtype=torch.int32)
+    tiles = parallel.plan_tiles(H, W, tile=32, halo=4)
+    for t in tiles:
+        cover[t.y0:t.y1, t.x0:t.x1] += 1
+        assert t.py0 == t.y0 - 4 and t.px1 == t.x1 + 4
+    assert int(cover.min()) == 1 and int(cover.max()) == 1
+    assert len(tiles) == 3 * 2
+
+
+def test_reflect_crop_matches_padding():
+    img = torch.arange(2 * 3 * 6 * 7, dtype=torch.float32).view(2, 3, 6, 7)
+    ref = torch.nn.functional.pad(img, (3, 3, 3, 3), mode="reflect")
+    got = parallel._reflect_crop(img, -3, 9, -3, 10)
+    assert torch.equal(got, ref)
+
+
+def test_tiled_inference_single_process_exact_in_the_interior():
+    """halo >= receptive-field radius: tiling reproduces whole-image inference away from the
+    image border (at the border the reflect padding differs from the conv's zero padding)"""
+    model = _ToySR().eval()
+    lr = torch.randn(1, 3, 40, 52)
+    full = model(lr)
+    tiled = parallel.tiled_super_resolve(model, lr, 2, tile=16, halo=4)
+    assert tiled.shape == full.shape
+    assert torch.allclose(tiled[..., 8:-8, 8:-8], full[..., 8:-8, 8:-8], atol=1e-6)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, dev = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    # (1) sharded tiled inference: every rank ends with the whole image
+    model = _ToySR().eval()
+    gen = torch.Generator().manual_seed(5)
+    lr = torch.randn(1, 3, 40, 52, generator=gen)
+    out = parallel.tiled_super_resolve(model, lr, 2, tile=16, halo=4, rank=r, world=w)
+    ref = parallel.tiled_super_resolve(model, lr, 2, tile=16, halo=4)
+    ok_tiles = torch.allclose(out, ref, atol=1e-6)
+    # (2) data parallel: per-rank batches, gradients averaged over the group
+    net = parallel.data_parallel(_ToySR(), dev)
+    gen2 = torch.Generator().manual_seed(100 + r)
+    x = torch.randn(2, 3, 8, 8, generator=gen2)
+    net(x).square().mean().backward()
+    g_ddp = net.module.a.weight.grad.clone()
+    single = _ToySR()
+    xs = torch.cat([torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(100 + i)) for i in range(w)])
+    single(xs).square().mean().backward()
+    ok_grad = torch.allclose(g_ddp, single.a.weight.grad, atol=1e-6)
+    q.put((rank, ok_tiles, ok_grad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world_size_two_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True)]

@@ -1,0 +1,267 @@
+"""The callers of the hot path: the DSWT and MSFT super-resolution networks.
+
+Stock PyTorch layers around the kernel-backed attention modules, with the reference's module
+names so that its checkpoints load (`state_dict` keys identical):
+DSWT: DSwinT_arch.py:36-69, :340-505.   MSFT: msft_arch.py:169-210, :257-273, :318-435.
+Nothing here is a kernel; it exists so that whole-model throughput (x4 SR megapixels/s,
+training patches/s) can be measured and the drop-in can be checked end to end.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import dswin, msft
+
+
+# ------------------------------------------------------------------------------------------------
+# DSWT
+# ------------------------------------------------------------------------------------------------
+class LastChannelConv2D(nn.Module):
+    """3x3 conv on an NHWC tensor (DSwinT_arch.py:36-44)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, groups=groups)
+
+    def forward(self, x):
+        return self.conv(x.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
+
+
+class GatedMLP(nn.Module):
+    """SiLU-gated MLP (DSwinT_arch.py:47-69); registered under the reference's name `MLP`."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, ffn_scale=4, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or int(in_features * ffn_scale)
+        self.fc1_gate = nn.Linear(in_features, hidden_features)
+        self.fc1_content = nn.Linear(in_features, hidden_features)
+        self.act = nn.SiLU()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.act(self.fc1_gate(x)) * self.fc1_content(x)))
+
+
+class DSWTViTBlock(nn.Module):
+    """DSwinT_arch.py:340-358: RMSNorm + ReZero residuals around WindowedMSA, DS-MSA and the MLP."""
+
+    def __init__(self, window_size, dim, n_heads=4, ffn_scale=2, drop_path=0.0):
+        super().__init__()
+        self.wmsa = dswin.WindowedMSA(dim=dim, window_size=window_size, num_heads=n_heads)
+        self.sdwa = dswin.DeformableSparseWindowAttention(window_size, dim, num_heads=n_heads)
+        self.mlp1 = GatedMLP(dim, ffn_scale=ffn_scale)
+        self.ln1 = nn.RMSNorm(dim)
+        self.ln2 = nn.RMSNorm(dim)
+        self.ln3 = nn.RMSNorm(dim)
+        self.rezero1 = nn.Parameter(torch.zeros(1))
+        self.rezero2 = nn.Parameter(torch.zeros(1))
+        self.rezero3 = nn.Parameter(torch.zeros(1))
+        self.drop_path = nn.Dropout(drop_path)
+
+    def forward(self, x):
+        x = x + self.rezero1 * self.drop_path(self.wmsa(self.ln1(x)))
+        x = x + self.rezero3 * self.drop_path(self.sdwa(self.ln3(x)))
+        x = x + self.rezero2 * self.drop_path(self.mlp1(self.ln2(x)))
+        return x
+
+
+class DSWTResidualBlock(nn.Module):
+    """DSwinT_arch.py:361-374."""
+
+    def __init__(self, n_sub_blocks, levels, window_size, dim, level_dim, n_heads, n_heads_fuse, ffn_scale=2,
+                 drop_path=0.):
+        super().__init__()
+        self.layers = nn.Sequential(*[DSWTViTBlock(window_size=window_size, dim=dim, n_heads=n_heads,
+                                                   ffn_scale=ffn_scale, drop_path=drop_path)
+                                      for _ in range(n_sub_blocks)])
+        self.out_layer = LastChannelConv2D(dim, dim, 3, 1, 1)
+
+    def forward(self, x):
+        return self.out_layer(self.layers(x)) + x
+
+
+def _reconstruction_tail(dim, feature_dim, scale_factor, last_div):
+    layers = [nn.Conv2d(dim, feature_dim, 3, 1, 1), nn.GELU(), nn.Conv2d(feature_dim, feature_dim, 3, 1, 1)]
+    for _ in range(int(np.log2(scale_factor))):
+        layers += [nn.Conv2d(feature_dim, feature_dim * 4, 3, 1, 1), nn.PixelShuffle(2), nn.GELU()]
+    layers += [nn.Conv2d(feature_dim, feature_dim // last_div, 3, 1, 1), nn.GELU(),
+               nn.Conv2d(feature_dim // last_div, 3, 3, 1, 1)]
+    return nn.Sequential(*layers)
+
+
+def _reflect_pad_to(x, divisor):
+    _, _, h, w = x.shape
+    ph = (divisor - h % divisor) % divisor
+    pw = (divisor - w % divisor) % divisor
+    return F.pad(x, (0, pw, 0, ph), "reflect") if (ph or pw) else x
+
+
+def _init_weights(m):
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+
+
+class DSWTransformer(nn.Module):
+    """The DSWT network, `MSFTransformer` of DSwinT_arch.py:376-505.
+
+    One deliberate difference: the reference's `update_temperature` tests for an undefined class
+    (`SparseDynamicWindowAttention`, DSwinT_arch.py:483) and raises NameError on every training
+    forward; here the cosine annealing it describes is applied to the DS-MSA modules."""
+
+    def __init__(self, block_type, n_blocks, n_sub_blocks, levels, window_size, dim, level_dim, n_heads,
+                 n_heads_fuse, feature_dim, scale_factor, ffn_scale=2, drop_path=0.1, annealing_itr=250000):
+        super().__init__()
+        self.LHSA_levels = levels
+        self.dim = dim
+        self.feature_dim = feature_dim
+        self.scale_factor = scale_factor
+        self.window_size = window_size
+        self.levels = levels
+        self.annealing_itr = annealing_itr
+        self.decay_rate = (0.1 / 1.0) ** (1 / annealing_itr)
+        self.feature_extractor = nn.Conv2d(3, dim, 3, 1, 1)
+        if block_type == "default":
+            self.layers = nn.Sequential(*[DSWTResidualBlock(n_sub_blocks=n_sub_blocks, levels=levels, dim=dim,
+                                                            level_dim=level_dim, window_size=window_size,
+                                                            n_heads=n_heads, n_heads_fuse=n_heads_fuse,
+                                                            ffn_scale=ffn_scale, drop_path=drop_path)
+                                          for _ in range(n_blocks)])
+        self.feature_transition = LastChannelConv2D(dim, dim, 3, 1, 1)
+        self.img_reconstruction = _reconstruction_tail(dim, feature_dim, scale_factor, last_div=4)
+        self.register_buffer("current_iteration", torch.tensor(0, dtype=torch.long))
+        self.apply(_init_weights)
+
+    def padding(self, x):
+        divisor = self.window_size if self.levels <= 0 else self.window_size * (2 ** (self.levels - 1))
+        return _reflect_pad_to(x, divisor)
+
+    def update_temperature(self):
+        if self.current_iteration < self.annealing_itr:
+            progress = float(self.current_iteration) / self.annealing_itr
+            temp = 0.1 + 0.5 * (1.0 - 0.1) * (1 + math.cos(math.pi * progress))
+            for module in self.modules():
+                if isinstance(module, dswin.DeformableSparseWindowAttention):
+                    module.temperature = temp
+        self.current_iteration += 1
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        if self.training:
+            self.update_temperature()
+        x = self.feature_extractor(self.padding(x))
+        x = x.permute(0, 2, 3, 1).contiguous()
+        x = self.feature_transition(self.layers(x)) + x
+        x = self.img_reconstruction(x.permute(0, 3, 1, 2).contiguous())
+        return x[:, :, :H * self.scale_factor, :W * self.scale_factor]
+
+
+# ------------------------------------------------------------------------------------------------
+# MSFT
+# ------------------------------------------------------------------------------------------------
+class MSFBlock_3(nn.Module):
+    """msft_arch.py:169-210: a pyramid of PatchMerging -> ViTBlock -> PatchUnMerging levels fused
+    with the full-resolution map by one more ViTBlock."""
+
+    def __init__(self, levels, window_size, dim, level_dim, n_heads, n_heads_fuse, ffn_scale=2, drop_path=0.0):
+        super().__init__()
+        self.levels = levels
+        level_dim = dim // 2
+        self.init_ds = nn.Conv2d(dim, level_dim, 1, 1)
+        self.level_ds = nn.ModuleList([nn.Conv2d(level_dim // (4 ** i), level_dim // (4 ** (i + 1)), 1, 1)
+                                       for i in range(levels - 1)])
+        self.level_layer = nn.ModuleList([
+            nn.Sequential(msft.PatchMerging(dim=level_dim, scale=2 ** i),
+                          msft.ViTBlock(window_size, level_dim, n_heads=n_heads, ffn_scale=ffn_scale, drop_path=drop_path),
+                          msft.PatchUnMerging(dim=level_dim, scale=2 ** i))
+            for i in range(1, levels)])
+        total = sum(level_dim // (4 ** i) for i in range(1, levels))
+        self.post_level_fuse = nn.Conv2d(total, total, 3, 1, 1)
+        self.fuse = nn.Sequential(
+            msft.ViTBlock(window_size, dim + total, n_heads=n_heads_fuse, ffn_scale=ffn_scale, drop_path=drop_path),
+            nn.Conv2d(dim + total, dim, 1, 1))
+        self.rezero = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        maps = []
+        z = self.init_ds(x)
+        for i in range(self.levels - 1):
+            z = self.level_ds[i](z)
+            maps.append(self.level_layer[i](z))
+        lv = self.post_level_fuse(torch.cat(maps, dim=1))
+        return self.rezero * self.fuse(torch.cat([x, lv], dim=1)) + x
+
+
+class MSFTResidualBlock(nn.Module):
+    """msft_arch.py:257-273."""
+
+    def __init__(self, n_sub_blocks, levels, window_size, dim, level_dim, n_heads, n_heads_fuse, ffn_scale=2,
+                 drop_path=0.):
+        super().__init__()
+        self.layers = nn.Sequential(*[MSFBlock_3(levels=levels, level_dim=level_dim, dim=dim, window_size=window_size,
+                                                 n_heads=n_heads, n_heads_fuse=n_heads_fuse, ffn_scale=ffn_scale,
+                                                 drop_path=drop_path) for _ in range(n_sub_blocks)])
+        self.out_layer = nn.Conv2d(dim, dim, 3, 1, 1)
+
+    def forward(self, x):
+        return self.out_layer(self.layers(x)) + x
+
+
+class MSFTransformer(nn.Module):
+    """The MSFT network, `MSFTransformer` of msft_arch.py:318-435 (block_type "default")."""
+
+    def __init__(self, block_type, n_blocks, n_sub_blocks, levels, window_size, dim, level_dim, n_heads,
+                 n_heads_fuse, feature_dim, scale_factor, ffn_scale=4, drop_path=0.1):
+        super().__init__()
+        if block_type != "default":
+            raise NotImplementedError("only block_type='default' is built (the reference's dense variant omits a "
+                                      "required constructor argument, msft_arch.py:279-286, and cannot be built)")
+        self.LHSA_levels = levels
+        self.dim = dim
+        self.feature_dim = feature_dim
+        self.scale_factor = scale_factor
+        self.window_size = window_size
+        self.levels = levels
+        self.feature_extractor = nn.Conv2d(3, dim, 3, 1, 1)
+        self.layers = nn.Sequential(*[MSFTResidualBlock(n_sub_blocks=n_sub_blocks, levels=levels, dim=dim,
+                                                        level_dim=level_dim, window_size=window_size, n_heads=n_heads,
+                                                        n_heads_fuse=n_heads_fuse, ffn_scale=ffn_scale,
+                                                        drop_path=drop_path) for _ in range(n_blocks)])
+        self.feature_transition = nn.Conv2d(dim, dim, 3, 1, 1)
+        self.img_reconstruction = _reconstruction_tail(dim, feature_dim, scale_factor, last_div=2)
+        self.apply(_init_weights)
+
+    def padding(self, x):
+        divisor = self.window_size if self.levels <= 0 else self.window_size * (2 ** (self.levels - 1))
+        return _reflect_pad_to(x, divisor)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        x = self.feature_extractor(self.padding(x))
+        x = self.feature_transition(self.layers(x)) + x
+        x = self.img_reconstruction(x)
+        return x[:, :, :H * self.scale_factor, :W * self.scale_factor]
+
+
+def dswt_from_config(cfg):
+    """Build DSWT from the `model:` section of the reference's configs/config.yaml."""
+    m = cfg["model"] if "model" in cfg else cfg
+    return DSWTransformer(block_type=m["block_type"], n_blocks=m["n_blocks"], n_sub_blocks=m["n_sub_blocks"],
+                          levels=m["levels"], window_size=m["window_size"], dim=m["dim"], level_dim=m["level_dim"],
+                          n_heads=m["n_heads"], n_heads_fuse=m["n_heads_fuse"], feature_dim=m["feature_dim"],
+                          scale_factor=m["scale_factor"])
+
+
+DSWT_DEFAULT = dict(block_type="default", n_blocks=8, n_sub_blocks=3, levels=1, window_size=16, dim=180,
+                    level_dim=96, n_heads=6, n_heads_fuse=4, feature_dim=64, scale_factor=4)
+MSFT_CONFIG_C = dict(block_type="default", n_blocks=8, n_sub_blocks=3, levels=2, window_size=8, dim=192,
+                     level_dim=96, n_heads=6, n_heads_fuse=4, feature_dim=64, scale_factor=4)

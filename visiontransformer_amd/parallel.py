@@ -1,0 +1,110 @@
+"""Multi-GPU use of the path on one 8 x MI355X node: one process per GPU, torch.distributed.
+
+The path shards in exactly two ways, both with no collective inside the data path:
+  * training - data parallel: independent samples per rank, one gradient all-reduce per step
+    (DistributedDataParallel; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU);
+    the reference wires gloo + DDP at toolkit/init.py:111,131;
+  * large-image inference - independent spatial tiles with a halo, dealt round-robin to the
+    ranks; every rank writes its own output regions and one final reduction assembles the image
+    (the reference has no tiling: toolkit/model_helper2.py:167-191 runs whole images).
+Tile-local results differ from whole-image inference by design (DS-MSA's top-k is global per
+image and the receptive field grows with depth), so parity is defined per tile.
+"""
+import os
+from dataclasses import dataclass
+from typing import List
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+def init_distributed(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*.
+    Returns (rank, world, device).  Single process: no group is created."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or ("nccl" if use_cuda else "gloo")
+        if backend == "nccl":
+            dist.init_process_group(backend=backend, device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
+    return rank, world, device
+
+
+def data_parallel(model, device):
+    """Wrap for data-parallel training when a process group exists (gradient all-reduce in
+    buckets, overlapped with backward).  Every path of the kernel-backed modules returns
+    gradients for all parameters it used, and the early-return paths of DS-MSA leave the
+    attention parameters unused, hence find_unused_parameters."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    ids = [device.index] if device.type == "cuda" else None
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=True)
+
+
+@dataclass
+class Tile:
+    y0: int  # core region in the LR image, [y0, y1) x [x0, x1)
+    y1: int
+    x0: int
+    x1: int
+    py0: int  # padded region (core + halo), may reach outside the image: reflect-padded
+    py1: int
+    px0: int
+    px1: int
+
+
+def plan_tiles(H, W, tile=256, halo=32) -> List[Tile]:
+    """Row-major list of tiles covering an H x W image; every core is at most tile x tile."""
+    tiles = []
+    for y0 in range(0, H, tile):
+        for x0 in range(0, W, tile):
+            y1, x1 = min(y0 + tile, H), min(x0 + tile, W)
+            tiles.append(Tile(y0, y1, x0, x1, y0 - halo, y1 + halo, x0 - halo, x1 + halo))
+    return tiles
+
+
+def _reflect_crop(img, py0, py1, px0, px1):
+    """img[:, :, py0:py1, px0:px1] where the window may stick out of the image: outside pixels
+    are reflected (like the reference's padding(), DSwinT_arch.py:463)."""
+    _, _, H, W = img.shape
+    top, left = max(0, -py0), max(0, -px0)
+    bot, right = max(0, py1 - H), max(0, px1 - W)
+    core = img[:, :, max(py0, 0):min(py1, H), max(px0, 0):min(px1, W)]
+    if top or left or bot or right:
+        # reflect needs pad < size; tiny borders are padded in several steps
+        while top or left or bot or right:
+            h, w = core.shape[-2:]
+            t, b_, l, r = min(top, h - 1), min(bot, h - 1), min(left, w - 1), min(right, w - 1)
+            core = F.pad(core, (l, r, t, b_), mode="reflect")
+            top, bot, left, right = top - t, bot - b_, left - l, right - r
+    return core
+
+
+@torch.no_grad()
+def tiled_super_resolve(model, lr, scale, tile=256, halo=32, rank=0, world=1, reduce=True):
+    """x`scale` super-resolution of lr [B,3,H,W] by tiles with halo.  Rank r computes tiles
+    r, r + world, ...; with reduce=True the disjoint output regions are summed over the group so
+    every rank returns the whole image (a single collective, after all compute)."""
+    B, C, H, W = lr.shape
+    out = torch.zeros(B, C, H * scale, W * scale, dtype=lr.dtype, device=lr.device)
+    for i, t in enumerate(plan_tiles(H, W, tile, halo)):
+        if i % world != rank:
+            continue
+        patch = _reflect_crop(lr, t.py0, t.py1, t.px0, t.px1)
+        sr = model(patch).to(out.dtype)
+        oy, ox = (t.y0 - t.py0) * scale, (t.x0 - t.px0) * scale
+        out[:, :, t.y0 * scale:t.y1 * scale, t.x0 * scale:t.x1 * scale] = \
+            sr[:, :, oy:oy + (t.y1 - t.y0) * scale, ox:ox + (t.x1 - t.x0) * scale]
+    if reduce and world > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    return out
