@@ -187,6 +187,37 @@ int dsw_shuffle_nchw_fwd(const void *t, int dtype, int B, int H, int W, int C, i
 int dsw_unshuffle_nhwc_fwd(const void *x, int dtype, int B, int c, int H, int W, int s, void *y,
                            void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Convolutions that sit on the DS-MSA path, NHWC, so that the reference's NHWC->NCHW round trip
+ * (DSwinT_arch.py:259, :317) disappears.  Weights and their gradients are fp32.
+ *
+ * dsw_dwconv3x3_fwd/bwd: depthwise 3x3, stride 1, zero padding 1 (out_conv, DSwinT_arch.py:198,
+ *   :317).  weight [C,9], bias [C] or NULL.  bwd writes dx, d_weight [C,9], d_bias [C];
+ *   partial: caller scratch of (dsw_dwconv3x3_bwd_blocks(B,H,W) + 1) * C * 10 floats.
+ * dsw_sparse_disc_fwd/bwd: the sparse discriminator (DSwinT_arch.py:180-186, :266) =
+ *   conv C->4 3x3 p1 (w0 [4,C,3,3], b0) + SiLU + conv 4->4 k=w stride w (w2 [4,4,w,w], b2) + SiLU
+ *   + conv 4->4 3x3 p1 (w4 [4,4,3,3], b4).  x [B,H,W,C] -> sd [B,4,H/w,W/w] (NCHW, sd_dtype);
+ *   t0 [B,H,W,4] fp32 and u [B,4,H/w,W/w] fp32 (the two pre-activation tensors) are saved for
+ *   the backward.  bwd: dsd -> dx [B,H,W,C] and the six parameter gradients; scratch: caller
+ *   buffer of dsw_sparse_disc_bwd_scratch(B,H,W,C,w) floats.
+ */
+int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B,
+                      int H, int W, int C, void *y, int y_dtype, void *stream);
+int dsw_dwconv3x3_bwd_blocks(int B, int H, int W);
+int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype, const float *weight,
+                      int B, int H, int W, int C, void *dx, int dx_dtype, float *d_weight,
+                      float *d_bias, float *partial, void *stream);
+int dsw_sparse_disc_fwd(const void *x, int x_dtype, const float *w0, const float *b0,
+                        const float *w2, const float *b2, const float *w4, const float *b4, int B,
+                        int H, int W, int C, int w, float *t0, float *u, void *sd, int sd_dtype,
+                        void *stream);
+int dsw_sparse_disc_bwd_blocks(int B, int H);
+size_t dsw_sparse_disc_bwd_scratch(int B, int H, int W, int C, int w);
+int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x, int x_dtype, const float *w0,
+                        const float *w2, const float *w4, const float *t0, const float *u, int B,
+                        int H, int W, int C, int w, void *dx, int dx_dtype, float *dw0, float *db0,
+                        float *dw2, float *db2, float *dw4, float *db4, float *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,3 +259,56 @@ def test_unsupported_arguments_fail_loudly(cuda0):
         K.window_attention(torch.zeros(1, 16, 3 * 8, device=cuda0), None, 4, 2, QKV_CHUNKED)
     with pytest.raises(RuntimeError, match="GPU only"):
         K.window_attention(torch.zeros(1, 64, 3 * 8), None, 8, 2, QKV_CHUNKED)
+
+
+# ----------------------------------------------------------------------------------------------
+# NHWC convolutions on the path
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 24, 12), (1, 32, 32, 180), (1, 5, 70, 8)])
+def test_dwconv3x3(cuda0, dtype, B, H, W, C):
+    K = _K()
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(C)
+    x = torch.randn(B, H, W, C, generator=gen)
+    wgt = torch.randn(C, 1, 3, 3, generator=gen) * 0.3
+    bias = torch.randn(C, generator=gen) * 0.1
+    r = torch.randn(B, H, W, C, generator=gen)
+    leaves = [t.clone().requires_grad_() for t in (x, wgt, bias)]
+    ref = F.conv2d(leaves[0].permute(0, 3, 1, 2), leaves[1], leaves[2], 1, 1, groups=C).permute(0, 2, 3, 1)
+    (ref * r).sum().backward()
+    gl = [x.to(cuda0).to(dtype).requires_grad_(), wgt.to(cuda0).requires_grad_(), bias.to(cuda0).requires_grad_()]
+    y = K.dwconv3x3_nhwc(gl[0], gl[1], gl[2])
+    (y.float() * r.to(cuda0)).sum().backward()
+    tol = TOL[dtype]
+    assert rel_err(y, ref) < tol
+    for got, want, name in zip(gl, leaves, ("x", "weight", "bias")):
+        assert rel_err(got.grad, want.grad) < tol, name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,w", [(2, 16, 24, 12, 8), (1, 64, 64, 180, 16), (2, 32, 16, 24, 16)])
+def test_sparse_discriminator(cuda0, dtype, B, H, W, C, w):
+    K = _K()
+    gen = torch.Generator().manual_seed(C + w)
+    x = torch.randn(B, H, W, C, generator=gen)
+    convs = torch.nn.Sequential(torch.nn.Conv2d(C, 4, 3, 1, 1), torch.nn.SiLU(), torch.nn.Conv2d(4, 4, w, stride=w),
+                                torch.nn.SiLU(), torch.nn.Conv2d(4, 4, 3, 1, 1))
+    with torch.no_grad():
+        for p in convs.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * (0.3 if p.dim() == 1 else (2.0 / p[0].numel()) ** 0.5))
+    P = {"sparse_discriminator." + k: v.detach().clone().requires_grad_() for k, v in convs.state_dict().items()}
+    xc = x.clone().requires_grad_()
+    ref = D.sparse_discriminator(P, xc.permute(0, 3, 1, 2).contiguous(), w)
+    r = torch.randn(ref.shape, generator=gen)
+    (ref * r).sum().backward()
+    convs = convs.to(cuda0)
+    xg = x.to(cuda0).to(dtype).requires_grad_()
+    sd = K.sparse_discriminator_nhwc(xg, (convs[0], convs[2], convs[4]), w)
+    assert sd.shape == ref.shape
+    (sd.float() * r.to(cuda0)).sum().backward()
+    tol = TOL[dtype]
+    assert rel_err(sd, ref) < tol
+    assert rel_err(xg.grad, xc.grad) < tol
+    for k, p in convs.state_dict(keep_vars=True).items():
+        assert rel_err(p.grad, P["sparse_discriminator." + k].grad) < tol, k

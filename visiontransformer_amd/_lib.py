@@ -42,6 +42,14 @@ SIGNATURES = {
     "dsw_unshuffle_nhwc_ln_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dsw_shuffle_nchw_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dsw_unshuffle_nhwc_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dsw_dwconv3x3_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "dsw_dwconv3x3_bwd_blocks": (_I, [_I, _I, _I]),
+    "dsw_dwconv3x3_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "dsw_sparse_disc_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "dsw_sparse_disc_bwd_blocks": (_I, [_I, _I]),
+    "dsw_sparse_disc_bwd_scratch": (_Z, [_I, _I, _I, _I, _I]),
+    "dsw_sparse_disc_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I,
+                                 _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 

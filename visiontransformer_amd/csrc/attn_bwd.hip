@@ -14,6 +14,8 @@
 // with LDS float adds into one private table per wave (program order inside a wave => bitwise
 // reproducible), summed in wave order and written as a per-(window, head) partial that a second
 // kernel reduces over windows in a fixed order.
+#include <utility>
+
 #include "attn_common.hpp"
 
 #pragma clang fp contract(fast)
@@ -40,7 +42,7 @@ template <typename T, int WS, int DP> struct BwdCfg {
     static constexpr int N_QBT = BF ? DP * TQS : 0;
     static constexpr size_t lds_bytes(bool bias) {
         return (size_t)(N_K + N_DS + 2 * N_QB + 2 * N_QBT) * sizeof(T) + (size_t)2 * L * sizeof(float) +
-               (bias ? (size_t)bias_lds<WS>::FLOATS * sizeof(float) : 0);
+               (bias ? (size_t)(bias_lds<WS>::FLOATS + (WS == 16 ? NW * 31 * 32 : 0)) * sizeof(float) : 0);
     }
     static constexpr int MIN_WAVES = (BF && !(WS == 16 && DP == 64)) ? 2 : 1;
 };
@@ -61,6 +63,39 @@ __device__ __forceinline__ uint4 load_bf16x8_masked(const bf16_t *row, int e0, i
     }
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
+
+// ---- d(bias table) for 16 x 16 windows: diagonal sums in registers ---------------------------------
+// In a dS tile (query = row = register, key = column = lane) the table entry of an element is
+// (di, dj) = (qi - ki, qj - kj).  Rotating each register's 16-lane rows by its qj puts every
+// element with the same dj in the same lane, so the 8 registers of one query row-group add up
+// element-wise; lanes whose rotation wrapped belong to dj + 16 and are kept apart by a 0/1 mask.
+template <int QJ_LO>  // rotate lane rows left by qj: lanes 0-31 hold qj = QJ_LO, lanes 32-63 qj = QJ_LO + 4
+__device__ __forceinline__ float rot_rows_by_qj(float x) {
+    const int xi = __float_as_int(x);
+    int y = xi;
+    if constexpr (((16 - QJ_LO) & 15) != 0) y = __builtin_amdgcn_update_dpp(y, xi, 0x120 + ((16 - QJ_LO) & 15), 0x3, 0xF, false);
+    if constexpr (((12 - QJ_LO) & 15) != 0) y = __builtin_amdgcn_update_dpp(y, xi, 0x120 + ((12 - QJ_LO) & 15), 0xC, 0xF, false);
+    return __int_as_float(y);
+}
+// lanes 0-31 receive the value of lane + 32 (v_permlane32_swap); lanes 32-63 are unspecified
+__device__ __forceinline__ float upper_half_to_lower(float x) {
+    const unsigned xi = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    return __uint_as_float(r[1]);
+}
+template <int R>
+__device__ __forceinline__ void diag_step(const f32x16 &ds, const float (&wrapf)[8], float (&all)[2], float (&wrapped)[2]) {
+    constexpr int QJ_LO = (R & 3) + 8 * ((R >> 2) & 1);
+    const float y = rot_rows_by_qj<QJ_LO>(ds[R]);
+    all[R >> 3] += y;
+    wrapped[R >> 3] = fmaf(y, wrapf[R & 7], wrapped[R >> 3]);
+}
+template <int... R>
+__device__ __forceinline__ void diag_sums(std::integer_sequence<int, R...>, const f32x16 &ds, const float (&wrapf)[8],
+                                          float (&all)[2], float (&wrapped)[2]) {
+    (diag_step<R>(ds, wrapf, all, wrapped), ...);
+}
+constexpr int BGW_STRIDE = 32, BGW_FLOATS = 31 * 32;  // per-wave gradient table [di+15][dj+15], w = 16
 
 template <typename T, int WS, int DP, bool BIAS, bool LEPE>
 __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::MIN_WAVES)) void win_attn_bwd_kernel(
@@ -83,6 +118,7 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     float *delta_s = reinterpret_cast<float *>(dObt + Cfg::N_QBT);  // [L]
     float *lse_s = delta_s + L;                                     // [L], already times log2(e)
     float *tb = lse_s + L;                                          // BIAS: [TBF]
+    float *bgw = tb + TBF;                                          // BIAS, w = 16: [NW][BGW_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
@@ -189,7 +225,15 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             const int di = it / TR, dj = it - di * TR;
             tb[di * TS + dj] = table[(size_t)it * g.heads + head] * LOG2E;
         }
+        if constexpr (WS == 16) {
+            for (int it = tid; it < NW * BGW_FLOATS; it += THREADS) bgw[it] = 0.f;
+        }
     }
+    // 1.0 where rotating a register's lane row by its qj wrapped around (those elements belong
+    // to dj + 16); index = register & 7, whose qj is (j & 3) + 8 (j >> 2) + 4 hh
+    float wrapf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wrapf[j] = ((lane & 15) + (j & 3) + 8 * (j >> 2) + 4 * hh >= 16) ? 1.f : 0.f;
 
     // this wave's K and V fragments (B operands: k-dim = head dim, column = key on the lane)
     uint4 kfb[BF ? KT : 1][DP / 16], vfb[BF ? KT : 1][DP / 16];
@@ -303,14 +347,6 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         __syncthreads();
         if (qb + 1 < NT) load_block(qb + 1);
 
-        // per-row constants of this lane's 16 accumulator rows: q = qb*32 + rho(r) + 4hh
-        float lrow[16], drow[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            lrow[r] = lse_s[qb * 32 + rho(r) + 4 * hh];
-            drow[r] = delta_s[qb * 32 + rho(r) + 4 * hh];
-        }
-
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const int tile = wave * KT + kt;
@@ -323,10 +359,11 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q_c = rho(r);
-                float v0 = -lrow[r];
+                // per-row constants of accumulator row r: query qb*32 + rho(r) + 4hh
+                float v0 = -lse_s[qb * 32 + q_c + 4 * hh];
                 if constexpr (BIAS) v0 += tb[lane_base + (q_c / WS) * TS + (q_c % WS)];
                 sacc[r] = v0;
-                pacc[r] = -drow[r];
+                pacc[r] = -delta_s[qb * 32 + q_c + 4 * hh];
             }
             // ---- S = Q K^T and dP = dO V^T (rows = queries, lane = key) ---------------------------
             if constexpr (BF) {
@@ -359,6 +396,28 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                 const float ds = p * pacc[r];
                 sacc[r] = p;
                 pacc[r] = ds;
+            }
+            if constexpr (BIAS && WS == 16) {
+                float all[2] = {0.f, 0.f}, wrapped[2] = {0.f, 0.f};
+                diag_sums(std::make_integer_sequence<int, 16>{}, pacc, wrapf, all, wrapped);
+#pragma unroll
+                for (int G = 0; G < 2; ++G) {  // lanes 0-31 += lanes 32-63 (one VALU swap, no LDS round trip)
+                    all[G] += upper_half_to_lower(all[G]);
+                    wrapped[G] += upper_half_to_lower(wrapped[G]);
+                }
+                if (hh == 0) {
+                    // lane (kip, m): entries (di, -m) and, for wrapped elements, (di, 16 - m).  Plain
+                    // read-add-write on the wave's own table (no two lanes of one instruction share an
+                    // entry; LDS float atomics cost hundreds of cycles each on this chip)
+                    const int m = lane & 15, kip = (lane >> 4) & 1;
+                    float *tw = bgw + wave * BGW_FLOATS;
+#pragma unroll
+                    for (int G = 0; G < 2; ++G) {
+                        const int row = (2 * (qb - tile) + G - kip + 15) * BGW_STRIDE;
+                        tw[row + 15 - m] += all[G] - wrapped[G];
+                        if (m > 0) tw[row + 31 - m] += wrapped[G];
+                    }
+                }
             }
             // ---- dS block to LDS for dQ ---------------------------------------------------------------
 #pragma unroll
@@ -402,7 +461,7 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         // ---- d(bias table): every thread owns a few table entries (di, dj) and sums the dS elements
         // of this block that map to them, straight from the dS tile - a gather in a fixed order,
         // so no atomics and bitwise reproducible.  Lanes that differ in dj read neighbouring keys.
-        if constexpr (BIAS) {
+        if constexpr (BIAS && WS != 16) {
             const int dj = (tid % (2 * WS)) - (WS - 1);   // lane WS*2-1 of each group is idle
             const int dig = tid / (2 * WS);                // 8 groups of di values
             if (dj < WS) {
@@ -503,13 +562,24 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     if constexpr (BIAS) {
         // the table entered the logits times log2(e) inside exp2, so d/dtable is dS itself
         float *dst = ws_table + ((size_t)win * g.heads + head) * (TR * TR);
-        const int dj = (tid % (2 * WS)) - (WS - 1);
-        const int dig = tid / (2 * WS);
-        if (dj < WS) {
+        if constexpr (WS == 16) {
+            __syncthreads();
+            for (int it = tid; it < TR * TR; it += THREADS) {
+                const int di = it / TR, dj = it - di * TR;
+                float acc = 0.f;
 #pragma unroll
-            for (int n = 0; n < BG_N; ++n) {
-                const int di = dig + 8 * n - (WS - 1);
-                if (di < WS) dst[(di + WS - 1) * TR + dj + WS - 1] = bgacc[n];
+                for (int wv = 0; wv < NW; ++wv) acc += bgw[wv * BGW_FLOATS + di * BGW_STRIDE + dj];
+                dst[it] = acc;
+            }
+        } else {
+            const int dj = (tid % (2 * WS)) - (WS - 1);
+            const int dig = tid / (2 * WS);
+            if (dj < WS) {
+#pragma unroll
+                for (int n = 0; n < BG_N; ++n) {
+                    const int di = dig + 8 * n - (WS - 1);
+                    if (di < WS) dst[(di + WS - 1) * TR + dj + WS - 1] = bgacc[n];
+                }
             }
         }
     }

@@ -1,0 +1,584 @@
+// NHWC convolutions that sit on the DS-MSA path next to the attention kernels:
+//   * depthwise 3x3 (out_conv, DSwinT_arch.py:198, :317), forward / data gradient / weight gradient;
+//   * the sparse discriminator (DSwinT_arch.py:180-186, :266): conv C->4 3x3 + SiLU + conv 4->4
+//     k=w stride w + SiLU + conv 4->4 3x3, forward and backward, without the reference's
+//     NHWC->NCHW copy of the whole activation.
+// All are bandwidth-bound: every kernel streams the activation once, 4 channels per lane, with the
+// small weight sets in LDS.  Parameter gradients use per-block partial sums reduced in a fixed
+// order (no atomics, bitwise reproducible).
+#include "common.hpp"
+
+namespace dsw {
+
+constexpr int CV_THREADS = 256;
+constexpr int CV_TILE = 32;  // pixels of one image row per block (stream kernels)
+
+__device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float silu_grad(float v) {
+    const float s = 1.f / (1.f + __expf(-v));
+    return s * (1.f + v * (1.f - s));
+}
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 fma4s(float4 a, float s, float4 c) {
+    return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise 3x3, stride 1, zero padding 1.  FLIP = data gradient (taps mirrored, no bias).
+// weights [C][9] fp32 in global -> LDS as [9][C]
+// ---------------------------------------------------------------------------------------------
+template <typename TI, typename TO, bool FLIP>
+__global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__restrict__ x, const float *__restrict__ wgt,
+                                                                   const float *__restrict__ bias, int H, int W, int C,
+                                                                   int tiles, TO *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];  // [9][C] + [C]
+    for (int i = threadIdx.x; i < C * 9; i += CV_THREADS) {
+        const int c = i / 9, t = i - c * 9;
+        ws[(FLIP ? 8 - t : t) * C + c] = wgt[i];
+    }
+    for (int i = threadIdx.x; i < C; i += CV_THREADS) ws[9 * C + i] = (bias != nullptr && !FLIP) ? bias[i] : 0.f;
+    __syncthreads();
+    const int tile = blockIdx.x % tiles, h = (blockIdx.x / tiles) % H, b = blockIdx.x / (tiles * H);
+    const int x0 = tile * CV_TILE, npix = min(CV_TILE, W - x0), CV = C >> 2;
+    const TI *img = x + (size_t)b * H * W * C;
+    for (int it = threadIdx.x; it < npix * CV; it += CV_THREADS) {
+        const int p = it / CV, c = (it - p * CV) << 2, xx = x0 + p;
+        float4 acc = *reinterpret_cast<const float4 *>(ws + 9 * C + c);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int yy = h + a - 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+                const int xc = xx + bb - 1;
+                if (xc < 0 || xc >= W) continue;
+                acc = fma4(io<TI>::ld4(img + ((size_t)yy * W + xc) * C + c), *reinterpret_cast<const float4 *>(ws + (a * 3 + bb) * C + c), acc);
+            }
+        }
+        io<TO>::st4(y + (((size_t)b * H + h) * W + xx) * C + c, acc);
+    }
+}
+
+// weight / bias gradient partials: one block per ROWS image rows; thread = (channel quad, pixel group)
+constexpr int DW_ROWS = 2;
+template <typename TG, typename TX>
+__global__ __launch_bounds__(CV_THREADS) void dwconv_wgrad_kernel(const TG *__restrict__ dy, const TX *__restrict__ x, int H,
+                                                                  int W, int C, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [PG][CV][40]
+    const int CV = C >> 2, PG = CV_THREADS / CV;
+    const int rows_per_img = (H + DW_ROWS - 1) / DW_ROWS;
+    const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x - b * rows_per_img) * DW_ROWS;
+    const int cv = threadIdx.x % CV, pg = threadIdx.x / CV;
+    float4 acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = f4zero();
+    if (pg < PG) {
+        const int c = cv << 2;
+        const TG *gimg = dy + (size_t)b * H * W * C;
+        const TX *ximg = x + (size_t)b * H * W * C;
+        for (int h = h0; h < min(h0 + DW_ROWS, H); ++h) {
+            for (int p = pg; p < W; p += PG) {
+                const float4 g = io<TG>::ld4(gimg + ((size_t)h * W + p) * C + c);
+                acc[9] = acc[9] + g;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int yy = h + a - 1;
+                    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) {
+                        const int xc = p + bb - 1;
+                        if (xc < 0 || xc >= W) continue;
+                        acc[a * 3 + bb] = fma4(g, io<TX>::ld4(ximg + ((size_t)yy * W + xc) * C + c), acc[a * 3 + bb]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) *reinterpret_cast<float4 *>(red + ((size_t)(pg * CV + cv) * 10 + i) * 4) = acc[i];
+    }
+    __syncthreads();
+    // partial[blk][c][k]: sum over pixel groups in order
+    for (int i = threadIdx.x; i < C * 10; i += CV_THREADS) {
+        const int c = i / 10, k = i - c * 10;
+        float s = 0.f;
+        for (int g2 = 0; g2 < PG; ++g2) s += red[((size_t)(g2 * CV + (c >> 2)) * 10 + k) * 4 + (c & 3)];
+        partial[(size_t)blockIdx.x * C * 10 + i] = s;
+    }
+}
+
+// out[i] = sum over blocks of partial[blk][i], 16 interleaved groups then the 16 partials in order
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float *__restrict__ partial, int nblocks, int n,
+                                                             float *__restrict__ out) {
+    __shared__ float part[16][17];
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    float acc = 0.f;
+    if (i < n)
+        for (int bl = grp; bl < nblocks; bl += 16) acc += partial[(size_t)bl * n + i];
+    part[grp][e] = acc;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][e];
+        out[i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sparse discriminator
+//   stage A (per window block): t0 = conv0(x) [saved, pre-SiLU], u = conv2(silu(t0)) [saved, pre-SiLU]
+//   stage B (tiny):            sd = conv4(silu(u))
+// weights: w0 [4][C][3][3], b0 [4]; w2 [4][4][w][w], b2 [4]; w4 [4][4][3][3], b4 [4]  (fp32)
+// ---------------------------------------------------------------------------------------------
+// LDS copy of w0 as [tap][ci][o] so that one float4 read gives the 4 outputs of (tap, ci)
+template <typename TX>
+__global__ __launch_bounds__(CV_THREADS) void sd_stage_a_kernel(const TX *__restrict__ x, const float *__restrict__ w0,
+                                                                const float *__restrict__ b0, const float *__restrict__ w2,
+                                                                const float *__restrict__ b2, int H, int W, int C, int w,
+                                                                float *__restrict__ t0, float *__restrict__ u) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *w0s = sm;                  // [9][C][4]
+    float *w2s = w0s + 9 * C * 4;     // [w*w][4 (c2)][4 (o)]
+    float *red = w2s + w * w * 16;    // [CV_THREADS/16][4]
+    const int Hw = H / w, Ww = W / w, L = w * w;
+    const int wc = blockIdx.x % Ww, wr = (blockIdx.x / Ww) % Hw, b = blockIdx.x / (Ww * Hw);
+    for (int i = threadIdx.x; i < 4 * C * 9; i += CV_THREADS) {
+        const int o = i / (C * 9), r = i - o * C * 9, ci = r / 9, t = r - ci * 9;
+        w0s[(t * C + ci) * 4 + o] = w0[i];
+    }
+    for (int i = threadIdx.x; i < 16 * L; i += CV_THREADS) {
+        const int o = i / (4 * L), r = i - o * 4 * L, c2 = r / L, pix = r - c2 * L;
+        w2s[(pix * 4 + c2) * 4 + o] = w2[i];
+    }
+    __syncthreads();
+    // 16 lanes per pixel, each over a strided share of the channel quads
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, CV = C >> 2;
+    const TX *img = x + (size_t)b * H * W * C;
+    float4 uacc = f4zero();  // this group's share of u[0..3]
+    for (int pix = grp; pix < L; pix += CV_THREADS / 16) {
+        const int y = wr * w + pix / w, xx = wc * w + pix % w;
+        float4 acc = f4zero();  // conv0 outputs 0..3 (partial over this lane's channels)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int yy = y + a - 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+                const int xc = xx + bb - 1;
+                if (xc < 0 || xc >= W) continue;
+                const float *wt = w0s + (size_t)(a * 3 + bb) * C * 4;
+                for (int cv = gl; cv < CV; cv += 16) {
+                    const float4 v = io<TX>::ld4(img + ((size_t)yy * W + xc) * C + (cv << 2));
+                    const float4 *wq = reinterpret_cast<const float4 *>(wt + (cv << 2) * 4);
+                    acc = fma4s(wq[0], v.x, acc);
+                    acc = fma4s(wq[1], v.y, acc);
+                    acc = fma4s(wq[2], v.z, acc);
+                    acc = fma4s(wq[3], v.w, acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64);
+            acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64);
+            acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        acc.x += b0[0];
+        acc.y += b0[1];
+        acc.z += b0[2];
+        acc.w += b0[3];
+        if (gl == 0) *reinterpret_cast<float4 *>(t0 + (((size_t)b * H + y) * W + xx) * 4) = acc;
+        // conv2 contribution of this pixel: u[o] += sum_c2 w2[o][c2][pix] * silu(t0[c2])
+        const float4 *w2q = reinterpret_cast<const float4 *>(w2s + pix * 16);
+        if (gl == 0) {
+            uacc = fma4s(w2q[0], silu(acc.x), uacc);
+            uacc = fma4s(w2q[1], silu(acc.y), uacc);
+            uacc = fma4s(w2q[2], silu(acc.z), uacc);
+            uacc = fma4s(w2q[3], silu(acc.w), uacc);
+        }
+    }
+    if (gl == 0) *reinterpret_cast<float4 *>(red + grp * 4) = uacc;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float s = b2[threadIdx.x];
+        for (int g2 = 0; g2 < CV_THREADS / 16; ++g2) s += red[g2 * 4 + threadIdx.x];
+        u[((size_t)(b * 4 + threadIdx.x) * Hw + wr) * Ww + wc] = s;
+    }
+}
+
+// sd[b,o,r,c] = b4[o] + sum_{c2,taps} w4[o][c2][tap] * silu(u[b,c2,r+a-1,c+bb-1]);  thread per output
+template <typename TO>
+__global__ void sd_stage_b_kernel(const float *__restrict__ u, const float *__restrict__ w4, const float *__restrict__ b4,
+                                  int B, int Hw, int Ww, TO *__restrict__ sd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 4 * Hw * Ww) return;
+    const int c = i % Ww, r = (i / Ww) % Hw, o = (i / (Ww * Hw)) % 4, b = i / (Ww * Hw * 4);
+    float acc = b4[o];
+    for (int c2 = 0; c2 < 4; ++c2)
+        for (int a = 0; a < 3; ++a) {
+            const int rr = r + a - 1;
+            if (rr < 0 || rr >= Hw) continue;
+            for (int bb = 0; bb < 3; ++bb) {
+                const int cc = c + bb - 1;
+                if (cc < 0 || cc >= Ww) continue;
+                acc = fmaf(w4[(o * 4 + c2) * 9 + a * 3 + bb], silu(u[((size_t)(b * 4 + c2) * Hw + rr) * Ww + cc]), acc);
+            }
+        }
+    io<TO>::st(sd + i, acc);
+}
+
+// ---- backward ------------------------------------------------------------------------------------------
+// stage B backward, thread per (b, c2, r, c): du = silu'(u) * sum_{o,taps} w4[o][c2][tap] * dsd[b,o,r-(a-1),c-(bb-1)]
+template <typename TG>
+__global__ void sd_bwd_b_kernel(const TG *__restrict__ dsd, const float *__restrict__ u, const float *__restrict__ w4, int B,
+                                int Hw, int Ww, float *__restrict__ du) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 4 * Hw * Ww) return;
+    const int c = i % Ww, r = (i / Ww) % Hw, c2 = (i / (Ww * Hw)) % 4, b = i / (Ww * Hw * 4);
+    float acc = 0.f;
+    for (int o = 0; o < 4; ++o)
+        for (int a = 0; a < 3; ++a) {
+            const int rr = r - (a - 1);
+            if (rr < 0 || rr >= Hw) continue;
+            for (int bb = 0; bb < 3; ++bb) {
+                const int cc = c - (bb - 1);
+                if (cc < 0 || cc >= Ww) continue;
+                acc = fmaf(w4[(o * 4 + c2) * 9 + a * 3 + bb], io<TG>::ld(dsd + ((size_t)(b * 4 + o) * Hw + rr) * Ww + cc), acc);
+            }
+        }
+    du[i] = acc * silu_grad(u[i]);
+}
+
+// d(w4) [4][4][9] and d(b4) [4]: one block, thread per entry, fixed-order loop over all cells
+template <typename TG>
+__global__ void sd_bwd_w4_kernel(const TG *__restrict__ dsd, const float *__restrict__ u, int B, int Hw, int Ww,
+                                 float *__restrict__ dw4, float *__restrict__ db4) {
+    const int i = threadIdx.x;
+    if (i < 144) {
+        const int o = i / 36, c2 = (i / 9) % 4, a = (i % 9) / 3, bb = i % 3;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int r = 0; r < Hw; ++r) {
+                const int rr = r + a - 1;
+                if (rr < 0 || rr >= Hw) continue;
+                for (int c = 0; c < Ww; ++c) {
+                    const int cc = c + bb - 1;
+                    if (cc < 0 || cc >= Ww) continue;
+                    acc = fmaf(io<TG>::ld(dsd + ((size_t)(b * 4 + o) * Hw + r) * Ww + c), silu(u[((size_t)(b * 4 + c2) * Hw + rr) * Ww + cc]), acc);
+                }
+            }
+        dw4[i] = acc;
+    } else if (i < 148) {
+        const int o = i - 144;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < Hw * Ww; ++j) acc += io<TG>::ld(dsd + (size_t)(b * 4 + o) * Hw * Ww + j);
+        db4[o] = acc;
+    }
+}
+
+// stage A backward, window side: dt0[b,y,x,c2] = silu'(t0) * sum_o w2[o][c2][pix] * du[b,o,win];  thread per pixel
+__global__ void sd_bwd_a_pix_kernel(const float *__restrict__ du, const float *__restrict__ t0, const float *__restrict__ w2,
+                                    int B, int H, int W, int w, float *__restrict__ dt0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * W) return;
+    const int xx = i % W, y = (i / W) % H, b = i / (W * H);
+    const int Hw = H / w, Ww = W / w, L = w * w;
+    const int wr = y / w, wc = xx / w, pix = (y - wr * w) * w + (xx - wc * w);
+    float d[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) d[o] = du[((size_t)(b * 4 + o) * Hw + wr) * Ww + wc];
+    const float4 t = *reinterpret_cast<const float4 *>(t0 + (size_t)i * 4);
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    float out[4];
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {
+        float acc = 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc = fmaf(w2[(size_t)(o * 4 + c2) * L + pix], d[o], acc);
+        out[c2] = acc * silu_grad(tv[c2]);
+    }
+    *reinterpret_cast<float4 *>(dt0 + (size_t)i * 4) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// d(w2) [4][4][L] and d(b2) [4]: thread per entry, fixed-order loop over all windows
+__global__ void sd_bwd_w2_kernel(const float *__restrict__ du, const float *__restrict__ t0, int B, int H, int W, int w,
+                                 float *__restrict__ dw2, float *__restrict__ db2) {
+    const int L = w * w, Hw = H / w, Ww = W / w;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16 * L) {
+        const int o = i / (4 * L), c2 = (i / L) % 4, pix = i % L;
+        const int py = pix / w, px = pix - py * w;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int wr = 0; wr < Hw; ++wr)
+                for (int wc = 0; wc < Ww; ++wc)
+                    acc = fmaf(du[((size_t)(b * 4 + o) * Hw + wr) * Ww + wc],
+                               silu(t0[(((size_t)b * H + wr * w + py) * W + wc * w + px) * 4 + c2]), acc);
+        dw2[i] = acc;
+    } else if (i < 16 * L + 4) {
+        const int o = i - 16 * L;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < Hw * Ww; ++j) acc += du[(size_t)(b * 4 + o) * Hw * Ww + j];
+        db2[o] = acc;
+    }
+}
+
+// dx[b,y,x,ci] = sum_{o,taps} w0[o][ci][tap] * dt0[b, y-(a-1), x-(bb-1), o]   (pixel-centric stream)
+template <typename TO>
+__global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__restrict__ dt0, const float *__restrict__ w0,
+                                                               int H, int W, int C, int tiles, TO *__restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) float w0s[];  // [tap][o][C]
+    for (int i = threadIdx.x; i < 4 * C * 9; i += CV_THREADS) {
+        const int o = i / (C * 9), r = i - o * C * 9, ci = r / 9, t = r - ci * 9;
+        w0s[(t * 4 + o) * C + ci] = w0[i];
+    }
+    __syncthreads();
+    const int tile = blockIdx.x % tiles, h = (blockIdx.x / tiles) % H, b = blockIdx.x / (tiles * H);
+    const int x0 = tile * CV_TILE, npix = min(CV_TILE, W - x0), CV = C >> 2;
+    const float *gimg = dt0 + (size_t)b * H * W * 4;
+    for (int it = threadIdx.x; it < npix * CV; it += CV_THREADS) {
+        const int p = it / CV, c = (it - p * CV) << 2, xx = x0 + p;
+        float4 acc = f4zero();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int yy = h - (a - 1);
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+                const int xc = xx - (bb - 1);
+                if (xc < 0 || xc >= W) continue;
+                const float4 g = *reinterpret_cast<const float4 *>(gimg + ((size_t)yy * W + xc) * 4);
+                const float *wt = w0s + (size_t)(a * 3 + bb) * 4 * C + c;
+                acc = fma4s(*reinterpret_cast<const float4 *>(wt), g.x, acc);
+                acc = fma4s(*reinterpret_cast<const float4 *>(wt + C), g.y, acc);
+                acc = fma4s(*reinterpret_cast<const float4 *>(wt + 2 * C), g.z, acc);
+                acc = fma4s(*reinterpret_cast<const float4 *>(wt + 3 * C), g.w, acc);
+            }
+        }
+        io<TO>::st4(dx + (((size_t)b * H + h) * W + xx) * C + c, acc);
+    }
+}
+
+// d(w0) partials: block = SD_ROWS image rows; work item = (channel quad, tap); 16 accumulators each
+constexpr int SD_ROWS = 8;
+template <typename TX>
+__global__ __launch_bounds__(CV_THREADS) void sd_bwd_w0_kernel(const float *__restrict__ dt0, const TX *__restrict__ x, int H,
+                                                               int W, int C, float *__restrict__ partial) {
+    const int CV = C >> 2, rows_per_img = (H + SD_ROWS - 1) / SD_ROWS;
+    const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x - b * rows_per_img) * SD_ROWS;
+    const float *gimg = dt0 + (size_t)b * H * W * 4;
+    const TX *ximg = x + (size_t)b * H * W * C;
+    float *dst = partial + (size_t)blockIdx.x * (4 * C * 9 + 4);
+    for (int item = threadIdx.x; item < CV * 9; item += CV_THREADS) {
+        const int cv = item / 9, t = item - cv * 9, a = t / 3, bb = t - a * 3, c = cv << 2;
+        float4 acc[4];  // [o] x 4 channels
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] = f4zero();
+        for (int h = h0; h < min(h0 + SD_ROWS, H); ++h) {
+            const int yy = h + a - 1;
+            if (yy < 0 || yy >= H) continue;
+            for (int p = 0; p < W; ++p) {
+                const int xc = p + bb - 1;
+                if (xc < 0 || xc >= W) continue;
+                const float4 g = *reinterpret_cast<const float4 *>(gimg + ((size_t)h * W + p) * 4);
+                const float4 v = io<TX>::ld4(ximg + ((size_t)yy * W + xc) * C + c);
+                acc[0] = fma4s(v, g.x, acc[0]);
+                acc[1] = fma4s(v, g.y, acc[1]);
+                acc[2] = fma4s(v, g.z, acc[2]);
+                acc[3] = fma4s(v, g.w, acc[3]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float av[4] = {acc[o].x, acc[o].y, acc[o].z, acc[o].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[((size_t)o * C + c + k) * 9 + t] = av[k];
+        }
+    }
+    if (threadIdx.x < 4) {  // d(b0) partial
+        float s = 0.f;
+        for (int h = h0; h < min(h0 + SD_ROWS, H); ++h)
+            for (int p = 0; p < W; ++p) s += gimg[((size_t)h * W + p) * 4 + threadIdx.x];
+        dst[4 * C * 9 + threadIdx.x] = s;
+    }
+}
+
+// packed [C][10] -> d_weight [C][9], d_bias [C]
+__global__ void split10_kernel(const float *__restrict__ packed, int C, float *__restrict__ dw, float *__restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 10) return;
+    const int c = i / 10, k = i - c * 10;
+    if (k < 9) dw[c * 9 + k] = packed[i];
+    else db[c] = packed[i];
+}
+// packed [n0 + n1] -> a [n0], b [n1]
+__global__ void copy2_kernel(const float *__restrict__ packed, int n0, int n1, float *__restrict__ a, float *__restrict__ b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n0) a[i] = packed[i];
+    else if (i < n0 + n1) b[i - n0] = packed[i];
+}
+
+static int check_conv(const char *who, int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(DSW_EINVAL, "%s: bad sizes B=%d H=%d W=%d C=%d", who, B, H, W, C);
+    if (C % 4) return fail(DSW_EUNSUPPORTED, "%s: channel count %d must be a multiple of 4", who, C);
+    if (C > 1024) return fail(DSW_EUNSUPPORTED, "%s: channel count %d > 1024", who, C);
+    return DSW_OK;
+}
+
+template <typename K> static int set_lds_attr(K kern, size_t lds, const char *who) {
+    if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "%s: needs %zu B of LDS", who, lds);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DSW_ELAUNCH, "%s: LDS attribute: %s", who, hipGetErrorString(e));
+    }
+    return DSW_OK;
+}
+
+}  // namespace dsw
+
+using namespace dsw;
+
+extern "C" int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
+                                 int C, void *y, int y_dtype, void *stream) {
+    int rc = check_conv("dsw_dwconv3x3_fwd", B, H, W, C);
+    if (rc) return rc;
+    DSW_REQUIRE(x && weight && y, "dsw_dwconv3x3_fwd: null pointer");
+    const int tiles = (W + CV_TILE - 1) / CV_TILE;
+    const size_t lds = (size_t)C * 10 * sizeof(float);
+    DSW_DISPATCH_DTYPE(x_dtype, TI, DSW_DISPATCH_DTYPE(y_dtype, TO, {
+        hipLaunchKernelGGL((dwconv_stream_kernel<TI, TO, false>), dim3(B * H * tiles), dim3(CV_THREADS), lds, as_stream(stream),
+                           (const TI *)x, weight, bias, H, W, C, tiles, (TO *)y);
+    }));
+    return check_launch("dwconv_stream_kernel");
+}
+
+extern "C" int dsw_dwconv3x3_bwd_blocks(int B, int H, int W) {
+    (void)W;
+    return B > 0 && H > 0 ? B * ((H + DW_ROWS - 1) / DW_ROWS) : 0;
+}
+
+extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype, const float *weight, int B,
+                                 int H, int W, int C, void *dx, int dx_dtype, float *d_weight, float *d_bias,
+                                 float *partial, void *stream) {
+    int rc = check_conv("dsw_dwconv3x3_bwd", B, H, W, C);
+    if (rc) return rc;
+    DSW_REQUIRE(dy && x && weight && dx && d_weight && d_bias && partial, "dsw_dwconv3x3_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int tiles = (W + CV_TILE - 1) / CV_TILE;
+    const size_t lds = (size_t)C * 10 * sizeof(float);
+    DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
+        hipLaunchKernelGGL((dwconv_stream_kernel<TG, TO, true>), dim3(B * H * tiles), dim3(CV_THREADS), lds, st,
+                           (const TG *)dy, weight, (const float *)nullptr, H, W, C, tiles, (TO *)dx);
+    }));
+    rc = check_launch("dwconv_stream_kernel<flip>");
+    if (rc) return rc;
+    const int CV = C / 4, PG = CV_THREADS / CV;
+    DSW_REQUIRE(PG >= 1, "dsw_dwconv3x3_bwd: too many channels");
+    const int nblocks = dsw_dwconv3x3_bwd_blocks(B, H, W);
+    const size_t lds2 = (size_t)PG * CV * 40 * sizeof(float);
+    DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(x_dtype, TX, {
+        auto kern = dwconv_wgrad_kernel<TG, TX>;
+        rc = set_lds_attr(kern, lds2, "dsw_dwconv3x3_bwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CV_THREADS), lds2, st, (const TG *)dy, (const TX *)x, H, W, C, partial);
+    }));
+    rc = check_launch("dwconv_wgrad_kernel");
+    if (rc) return rc;
+    // partial rows are [C][10] = 9 taps + bias; reduce into a packed [C*10] staging area at the
+    // end of `partial`, then split (the split is a strided copy done by the caller's view)
+    float *packed = partial + (size_t)nblocks * C * 10;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((C * 10 + 15) / 16), dim3(256), 0, st, partial, nblocks, C * 10, packed);
+    rc = check_launch("partial_reduce_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(split10_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, packed, C, d_weight, d_bias);
+    return check_launch("split10_kernel");
+}
+
+extern "C" int dsw_sparse_disc_fwd(const void *x, int x_dtype, const float *w0, const float *b0, const float *w2,
+                                   const float *b2, const float *w4, const float *b4, int B, int H, int W, int C, int w,
+                                   float *t0, float *u, void *sd, int sd_dtype, void *stream) {
+    int rc = check_conv("dsw_sparse_disc_fwd", B, H, W, C);
+    if (rc) return rc;
+    DSW_REQUIRE(w > 0 && H % w == 0 && W % w == 0, "dsw_sparse_disc_fwd: H,W (%d,%d) must be multiples of %d", H, W, w);
+    DSW_REQUIRE(x && w0 && b0 && w2 && b2 && w4 && b4 && t0 && u && sd, "dsw_sparse_disc_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int Hw = H / w, Ww = W / w;
+    const size_t lds = (size_t)(9 * C * 4 + w * w * 16 + (CV_THREADS / 16) * 4) * sizeof(float);
+    DSW_DISPATCH_DTYPE(x_dtype, TX, {
+        auto kern = sd_stage_a_kernel<TX>;
+        rc = set_lds_attr(kern, lds, "dsw_sparse_disc_fwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * Hw * Ww), dim3(CV_THREADS), lds, st, (const TX *)x, w0, b0, w2, b2, H, W, C, w, t0, u);
+    });
+    rc = check_launch("sd_stage_a_kernel");
+    if (rc) return rc;
+    const int n = B * 4 * Hw * Ww;
+    DSW_DISPATCH_DTYPE(sd_dtype, TO, {
+        hipLaunchKernelGGL((sd_stage_b_kernel<TO>), dim3((n + 255) / 256), dim3(256), 0, st, u, w4, b4, B, Hw, Ww, (TO *)sd);
+    });
+    return check_launch("sd_stage_b_kernel");
+}
+
+extern "C" int dsw_sparse_disc_bwd_blocks(int B, int H) { return B > 0 && H > 0 ? B * ((H + SD_ROWS - 1) / SD_ROWS) : 0; }
+
+extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x, int x_dtype, const float *w0,
+                                   const float *w2, const float *w4, const float *t0, const float *u, int B, int H, int W,
+                                   int C, int w, void *dx, int dx_dtype, float *dw0, float *db0, float *dw2, float *db2,
+                                   float *dw4, float *db4, float *scratch, void *stream) {
+    int rc = check_conv("dsw_sparse_disc_bwd", B, H, W, C);
+    if (rc) return rc;
+    DSW_REQUIRE(w > 0 && H % w == 0 && W % w == 0, "dsw_sparse_disc_bwd: H,W (%d,%d) must be multiples of %d", H, W, w);
+    DSW_REQUIRE(dsd && x && w0 && w2 && w4 && t0 && u && dx && dw0 && db0 && dw2 && db2 && dw4 && db4 && scratch,
+                "dsw_sparse_disc_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int Hw = H / w, Ww = W / w, L = w * w, n = B * 4 * Hw * Ww;
+    // scratch layout: du [n] | dt0 [B*H*W*4] | w0 partials [nblk][4*C*9+4] | packed [4*C*9+4]
+    float *du = scratch;
+    float *dt0 = du + ((n + 3) & ~3);
+    float *part = dt0 + (size_t)B * H * W * 4;
+    const int nblk = dsw_sparse_disc_bwd_blocks(B, H);
+    const int np = 4 * C * 9 + 4;
+    float *packed = part + (size_t)nblk * np;
+    DSW_DISPATCH_DTYPE(dsd_dtype, TG, {
+        hipLaunchKernelGGL((sd_bwd_b_kernel<TG>), dim3((n + 255) / 256), dim3(256), 0, st, (const TG *)dsd, u, w4, B, Hw, Ww, du);
+        hipLaunchKernelGGL((sd_bwd_w4_kernel<TG>), dim3(1), dim3(256), 0, st, (const TG *)dsd, u, B, Hw, Ww, dw4, db4);
+    });
+    rc = check_launch("sd_bwd_b/w4 kernels");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sd_bwd_a_pix_kernel, dim3((B * H * W + 255) / 256), dim3(256), 0, st, du, t0, w2, B, H, W, w, dt0);
+    hipLaunchKernelGGL(sd_bwd_w2_kernel, dim3((16 * L + 4 + 255) / 256), dim3(256), 0, st, du, t0, B, H, W, w, dw2, db2);
+    rc = check_launch("sd_bwd_a/w2 kernels");
+    if (rc) return rc;
+    const int tiles = (W + CV_TILE - 1) / CV_TILE;
+    const size_t lds = (size_t)36 * C * sizeof(float);
+    DSW_DISPATCH_DTYPE(dx_dtype, TO, {
+        auto kern = sd_bwd_dx_kernel<TO>;
+        rc = set_lds_attr(kern, lds, "dsw_sparse_disc_bwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * H * tiles), dim3(CV_THREADS), lds, st, dt0, w0, H, W, C, tiles, (TO *)dx);
+    });
+    DSW_DISPATCH_DTYPE(x_dtype, TX, {
+        hipLaunchKernelGGL((sd_bwd_w0_kernel<TX>), dim3(nblk), dim3(CV_THREADS), 0, st, dt0, (const TX *)x, H, W, C, part);
+    });
+    rc = check_launch("sd_bwd_dx/w0 kernels");
+    if (rc) return rc;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((np + 15) / 16), dim3(256), 0, st, part, nblk, np, packed);
+    rc = check_launch("partial_reduce_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(copy2_kernel, dim3((np + 255) / 256), dim3(256), 0, st, packed, 4 * C * 9, 4, dw0, db0);
+    return check_launch("copy2_kernel");
+}
+
+// floats of scratch dsw_sparse_disc_bwd needs
+extern "C" size_t dsw_sparse_disc_bwd_scratch(int B, int H, int W, int C, int w) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || w <= 0) return 0;
+    const int n = B * 4 * (H / w) * (W / w);
+    const size_t np = (size_t)4 * C * 9 + 4;
+    return (size_t)((n + 3) & ~3) + (size_t)B * H * W * 4 + (size_t)dsw_sparse_disc_bwd_blocks(B, H) * np + np;
+}

@@ -117,8 +117,8 @@ class WindowedMSA(WindowedAttention):
 class DeformableSparseWindowAttention(WindowedAttention):
     """DSwinT_arch.py:174-317, NHWC throughout (the reference's NCHW round trip at :259/:317
     is gone).  Kernels: window selection, bilinear window gather, fused attention, gated
-    scatter-mean write-back.  The sparse discriminator, the two Linears and out_conv stay torch
-    ops on channels-last views."""
+    scatter-mean write-back, and NHWC kernels for the sparse discriminator and the depthwise
+    out_conv.  Only the two Linears are torch ops."""
 
     def __init__(self, window_size, dim, num_heads):
         super().__init__(window_size, dim, num_heads)
@@ -142,6 +142,9 @@ class DeformableSparseWindowAttention(WindowedAttention):
         # runs); None = draw it the way F.gumbel_softmax does (DSwinT_arch.py:211)
         self.gumbel_noise = None
         self.last_selection = None
+        # True: run the sparse discriminator and out_conv through torch (MIOpen, NCHW copies)
+        # instead of the NHWC HIP kernels
+        self.use_torch_convs = False
 
     def _noise(self, scores_flat):
         if not self.training:
@@ -154,9 +157,14 @@ class DeformableSparseWindowAttention(WindowedAttention):
         B, H, W, C = x.shape
         w = self.w
         x = x.contiguous()
-        # MIOpen's channels-last convolutions fall back to naive kernels for these shapes (tens of
-        # ms per call on MI355X), so the two torch convolutions get NCHW copies like the reference
-        sd = self.sparse_discriminator(x.permute(0, 3, 1, 2).contiguous()).contiguous()
+        act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if act not in (torch.float32, torch.bfloat16):
+            act = x.dtype
+        if self.use_torch_convs:
+            sd = self.sparse_discriminator(x.permute(0, 3, 1, 2).contiguous()).contiguous()
+        else:
+            sd = K.sparse_discriminator_nhwc(x, (self.sparse_discriminator[0], self.sparse_discriminator[2],
+                                                 self.sparse_discriminator[4]), w, out_dtype=act)
         Hw, Ww = sd.shape[2], sd.shape[3]
         k = int((Hw * Ww) * self.num_win_selected)
         self.last_selection = None
@@ -168,13 +176,11 @@ class DeformableSparseWindowAttention(WindowedAttention):
         self.last_selection = sel
         if sel.n == 0:  # DSwinT_arch.py:291-292
             return x
-        act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-        if act not in (torch.float32, torch.bfloat16):
-            act = x.dtype
         before = K.gather_windows(x, sel, w, out_dtype=act)              # [n, L, C]
         qkv = self.in_proj(before)
         z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED)
         after = self.out_proj(z)
         y = K.scatter_mean_residual(x, after, sel, w)                     # [B,H,W,C]
-        out = self.out_conv(y.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1)
-        return out.contiguous()
+        if self.use_torch_convs:
+            return self.out_conv(y.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
+        return K.dwconv3x3_nhwc(y, self.out_conv.weight, self.out_conv.bias, out_dtype=act)

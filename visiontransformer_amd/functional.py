@@ -332,3 +332,89 @@ def shuffle_nchw(t, scale=1):
 def unshuffle_nhwc(x, scale=1):
     """PixelUnshuffle(scale) + NCHW->NHWC in one pass.  x [B,c,H,W] -> [B,H/s,W/s,c*s*s]."""
     return _UnshuffleFn.apply(x, int(scale))
+
+
+# ---------------------------------------------------------------------------------------------
+# NHWC convolutions of the DS-MSA path (DSwinT_arch.py:180-186, :198, :266, :317)
+# ---------------------------------------------------------------------------------------------
+class _DWConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_dtype):
+        _lib.require_cuda(x)
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        w32 = weight.detach().to(torch.float32).reshape(C, 9).contiguous()
+        b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        y = torch.empty(B, H, W, C, dtype=out_dtype, device=x.device)
+        call("dsw_dwconv3x3_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(y),
+             dtype_code(out_dtype), stream(x.device))
+        ctx.save_for_backward(x, w32)
+        ctx.meta = (weight.shape, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w32 = ctx.saved_tensors
+        wshape, wdt, bdt = ctx.meta
+        B, H, W, C = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, 9, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        nblk = _lib.load().dsw_dwconv3x3_bwd_blocks(B, H, W)
+        partial = torch.empty((nblk + 1) * C * 10, dtype=torch.float32, device=dev)
+        call("dsw_dwconv3x3_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype), ptr(w32), B, H, W, C,
+             ptr(dx), dtype_code(dx.dtype), ptr(dw), ptr(db), ptr(partial), stream(dev))
+        return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), None
+
+
+def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None):
+    """Depthwise 3x3 conv, stride 1, zero padding 1, on an NHWC tensor (out_conv of DS-MSA,
+    DSwinT_arch.py:198, :317).  weight [C,1,3,3]."""
+    return _DWConvFn.apply(x, weight, bias, out_dtype or x.dtype)
+
+
+class _SparseDiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, b0, w2, b2, w4, b4, w, out_dtype):
+        _lib.require_cuda(x)
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        dev = x.device
+        ps = [p.detach().to(torch.float32).contiguous() for p in (w0, b0, w2, b2, w4, b4)]
+        t0 = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+        u = torch.empty(B, 4, H // w, W // w, dtype=torch.float32, device=dev)
+        sd = torch.empty(B, 4, H // w, W // w, dtype=out_dtype, device=dev)
+        call("dsw_sparse_disc_fwd", ptr(x), dtype_code(x.dtype), *[ptr(p) for p in ps], B, H, W, C, w, ptr(t0), ptr(u),
+             ptr(sd), dtype_code(out_dtype), stream(dev))
+        ctx.save_for_backward(x, ps[0], ps[2], ps[4], t0, u)
+        ctx.meta = (w, [(p.shape, p.dtype) for p in (w0, b0, w2, b2, w4, b4)])
+        return sd
+
+    @staticmethod
+    def backward(ctx, dsd):
+        x, w0, w2, w4, t0, u = ctx.saved_tensors
+        w, pmeta = ctx.meta
+        B, H, W, C = x.shape
+        dev = x.device
+        dsd = dsd.contiguous()
+        dx = torch.empty_like(x)
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = [torch.empty(4 * C * 9, **f32), torch.empty(4, **f32), torch.empty(16 * w * w, **f32), torch.empty(4, **f32),
+             torch.empty(144, **f32), torch.empty(4, **f32)]
+        nfl = _lib.load().dsw_sparse_disc_bwd_scratch(B, H, W, C, w)
+        scratch = torch.empty(int(nfl), **f32)
+        call("dsw_sparse_disc_bwd", ptr(dsd), dtype_code(dsd.dtype), ptr(x), dtype_code(x.dtype), ptr(w0), ptr(w2), ptr(w4),
+             ptr(t0), ptr(u), B, H, W, C, w, ptr(dx), dtype_code(dx.dtype), *[ptr(t) for t in g], ptr(scratch), stream(dev))
+        grads = [t.view(shape).to(dt) for t, (shape, dt) in zip(g, pmeta)]
+        return (dx, *grads, None, None)
+
+
+def sparse_discriminator_nhwc(x, convs, w, out_dtype=None):
+    """The DS-MSA sparse discriminator on an NHWC tensor: conv C->4 3x3 + SiLU + conv 4->4 k=w
+    stride w + SiLU + conv 4->4 3x3 (DSwinT_arch.py:180-186, :266).  `convs` = the three Conv2d
+    modules; returns sd [B,4,H/w,W/w]."""
+    c0, c2, c4 = convs
+    return _SparseDiscFn.apply(x, c0.weight, c0.bias, c2.weight, c2.bias, c4.weight, c4.bias, int(w),
+                               out_dtype or x.dtype)
