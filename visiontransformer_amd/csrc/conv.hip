@@ -154,51 +154,66 @@ __global__ __launch_bounds__(CV_THREADS) void sd_stage_a_kernel(const TX *__rest
         w2s[(pix * 4 + c2) * 4 + o] = w2[i];
     }
     __syncthreads();
-    // 16 lanes per pixel, each over a strided share of the channel quads
+    // 16 lanes per strip of 4 consecutive pixels of a window row; each lane covers a strided share of
+    // the channel quads, so one set of weight reads serves 4 pixels and 6 input columns serve 3 taps
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, CV = C >> 2;
     const TX *img = x + (size_t)b * H * W * C;
     float4 uacc = f4zero();  // this group's share of u[0..3]
-    for (int pix = grp; pix < L; pix += CV_THREADS / 16) {
-        const int y = wr * w + pix / w, xx = wc * w + pix % w;
-        float4 acc = f4zero();  // conv0 outputs 0..3 (partial over this lane's channels)
+    const int strips_per_row = w >> 2, nstrips = w * strips_per_row;
+    for (int sidx = grp; sidx < nstrips; sidx += CV_THREADS / 16) {
+        const int py = sidx / strips_per_row, px0 = (sidx - py * strips_per_row) << 2;
+        const int y = wr * w + py, xs = wc * w + px0;
+        float4 acc[4];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) acc[pp] = f4zero();
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int yy = y + a - 1;
             if (yy < 0 || yy >= H) continue;
+            for (int cv = gl; cv < CV; cv += 16) {
+                float4 v[6];
 #pragma unroll
-            for (int bb = 0; bb < 3; ++bb) {
-                const int xc = xx + bb - 1;
-                if (xc < 0 || xc >= W) continue;
-                const float *wt = w0s + (size_t)(a * 3 + bb) * C * 4;
-                for (int cv = gl; cv < CV; cv += 16) {
-                    const float4 v = io<TX>::ld4(img + ((size_t)yy * W + xc) * C + (cv << 2));
-                    const float4 *wq = reinterpret_cast<const float4 *>(wt + (cv << 2) * 4);
-                    acc = fma4s(wq[0], v.x, acc);
-                    acc = fma4s(wq[1], v.y, acc);
-                    acc = fma4s(wq[2], v.z, acc);
-                    acc = fma4s(wq[3], v.w, acc);
+                for (int k = 0; k < 6; ++k) {
+                    const int xc = xs + k - 1;
+                    v[k] = (xc >= 0 && xc < W) ? io<TX>::ld4(img + ((size_t)yy * W + xc) * C + (cv << 2)) : f4zero();
+                }
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    const float4 *wq = reinterpret_cast<const float4 *>(w0s + ((size_t)(a * 3 + bb) * C + (cv << 2)) * 4);
+                    const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2], q3 = wq[3];
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        const float4 vv = v[pp + bb];
+                        acc[pp] = fma4s(q0, vv.x, acc[pp]);
+                        acc[pp] = fma4s(q1, vv.y, acc[pp]);
+                        acc[pp] = fma4s(q2, vv.z, acc[pp]);
+                        acc[pp] = fma4s(q3, vv.w, acc[pp]);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            acc.x += __shfl_xor(acc.x, o, 64);
-            acc.y += __shfl_xor(acc.y, o, 64);
-            acc.z += __shfl_xor(acc.z, o, 64);
-            acc.w += __shfl_xor(acc.w, o, 64);
-        }
-        acc.x += b0[0];
-        acc.y += b0[1];
-        acc.z += b0[2];
-        acc.w += b0[3];
-        if (gl == 0) *reinterpret_cast<float4 *>(t0 + (((size_t)b * H + y) * W + xx) * 4) = acc;
-        // conv2 contribution of this pixel: u[o] += sum_c2 w2[o][c2][pix] * silu(t0[c2])
-        const float4 *w2q = reinterpret_cast<const float4 *>(w2s + pix * 16);
-        if (gl == 0) {
-            uacc = fma4s(w2q[0], silu(acc.x), uacc);
-            uacc = fma4s(w2q[1], silu(acc.y), uacc);
-            uacc = fma4s(w2q[2], silu(acc.z), uacc);
-            uacc = fma4s(w2q[3], silu(acc.w), uacc);
+        for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                acc[pp].x += __shfl_xor(acc[pp].x, o, 64);
+                acc[pp].y += __shfl_xor(acc[pp].y, o, 64);
+                acc[pp].z += __shfl_xor(acc[pp].z, o, 64);
+                acc[pp].w += __shfl_xor(acc[pp].w, o, 64);
+            }
+            acc[pp].x += b0[0];
+            acc[pp].y += b0[1];
+            acc[pp].z += b0[2];
+            acc[pp].w += b0[3];
+            if (gl == 0) {
+                *reinterpret_cast<float4 *>(t0 + (((size_t)b * H + y) * W + xs + pp) * 4) = acc[pp];
+                // conv2 contribution of this pixel: u[o] += sum_c2 w2[o][c2][pix] * silu(t0[c2])
+                const float4 *w2q = reinterpret_cast<const float4 *>(w2s + (py * w + px0 + pp) * 16);
+                uacc = fma4s(w2q[0], silu(acc[pp].x), uacc);
+                uacc = fma4s(w2q[1], silu(acc[pp].y), uacc);
+                uacc = fma4s(w2q[2], silu(acc[pp].z), uacc);
+                uacc = fma4s(w2q[3], silu(acc[pp].w), uacc);
+            }
         }
     }
     if (gl == 0) *reinterpret_cast<float4 *>(red + grp * 4) = uacc;
@@ -253,31 +268,32 @@ __global__ void sd_bwd_b_kernel(const TG *__restrict__ dsd, const float *__restr
     du[i] = acc * silu_grad(u[i]);
 }
 
-// d(w4) [4][4][9] and d(b4) [4]: one block, thread per entry, fixed-order loop over all cells
+// d(w4) [4][4][9] and d(b4) [4]: one block per entry, fixed-order block reduction over all cells
 template <typename TG>
-__global__ void sd_bwd_w4_kernel(const TG *__restrict__ dsd, const float *__restrict__ u, int B, int Hw, int Ww,
-                                 float *__restrict__ dw4, float *__restrict__ db4) {
-    const int i = threadIdx.x;
+__global__ __launch_bounds__(256) void sd_bwd_w4_kernel(const TG *__restrict__ dsd, const float *__restrict__ u, int B, int Hw,
+                                                        int Ww, float *__restrict__ dw4, float *__restrict__ db4) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, ncell = B * Hw * Ww;
+    float acc = 0.f;
     if (i < 144) {
         const int o = i / 36, c2 = (i / 9) % 4, a = (i % 9) / 3, bb = i % 3;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int r = 0; r < Hw; ++r) {
-                const int rr = r + a - 1;
-                if (rr < 0 || rr >= Hw) continue;
-                for (int c = 0; c < Ww; ++c) {
-                    const int cc = c + bb - 1;
-                    if (cc < 0 || cc >= Ww) continue;
-                    acc = fmaf(io<TG>::ld(dsd + ((size_t)(b * 4 + o) * Hw + r) * Ww + c), silu(u[((size_t)(b * 4 + c2) * Hw + rr) * Ww + cc]), acc);
-                }
-            }
-        dw4[i] = acc;
-    } else if (i < 148) {
+        for (int j = threadIdx.x; j < ncell; j += 256) {
+            const int c = j % Ww, r = (j / Ww) % Hw, b = j / (Ww * Hw);
+            const int rr = r + a - 1, cc = c + bb - 1;
+            if (rr < 0 || rr >= Hw || cc < 0 || cc >= Ww) continue;
+            acc = fmaf(io<TG>::ld(dsd + ((size_t)(b * 4 + o) * Hw + r) * Ww + c), silu(u[((size_t)(b * 4 + c2) * Hw + rr) * Ww + cc]), acc);
+        }
+    } else {
         const int o = i - 144;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int j = 0; j < Hw * Ww; ++j) acc += io<TG>::ld(dsd + (size_t)(b * 4 + o) * Hw * Ww + j);
-        db4[o] = acc;
+        for (int j = threadIdx.x; j < ncell; j += 256) {
+            const int b = j / (Ww * Hw), cell = j - b * Ww * Hw;
+            acc += io<TG>::ld(dsd + (size_t)(b * 4 + o) * Hw * Ww + cell);
+        }
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        if (i < 144) dw4[i] = t;
+        else db4[i - 144] = t;
     }
 }
 
@@ -305,27 +321,41 @@ __global__ void sd_bwd_a_pix_kernel(const float *__restrict__ du, const float *_
     *reinterpret_cast<float4 *>(dt0 + (size_t)i * 4) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
-// d(w2) [4][4][L] and d(b2) [4]: thread per entry, fixed-order loop over all windows
-__global__ void sd_bwd_w2_kernel(const float *__restrict__ du, const float *__restrict__ t0, int B, int H, int W, int w,
-                                 float *__restrict__ dw2, float *__restrict__ db2) {
-    const int L = w * w, Hw = H / w, Ww = W / w;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 16 * L) {
-        const int o = i / (4 * L), c2 = (i / L) % 4, pix = i % L;
-        const int py = pix / w, px = pix - py * w;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int wr = 0; wr < Hw; ++wr)
-                for (int wc = 0; wc < Ww; ++wc)
-                    acc = fmaf(du[((size_t)(b * 4 + o) * Hw + wr) * Ww + wc],
-                               silu(t0[(((size_t)b * H + wr * w + py) * W + wc * w + px) * 4 + c2]), acc);
-        dw2[i] = acc;
-    } else if (i < 16 * L + 4) {
-        const int o = i - 16 * L;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int j = 0; j < Hw * Ww; ++j) acc += du[(size_t)(b * 4 + o) * Hw * Ww + j];
-        db2[o] = acc;
+// d(w2) [4][4][L] and d(b2) [4].  Block = 16 (c2, pix) entries x 16 window groups; every thread sums
+// its windows for the 4 outputs at once, then the 16 group partials are added in order.
+__global__ __launch_bounds__(256) void sd_bwd_w2_kernel(const float *__restrict__ du, const float *__restrict__ t0, int B, int H,
+                                                        int W, int w, float *__restrict__ dw2, float *__restrict__ db2) {
+    __shared__ float part[16][16][5];
+    const int L = w * w, Hw = H / w, Ww = W / w, nwin = B * Hw * Ww;
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int ent = blockIdx.x * 16 + e;  // c2 * L + pix; entries >= 4L: the four d(b2) sums
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ent < 4 * L) {
+        const int c2 = ent / L, pix = ent - c2 * L, py = pix / w, px = pix - py * w;
+        for (int wi = grp; wi < nwin; wi += 16) {
+            const int wc = wi % Ww, wr = (wi / Ww) % Hw, b = wi / (Ww * Hw);
+            const float tv = silu(t0[(((size_t)b * H + wr * w + py) * W + wc * w + px) * 4 + c2]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] = fmaf(du[((size_t)(b * 4 + o) * Hw + wr) * Ww + wc], tv, acc[o]);
+        }
+    } else if (ent == 4 * L) {
+        for (int wi = grp; wi < nwin; wi += 16) {
+            const int cell = wi % (Ww * Hw), b = wi / (Ww * Hw);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] += du[(size_t)(b * 4 + o) * Hw * Ww + cell];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) part[grp][e][o] = acc[o];
+    __syncthreads();
+    if (grp == 0 && ent <= 4 * L) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float t = 0.f;
+            for (int k = 0; k < 16; ++k) t += part[k][e][o];
+            if (ent < 4 * L) dw2[(size_t)o * 4 * L + ent] = t;
+            else db2[o] = t;
+        }
     }
 }
 
@@ -365,47 +395,69 @@ __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__re
     }
 }
 
-// d(w0) partials: block = SD_ROWS image rows; work item = (channel quad, tap); 16 accumulators each
-constexpr int SD_ROWS = 8;
+// d(w0) partials: block = SD_ROWS image rows; thread = (channel quad, tap row a, pixel part).  Walking
+// along an image row the three tap columns are a sliding window of x, so each pixel costs one new
+// x load and one dt0 load for 48 FMAs.  12 float4 accumulators: [bb][o] x 4 channels.
+constexpr int SD_ROWS = 4;
 template <typename TX>
 __global__ __launch_bounds__(CV_THREADS) void sd_bwd_w0_kernel(const float *__restrict__ dt0, const TX *__restrict__ x, int H,
                                                                int W, int C, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [PP][CV*3][48]
     const int CV = C >> 2, rows_per_img = (H + SD_ROWS - 1) / SD_ROWS;
+    const int PP = max(1, CV_THREADS / (CV * 3));  // pixel parts per row
     const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x - b * rows_per_img) * SD_ROWS;
     const float *gimg = dt0 + (size_t)b * H * W * 4;
     const TX *ximg = x + (size_t)b * H * W * C;
     float *dst = partial + (size_t)blockIdx.x * (4 * C * 9 + 4);
-    for (int item = threadIdx.x; item < CV * 9; item += CV_THREADS) {
-        const int cv = item / 9, t = item - cv * 9, a = t / 3, bb = t - a * 3, c = cv << 2;
-        float4 acc[4];  // [o] x 4 channels
+    const int item = threadIdx.x % (CV * 3), part = threadIdx.x / (CV * 3);
+    if (part < PP) {
+        const int cv = item / 3, a = item - cv * 3, c = cv << 2;
+        const int chunk = (W + PP - 1) / PP, p0 = part * chunk, p1 = min(p0 + chunk, W);
+        float4 acc[3][4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o] = f4zero();
+        for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[bb][o] = f4zero();
         for (int h = h0; h < min(h0 + SD_ROWS, H); ++h) {
             const int yy = h + a - 1;
-            if (yy < 0 || yy >= H) continue;
-            for (int p = 0; p < W; ++p) {
-                const int xc = p + bb - 1;
-                if (xc < 0 || xc >= W) continue;
+            if (yy < 0 || yy >= H || p0 >= p1) continue;
+            const TX *xrow = ximg + (size_t)yy * W * C + c;
+            float4 xm = p0 > 0 ? io<TX>::ld4(xrow + (size_t)(p0 - 1) * C) : f4zero();
+            float4 x0 = io<TX>::ld4(xrow + (size_t)p0 * C);
+            for (int p = p0; p < p1; ++p) {
+                const float4 xp = (p + 1 < W) ? io<TX>::ld4(xrow + (size_t)(p + 1) * C) : f4zero();
                 const float4 g = *reinterpret_cast<const float4 *>(gimg + ((size_t)h * W + p) * 4);
-                const float4 v = io<TX>::ld4(ximg + ((size_t)yy * W + xc) * C + c);
-                acc[0] = fma4s(v, g.x, acc[0]);
-                acc[1] = fma4s(v, g.y, acc[1]);
-                acc[2] = fma4s(v, g.z, acc[2]);
-                acc[3] = fma4s(v, g.w, acc[3]);
+                const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    acc[0][o] = fma4s(xm, gv[o], acc[0][o]);
+                    acc[1][o] = fma4s(x0, gv[o], acc[1][o]);
+                    acc[2][o] = fma4s(xp, gv[o], acc[2][o]);
+                }
+                xm = x0;
+                x0 = xp;
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const float av[4] = {acc[o].x, acc[o].y, acc[o].z, acc[o].w};
+        for (int bb = 0; bb < 3; ++bb)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dst[((size_t)o * C + c + k) * 9 + t] = av[k];
-        }
+            for (int o = 0; o < 4; ++o)
+                *reinterpret_cast<float4 *>(red + (((size_t)part * CV * 3 + item) * 12 + bb * 4 + o) * 4) = acc[bb][o];
+    }
+    __syncthreads();
+    // dst[o][ci][tap] = sum over pixel parts (in order)
+    for (int i = threadIdx.x; i < 4 * C * 9; i += CV_THREADS) {
+        const int o = i / (C * 9), r = i - o * C * 9, ci = r / 9, t = r - ci * 9, a = t / 3, bb = t - a * 3;
+        const int it2 = (ci >> 2) * 3 + a;
+        float sacc = 0.f;
+        for (int pt = 0; pt < PP; ++pt) sacc += red[(((size_t)pt * CV * 3 + it2) * 12 + bb * 4 + o) * 4 + (ci & 3)];
+        dst[i] = sacc;
     }
     if (threadIdx.x < 4) {  // d(b0) partial
-        float s = 0.f;
+        float sb = 0.f;
         for (int h = h0; h < min(h0 + SD_ROWS, H); ++h)
-            for (int p = 0; p < W; ++p) s += gimg[((size_t)h * W + p) * 4 + threadIdx.x];
-        dst[4 * C * 9 + threadIdx.x] = s;
+            for (int p = 0; p < W; ++p) sb += gimg[((size_t)h * W + p) * 4 + threadIdx.x];
+        dst[4 * C * 9 + threadIdx.x] = sb;
     }
 }
 
@@ -506,6 +558,7 @@ extern "C" int dsw_sparse_disc_fwd(const void *x, int x_dtype, const float *w0, 
     int rc = check_conv("dsw_sparse_disc_fwd", B, H, W, C);
     if (rc) return rc;
     DSW_REQUIRE(w > 0 && H % w == 0 && W % w == 0, "dsw_sparse_disc_fwd: H,W (%d,%d) must be multiples of %d", H, W, w);
+    if (w % 4) return fail(DSW_EUNSUPPORTED, "dsw_sparse_disc_fwd: window size %d must be a multiple of 4", w);
     DSW_REQUIRE(x && w0 && b0 && w2 && b2 && w4 && b4 && t0 && u && sd, "dsw_sparse_disc_fwd: null pointer");
     hipStream_t st = as_stream(stream);
     const int Hw = H / w, Ww = W / w;
@@ -547,12 +600,12 @@ extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x
     float *packed = part + (size_t)nblk * np;
     DSW_DISPATCH_DTYPE(dsd_dtype, TG, {
         hipLaunchKernelGGL((sd_bwd_b_kernel<TG>), dim3((n + 255) / 256), dim3(256), 0, st, (const TG *)dsd, u, w4, B, Hw, Ww, du);
-        hipLaunchKernelGGL((sd_bwd_w4_kernel<TG>), dim3(1), dim3(256), 0, st, (const TG *)dsd, u, B, Hw, Ww, dw4, db4);
+        hipLaunchKernelGGL((sd_bwd_w4_kernel<TG>), dim3(148), dim3(256), 0, st, (const TG *)dsd, u, B, Hw, Ww, dw4, db4);
     });
     rc = check_launch("sd_bwd_b/w4 kernels");
     if (rc) return rc;
     hipLaunchKernelGGL(sd_bwd_a_pix_kernel, dim3((B * H * W + 255) / 256), dim3(256), 0, st, du, t0, w2, B, H, W, w, dt0);
-    hipLaunchKernelGGL(sd_bwd_w2_kernel, dim3((16 * L + 4 + 255) / 256), dim3(256), 0, st, du, t0, B, H, W, w, dw2, db2);
+    hipLaunchKernelGGL(sd_bwd_w2_kernel, dim3((4 * L + 1 + 15) / 16), dim3(256), 0, st, du, t0, B, H, W, w, dw2, db2);
     rc = check_launch("sd_bwd_a/w2 kernels");
     if (rc) return rc;
     const int tiles = (W + CV_TILE - 1) / CV_TILE;
@@ -564,7 +617,13 @@ extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x
         hipLaunchKernelGGL(kern, dim3(B * H * tiles), dim3(CV_THREADS), lds, st, dt0, w0, H, W, C, tiles, (TO *)dx);
     });
     DSW_DISPATCH_DTYPE(x_dtype, TX, {
-        hipLaunchKernelGGL((sd_bwd_w0_kernel<TX>), dim3(nblk), dim3(CV_THREADS), 0, st, dt0, (const TX *)x, H, W, C, part);
+        auto kern0 = sd_bwd_w0_kernel<TX>;
+        const int CVq = C / 4, PPq = CV_THREADS / (CVq * 3) > 0 ? CV_THREADS / (CVq * 3) : 1;
+        if (CVq * 3 > CV_THREADS) return fail(DSW_EUNSUPPORTED, "dsw_sparse_disc_bwd: %d channels > %d", C, CV_THREADS / 3 * 4);
+        const size_t lds0 = (size_t)PPq * CVq * 3 * 48 * sizeof(float);
+        rc = set_lds_attr(kern0, lds0, "dsw_sparse_disc_bwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern0, dim3(nblk), dim3(CV_THREADS), lds0, st, dt0, (const TX *)x, H, W, C, part);
     });
     rc = check_launch("sd_bwd_dx/w0 kernels");
     if (rc) return rc;

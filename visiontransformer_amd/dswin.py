@@ -109,9 +109,9 @@ class WindowedMSA(WindowedAttention):
     def forward(self, x):
         B, H, W, C = x.shape
         _check_no_attn_dropout(self.attn_drop, self.training)
-        qkv = self.qkv(x)
+        qkv = K.linear(x, self.qkv)
         z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W))
-        return self.out_proj(z)
+        return K.linear(z, self.out_proj)
 
 
 class DeformableSparseWindowAttention(WindowedAttention):
@@ -177,9 +177,9 @@ class DeformableSparseWindowAttention(WindowedAttention):
         if sel.n == 0:  # DSwinT_arch.py:291-292
             return x
         before = K.gather_windows(x, sel, w, out_dtype=act)              # [n, L, C]
-        qkv = self.in_proj(before)
+        qkv = K.linear(before, self.in_proj)
         z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED)
-        after = self.out_proj(z)
+        after = K.linear(z, self.out_proj)
         y = K.scatter_mean_residual(x, after, sel, w)                     # [B,H,W,C]
         if self.use_torch_convs:
             return self.out_conv(y.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()

@@ -418,3 +418,49 @@ def sparse_discriminator_nhwc(x, convs, w, out_dtype=None):
     c0, c2, c4 = convs
     return _SparseDiscFn.apply(x, c0.weight, c0.bias, c2.weight, c2.bias, c4.weight, c4.bias, int(w),
                                out_dtype or x.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear projections of the attention modules (DSwinT_arch.py:303, :308, :334, :337)
+# ---------------------------------------------------------------------------------------------
+_WGRAD_CHUNK = 2048
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b through the stock GEMM library, with one change in the backward: the weight
+    gradient dY^T X has a tiny output ([3C, C]) and a huge reduction dimension (all tokens), which
+    the library runs on a handful of CUs; it is issued as a batched GEMM over token chunks and
+    the chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act_dtype):
+        with torch.autocast("cuda", enabled=False):
+            x2 = x.reshape(-1, x.shape[-1]).to(act_dtype)
+            w = weight.to(act_dtype)
+            y = torch.addmm(bias.to(act_dtype), x2, w.t()) if bias is not None else x2 @ w.t()
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y.view(x.shape[:-1] + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        xshape, xdt, wdt, bdt = ctx.meta
+        with torch.autocast("cuda", enabled=False):
+            dy2 = dy.reshape(-1, dy.shape[-1]).to(w.dtype)
+            dx = (dy2 @ w).view(xshape).to(xdt)
+            T, N, Kd = x2.shape[0], dy2.shape[1], x2.shape[1]
+            if T >= 8 * _WGRAD_CHUNK and T % _WGRAD_CHUNK == 0:
+                S = T // _WGRAD_CHUNK
+                part = torch.bmm(dy2.view(S, _WGRAD_CHUNK, N).transpose(1, 2), x2.view(S, _WGRAD_CHUNK, Kd))
+                dw = part.sum(0, dtype=torch.float32)
+            else:
+                dw = (dy2.t() @ x2).float()
+            db = None if bdt is None else dy2.sum(0, dtype=torch.float32).to(bdt)
+        return dx, dw.to(wdt), db, None
+
+
+def linear(x, lin):
+    """`lin(x)` for an nn.Linear `lin`, honouring CUDA autocast like F.linear does."""
+    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    return _LinearFn.apply(x, lin.weight, lin.bias, act)

@@ -72,10 +72,10 @@ class WindowedMSA(nn.Module):
                 "msft_arch.py:136, so its outputs are random there)")
         B, N, C = x.shape
         assert N == H * W
-        qkv = self.qkv(x)
+        qkv = K.linear(x, self.qkv)
         z = K.window_attention(qkv, None, self.window_size, self.num_heads, QKV_CHUNKED, grid=(B, H, W),
                                lepe_w=self.pe_encoder.weight, lepe_b=self.pe_encoder.bias)
-        return self.proj_drop(self.out_proj(z))
+        return self.proj_drop(K.linear(z, self.out_proj))
 
 
 class MLP(nn.Module):
