@@ -77,7 +77,7 @@ def time_calls(fn, iters, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per call
 
 
-def kernel_rooflines(device, iters=20):
+def kernel_rooflines(device, iters=20, warm=3):
     """Per-kernel achieved rate at config B shapes, measured with events on the launch stream."""
     from visiontransformer_amd import functional as K
     from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
@@ -93,8 +93,8 @@ def kernel_rooflines(device, iters=20):
     o = K.window_attention(qkv, tab, WIN, HEADS, QKV_INTERLEAVED, grid=(B_PER_GPU, HW, HW))
     do = torch.randn_like(o)
     t_f = time_calls(lambda: K.window_attention(qkv.detach(), table, WIN, HEADS, QKV_INTERLEAVED,
-                                                grid=(B_PER_GPU, HW, HW)), iters)
-    t_b = time_calls(lambda: torch.autograd.grad(o, (qkv, tab), do, retain_graph=True), iters)
+                                                grid=(B_PER_GPU, HW, HW)), iters, warm)
+    t_b = time_calls(lambda: torch.autograd.grad(o, (qkv, tab), do, retain_graph=True), iters, warm)
     flops_f, flops_b = 4.0 * T * L * C, 8.0 * T * L * C
     out["win_attn_fwd"] = dict(bound="mfma", achieved=flops_f / t_f / 1e12, peak=MFMA_BF16_PEAK_TFLOPS,
                                unit="TFLOP/s", us=t_f * 1e6, algorithmic=flops_f)
@@ -107,13 +107,13 @@ def kernel_rooflines(device, iters=20):
     sig = sd[:, 1:].sigmoid()
     sel = K.select_windows(sd, sig, None, 1.0, 4, WIN, HW, HW)
     n = sel.n
-    t_s = time_calls(lambda: K.select_windows(sd, sig, None, 1.0, 4, WIN, HW, HW), iters)
+    t_s = time_calls(lambda: K.select_windows(sd, sig, None, 1.0, 4, WIN, HW, HW), iters, warm)
     out["select"] = dict(bound="latency", us=t_s * 1e6)
     xs = x.clone().requires_grad_()
     g = K.gather_windows(xs, sel, WIN, out_dtype=bf)
-    t_g = time_calls(lambda: K.gather_windows(x, sel, WIN, out_dtype=bf), iters)
+    t_g = time_calls(lambda: K.gather_windows(x, sel, WIN, out_dtype=bf), iters, warm)
     dg = torch.randn_like(g)
-    t_gb = time_calls(lambda: torch.autograd.grad(g, xs, dg, retain_graph=True), iters)
+    t_gb = time_calls(lambda: torch.autograd.grad(g, xs, dg, retain_graph=True), iters, warm)
     by_g = n * C * ((WIN + 1) ** 2 * 4 + L * 2)
     by_gb = n * C * L * 2 + B_PER_GPU * HW * HW * C * 4
     out["gather_fwd"] = dict(bound="hbm", achieved=by_g / t_g / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t_g * 1e6,
@@ -122,9 +122,9 @@ def kernel_rooflines(device, iters=20):
                              algorithmic=by_gb)
     after = torch.randn(n, L, C, device=device).to(bf).requires_grad_()
     y = K.scatter_mean_residual(xs, after, sel, WIN)
-    t_sc = time_calls(lambda: K.scatter_mean_residual(x, after.detach(), sel, WIN), iters)
+    t_sc = time_calls(lambda: K.scatter_mean_residual(x, after.detach(), sel, WIN), iters, warm)
     dy = torch.randn_like(y)
-    t_scb = time_calls(lambda: torch.autograd.grad(y, (xs, after), dy, retain_graph=True), iters)
+    t_scb = time_calls(lambda: torch.autograd.grad(y, (xs, after), dy, retain_graph=True), iters, warm)
     by_sc = n * C * L * 2 + 2 * B_PER_GPU * HW * HW * C * 4
     by_scb = 2 * B_PER_GPU * HW * HW * C * 4 + n * C * L * (2 + 2) + n * C * (WIN + 1) ** 2 * 4
     out["scatter_mean_fwd"] = dict(bound="hbm", achieved=by_sc / t_sc / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -137,9 +137,23 @@ def kernel_rooflines(device, iters=20):
     return out
 
 
-def cpu_baseline(sample_batch=4, iters=3):
-    """The CPU oracle on this host's cores: the same pair, fp32, forward + backward, on a
-    bounded sample (a fraction of the batch) so that the default run stays within minutes."""
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over
+    `bench.py --pmc-target` (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE; see
+    tools/pmc_summary.py).  Counters cannot be read from inside this process, so the figure is
+    the one measured by those passes at the same shapes; None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel]["traffic"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpu_baseline(sample_batch=8, budget_s=15.0):
+    """The CPU oracle on this host's cores: the same residual pair, fp32, forward + backward, on a
+    bounded sample (a quarter of the batch, repeated until about budget_s seconds have passed)
+    so that the default run stays within minutes."""
     from oracle import dswin_oracle as D
     cores = os.cpu_count() or 1
     threads = min(cores, 16)
@@ -152,17 +166,19 @@ def cpu_baseline(sample_batch=4, iters=3):
     noise = D.gumbel_noise((sample_batch, (HW // WIN) ** 2), gen)
 
     def step():
-        y = D.dsmsa_forward(Ps, D.wmsa_forward(Pw, x, WIN, HEADS), WIN, HEADS, training=True, noise=noise)
+        y = x + D.wmsa_forward(Pw, x, WIN, HEADS)
+        y = y + D.dsmsa_forward(Ps, y, WIN, HEADS, training=True, noise=noise)
         y.sum().backward()
 
     step()
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    iters, t0 = 0, time.perf_counter()
+    while iters < 2 or time.perf_counter() - t0 < budget_s:
         step()
+        iters += 1
     dt = (time.perf_counter() - t0) / iters
     return dict(value=sample_batch / dt, unit="patches/s", cores=threads, kind="port",
-                sample="CPU oracle (PyTorch restatement of DSwinT_arch.py WindowedMSA + DS-MSA), fp32, fwd+bwd, "
-                       "batch %d of 64x64x180, %d iters, %.2f s/iter" % (sample_batch, iters, dt))
+                sample="CPU oracle (PyTorch restatement of DSwinT_arch.py WindowedMSA + DS-MSA, residual pair), fp32, "
+                       "fwd+bwd, batch %d of 64x64x180, %d iters, %.2f s/iter" % (sample_batch, iters, dt))
 
 
 def main():
@@ -172,6 +188,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--pmc-target", action="store_true",
+                    help="launch every kernel of the path twice at the bench shapes and exit (the "
+                         "program rocprofv3 --pmc passes run; see tools/pmc_summary.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,6 +207,10 @@ def main():
 
     from visiontransformer_amd import _lib
     _lib.load()
+    if args.pmc_target:
+        kernel_rooflines(device, iters=2, warm=0)
+        torch.cuda.synchronize()
+        return
     model = build_pair(device)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
@@ -245,7 +268,8 @@ def main():
             ks = kernel_rooflines(device)
             dom = ks["win_attn_bwd"]
             line["roofline"] = {"bound": "mfma", "kernel": "win_attn_bwd_kernel<bf16,w16,d32>", "achieved": dom["achieved"],
-                                "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                                "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"],
+                                "traffic": pmc_traffic("win_attn_bwd_kernel<unsigned short, 16, 32, true, false>"),
                                 "us_per_launch": dom["us"]}
             line["kernels"] = ks
         if world == 1 and not args.no_cpu_baseline:
