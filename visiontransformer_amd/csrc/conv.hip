@@ -11,7 +11,6 @@
 namespace dsw {
 
 constexpr int CV_THREADS = 256;
-constexpr int CV_TILE = 32;  // pixels of one image row per block (stream kernels)
 
 __device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
 __device__ __forceinline__ float silu_grad(float v) {
@@ -29,10 +28,15 @@ __device__ __forceinline__ float4 fma4s(float4 a, float s, float4 c) {
 // depthwise 3x3, stride 1, zero padding 1.  FLIP = data gradient (taps mirrored, no bias).
 // weights [C][9] fp32 in global -> LDS as [9][C]
 // ---------------------------------------------------------------------------------------------
+// An image row is W*C/4 consecutive float4; thread i of a row segment owns float4 i (pixel i / (C/4),
+// channel quad i % (C/4)) and walks down CW_ROWS image rows with a 3 x 3 register window, so every
+// load instruction of a wave is one contiguous run, a row is fetched (CW_ROWS + 2) / CW_ROWS times,
+// and the left / right neighbours come from the vector cache.  The 9 tap vectors stay in registers.
+constexpr int CW_ROWS = 8;
 template <typename TI, typename TO, bool FLIP>
 __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__restrict__ x, const float *__restrict__ wgt,
                                                                    const float *__restrict__ bias, int H, int W, int C,
-                                                                   int tiles, TO *__restrict__ y) {
+                                                                   int segs, TO *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float ws[];  // [9][C] + [C]
     for (int i = threadIdx.x; i < C * 9; i += CV_THREADS) {
         const int c = i / 9, t = i - c * 9;
@@ -40,71 +44,104 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
     }
     for (int i = threadIdx.x; i < C; i += CV_THREADS) ws[9 * C + i] = (bias != nullptr && !FLIP) ? bias[i] : 0.f;
     __syncthreads();
-    const int tile = blockIdx.x % tiles, h = (blockIdx.x / tiles) % H, b = blockIdx.x / (tiles * H);
-    const int x0 = tile * CV_TILE, npix = min(CV_TILE, W - x0), CV = C >> 2;
-    const TI *img = x + (size_t)b * H * W * C;
-    for (int it = threadIdx.x; it < npix * CV; it += CV_THREADS) {
-        const int p = it / CV, c = (it - p * CV) << 2, xx = x0 + p;
-        float4 acc = *reinterpret_cast<const float4 *>(ws + 9 * C + c);
+    const int CV = C >> 2, rowq = W * CV, hblocks = (H + CW_ROWS - 1) / CW_ROWS;
+    const int seg = blockIdx.x % segs, hb = (blockIdx.x / segs) % hblocks, b = blockIdx.x / (segs * hblocks);
+    const int i = seg * CV_THREADS + threadIdx.x;
+    if (i >= rowq) return;
+    const int xx = i / CV, c = (i - xx * CV) << 2;
+    float4 wq[9];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int yy = h + a - 1;
-            if (yy < 0 || yy >= H) continue;
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb) {
-                const int xc = xx + bb - 1;
-                if (xc < 0 || xc >= W) continue;
-                acc = fma4(io<TI>::ld4(img + ((size_t)yy * W + xc) * C + c), *reinterpret_cast<const float4 *>(ws + (a * 3 + bb) * C + c), acc);
-            }
+    for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const float4 *>(ws + t * C + c);
+    const float4 bq = *reinterpret_cast<const float4 *>(ws + 9 * C + c);
+    const size_t rs = (size_t)W * C;
+    const TI *src = x + (size_t)b * H * rs + (size_t)i * 4;
+    TO *dst = y + (size_t)b * H * rs + (size_t)i * 4;
+    const bool has_l = xx > 0, has_r = xx < W - 1;
+    const int h0 = hb * CW_ROWS, h1 = min(h0 + CW_ROWS, H);
+    float4 r0[3], r1[3], r2[3];
+    auto load_row = [&](int yy, float4(&r)[3]) {
+        if (yy < 0 || yy >= H) {
+            r[0] = r[1] = r[2] = f4zero();
+        } else {
+            const TI *pr = src + (size_t)yy * rs;
+            r[1] = io<TI>::ld4(pr);
+            r[0] = has_l ? io<TI>::ld4(pr - C) : f4zero();
+            r[2] = has_r ? io<TI>::ld4(pr + C) : f4zero();
         }
-        io<TO>::st4(y + (((size_t)b * H + h) * W + xx) * C + c, acc);
+    };
+    load_row(h0 - 1, r0);
+    load_row(h0, r1);
+#pragma unroll 2
+    for (int h = h0; h < h1; ++h) {
+        load_row(h + 1, r2);
+        float4 acc = bq;
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+            acc = fma4(r0[bb], wq[bb], acc);
+            acc = fma4(r1[bb], wq[3 + bb], acc);
+            acc = fma4(r2[bb], wq[6 + bb], acc);
+        }
+        io<TO>::st4(dst + (size_t)h * rs, acc);
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) r0[bb] = r1[bb], r1[bb] = r2[bb];
     }
 }
 
-// weight / bias gradient partials: one block per ROWS image rows; thread = (channel quad, pixel group)
-constexpr int DW_ROWS = 2;
+// weight / bias gradient partials: one block per DW_ROWS image rows.  Thread = (pixel part, channel
+// quad, tap row a): walking along an image row the three tap columns are a sliding window of x, so a
+// pixel costs one x load and one dy load.  The parts are summed through LDS in part order.
+constexpr int DW_ROWS = 4;
+constexpr int WG_THREADS = 448;  // 3 parts x (45 quads x 3 tap rows) at C = 180
 template <typename TG, typename TX>
-__global__ __launch_bounds__(CV_THREADS) void dwconv_wgrad_kernel(const TG *__restrict__ dy, const TX *__restrict__ x, int H,
+__global__ __launch_bounds__(WG_THREADS) void dwconv_wgrad_kernel(const TG *__restrict__ dy, const TX *__restrict__ x, int H,
                                                                   int W, int C, float *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [PG][CV][40]
-    const int CV = C >> 2, PG = CV_THREADS / CV;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [CV*3][16]: 3 tap columns + dy sum, x 4 channels
+    const int CV = C >> 2, NI = CV * 3, PP = max(1, WG_THREADS / NI);
     const int rows_per_img = (H + DW_ROWS - 1) / DW_ROWS;
     const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x - b * rows_per_img) * DW_ROWS;
-    const int cv = threadIdx.x % CV, pg = threadIdx.x / CV;
-    float4 acc[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = f4zero();
-    if (pg < PG) {
-        const int c = cv << 2;
-        const TG *gimg = dy + (size_t)b * H * W * C;
-        const TX *ximg = x + (size_t)b * H * W * C;
+    const int item = threadIdx.x % NI, part = threadIdx.x / NI;
+    const int cv = item / 3, a = item - cv * 3, c = cv << 2;
+    const int chunk = (W + PP - 1) / PP, p0 = part * chunk, p1 = min(p0 + chunk, W);
+    float4 acc[3] = {f4zero(), f4zero(), f4zero()}, gsum = f4zero();
+    if (part < PP && p0 < p1) {
+        const TG *gimg = dy + (size_t)b * H * W * C + c;
+        const TX *ximg = x + (size_t)b * H * W * C + c;
         for (int h = h0; h < min(h0 + DW_ROWS, H); ++h) {
-            for (int p = pg; p < W; p += PG) {
-                const float4 g = io<TG>::ld4(gimg + ((size_t)h * W + p) * C + c);
-                acc[9] = acc[9] + g;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int yy = h + a - 1;
-                    if (yy < 0 || yy >= H) continue;
-#pragma unroll
-                    for (int bb = 0; bb < 3; ++bb) {
-                        const int xc = p + bb - 1;
-                        if (xc < 0 || xc >= W) continue;
-                        acc[a * 3 + bb] = fma4(g, io<TX>::ld4(ximg + ((size_t)yy * W + xc) * C + c), acc[a * 3 + bb]);
-                    }
-                }
+            const int yy = h + a - 1;
+            if (yy < 0 || yy >= H) continue;
+            const TX *xrow = ximg + (size_t)yy * W * C;
+            const TG *grow = gimg + (size_t)h * W * C;
+            float4 xm = p0 > 0 ? io<TX>::ld4(xrow + (size_t)(p0 - 1) * C) : f4zero();
+            float4 xc = io<TX>::ld4(xrow + (size_t)p0 * C);
+#pragma unroll 4
+            for (int p = p0; p < p1; ++p) {
+                const float4 xp = (p + 1 < W) ? io<TX>::ld4(xrow + (size_t)(p + 1) * C) : f4zero();
+                const float4 g = io<TG>::ld4(grow + (size_t)p * C);
+                acc[0] = fma4(g, xm, acc[0]);
+                acc[1] = fma4(g, xc, acc[1]);
+                acc[2] = fma4(g, xp, acc[2]);
+                gsum = gsum + g;
+                xm = xc;
+                xc = xp;
             }
         }
-#pragma unroll
-        for (int i = 0; i < 10; ++i) *reinterpret_cast<float4 *>(red + ((size_t)(pg * CV + cv) * 10 + i) * 4) = acc[i];
     }
-    __syncthreads();
-    // partial[blk][c][k]: sum over pixel groups in order
-    for (int i = threadIdx.x; i < C * 10; i += CV_THREADS) {
-        const int c = i / 10, k = i - c * 10;
-        float s = 0.f;
-        for (int g2 = 0; g2 < PG; ++g2) s += red[((size_t)(g2 * CV + (c >> 2)) * 10 + k) * 4 + (c & 3)];
-        partial[(size_t)blockIdx.x * C * 10 + i] = s;
+    for (int pt = 0; pt < PP; ++pt) {
+        if (part == pt) {
+            float4 *dst = reinterpret_cast<float4 *>(red + (size_t)item * 16);
+            if (pt == 0) {
+                dst[0] = acc[0], dst[1] = acc[1], dst[2] = acc[2], dst[3] = gsum;
+            } else {
+                dst[0] = dst[0] + acc[0], dst[1] = dst[1] + acc[1], dst[2] = dst[2] + acc[2], dst[3] = dst[3] + gsum;
+            }
+        }
+        __syncthreads();
+    }
+    // partial[blk][c][k]: k = a*3 + bb, k = 9: bias (the dy sum of the a = 1 thread, whose rows are all valid)
+    for (int i = threadIdx.x; i < C * 10; i += WG_THREADS) {
+        const int ch = i / 10, k = i - ch * 10;
+        const int a2 = k < 9 ? k / 3 : 1, slot = k < 9 ? k - a2 * 3 : 3;
+        partial[(size_t)blockIdx.x * C * 10 + i] = red[((size_t)((ch >> 2) * 3 + a2) * 4 + slot) * 4 + (ch & 3)];
     }
 }
 
@@ -133,64 +170,64 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float *__rest
 //   stage B (tiny):            sd = conv4(silu(u))
 // weights: w0 [4][C][3][3], b0 [4]; w2 [4][4][w][w], b2 [4]; w4 [4][4][3][3], b4 [4]  (fp32)
 // ---------------------------------------------------------------------------------------------
-// LDS copy of w0 as [tap][ci][o] so that one float4 read gives the 4 outputs of (tap, ci)
+// conv0: t0[b,y,x,o] = b0[o] + sum_{ci,taps} w0[o][ci][tap] * x[b,y+a-1,x+bb-1,ci].
+// 16 lanes per strip of 4 consecutive pixels of an image row; each lane covers a strided share of
+// the channel quads, so one set of weight reads serves 4 pixels and 6 input columns serve 3 taps.
+// A strip is 3 tap rows x ceil(C/64) channel rounds; the 6 input vectors of the next round are in
+// flight while the current round's 192 FMAs run.  Blocks loop over strips (weights staged once).
+// LDS copy of w0 as [tap][ci][o]: one float4 read gives the 4 outputs of (tap, ci).
 template <typename TX>
 __global__ __launch_bounds__(CV_THREADS) void sd_stage_a_kernel(const TX *__restrict__ x, const float *__restrict__ w0,
-                                                                const float *__restrict__ b0, const float *__restrict__ w2,
-                                                                const float *__restrict__ b2, int H, int W, int C, int w,
-                                                                float *__restrict__ t0, float *__restrict__ u) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *w0s = sm;                  // [9][C][4]
-    float *w2s = w0s + 9 * C * 4;     // [w*w][4 (c2)][4 (o)]
-    float *red = w2s + w * w * 16;    // [CV_THREADS/16][4]
-    const int Hw = H / w, Ww = W / w, L = w * w;
-    const int wc = blockIdx.x % Ww, wr = (blockIdx.x / Ww) % Hw, b = blockIdx.x / (Ww * Hw);
-    for (int i = threadIdx.x; i < 4 * C * 9; i += CV_THREADS) {
-        const int o = i / (C * 9), r = i - o * C * 9, ci = r / 9, t = r - ci * 9;
-        w0s[(t * C + ci) * 4 + o] = w0[i];
-    }
-    for (int i = threadIdx.x; i < 16 * L; i += CV_THREADS) {
-        const int o = i / (4 * L), r = i - o * 4 * L, c2 = r / L, pix = r - c2 * L;
-        w2s[(pix * 4 + c2) * 4 + o] = w2[i];
+                                                                const float *__restrict__ b0, int B, int H, int W, int C,
+                                                                float *__restrict__ t0) {
+    extern __shared__ __attribute__((aligned(16))) float w0s[];  // [9][C][4]
+    for (int i = threadIdx.x; i < 4 * C; i += CV_THREADS) {
+        const int o = i / C, ci = i - o * C;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w0s[(t * C + ci) * 4 + o] = w0[(size_t)i * 9 + t];
     }
     __syncthreads();
-    // 16 lanes per strip of 4 consecutive pixels of a window row; each lane covers a strided share of
-    // the channel quads, so one set of weight reads serves 4 pixels and 6 input columns serve 3 taps
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, CV = C >> 2;
-    const TX *img = x + (size_t)b * H * W * C;
-    float4 uacc = f4zero();  // this group's share of u[0..3]
-    const int strips_per_row = w >> 2, nstrips = w * strips_per_row;
-    for (int sidx = grp; sidx < nstrips; sidx += CV_THREADS / 16) {
-        const int py = sidx / strips_per_row, px0 = (sidx - py * strips_per_row) << 2;
-        const int y = wr * w + py, xs = wc * w + px0;
-        float4 acc[4];
+    const int strips_per_row = W >> 2, nit = (CV + 15) >> 4, rounds = 3 * nit;
+    const long long nstrips = (long long)B * H * strips_per_row;
+    const float4 bq = make_float4(b0[0], b0[1], b0[2], b0[3]);
+    for (long long s0 = (long long)blockIdx.x * (CV_THREADS / 16); s0 < nstrips; s0 += (long long)gridDim.x * (CV_THREADS / 16)) {
+        // out-of-range groups run on a clamped strip (the shuffles below need every lane) and skip the store
+        const bool live = s0 + grp < nstrips;
+        const long long sc = live ? s0 + grp : nstrips - 1;
+        const int xs = (int)(sc % strips_per_row) << 2;
+        const int y = (int)((sc / strips_per_row) % H), b = (int)(sc / ((long long)strips_per_row * H));
+        const TX *img = x + (size_t)b * H * W * C;
+        auto load_round = [&](int r, float4(&v)[6]) {
+            const int a = r / nit, cv = gl + ((r - a * nit) << 4), yy = y + a - 1;
+            const bool ok = yy >= 0 && yy < H && cv < CV;
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) acc[pp] = f4zero();
+            for (int k = 0; k < 6; ++k) {
+                const int xc = xs + k - 1;
+                v[k] = (ok && xc >= 0 && xc < W) ? io<TX>::ld4(img + ((size_t)yy * W + xc) * C + (cv << 2)) : f4zero();
+            }
+        };
+        float4 acc[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
+        float4 vc[6], vn[6];
+        load_round(0, vc);
+        for (int r = 0; r < rounds; ++r) {
+            if (r + 1 < rounds) load_round(r + 1, vn);
+            const int a = r / nit, cv = min(gl + ((r - a * nit) << 4), CV - 1);  // past-the-end lanes hold zeros in vc
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int yy = y + a - 1;
-            if (yy < 0 || yy >= H) continue;
-            for (int cv = gl; cv < CV; cv += 16) {
-                float4 v[6];
+            for (int bb = 0; bb < 3; ++bb) {
+                const float4 *wq = reinterpret_cast<const float4 *>(w0s + ((size_t)(a * 3 + bb) * C + (cv << 2)) * 4);
+                const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2], q3 = wq[3];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const int xc = xs + k - 1;
-                    v[k] = (xc >= 0 && xc < W) ? io<TX>::ld4(img + ((size_t)yy * W + xc) * C + (cv << 2)) : f4zero();
-                }
-#pragma unroll
-                for (int bb = 0; bb < 3; ++bb) {
-                    const float4 *wq = reinterpret_cast<const float4 *>(w0s + ((size_t)(a * 3 + bb) * C + (cv << 2)) * 4);
-                    const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2], q3 = wq[3];
-#pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) {
-                        const float4 vv = v[pp + bb];
-                        acc[pp] = fma4s(q0, vv.x, acc[pp]);
-                        acc[pp] = fma4s(q1, vv.y, acc[pp]);
-                        acc[pp] = fma4s(q2, vv.z, acc[pp]);
-                        acc[pp] = fma4s(q3, vv.w, acc[pp]);
-                    }
+                for (int pp = 0; pp < 4; ++pp) {
+                    const float4 vv = vc[pp + bb];
+                    acc[pp] = fma4s(q0, vv.x, acc[pp]);
+                    acc[pp] = fma4s(q1, vv.y, acc[pp]);
+                    acc[pp] = fma4s(q2, vv.z, acc[pp]);
+                    acc[pp] = fma4s(q3, vv.w, acc[pp]);
                 }
             }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vc[k] = vn[k];
         }
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
@@ -201,27 +238,38 @@ __global__ __launch_bounds__(CV_THREADS) void sd_stage_a_kernel(const TX *__rest
                 acc[pp].z += __shfl_xor(acc[pp].z, o, 64);
                 acc[pp].w += __shfl_xor(acc[pp].w, o, 64);
             }
-            acc[pp].x += b0[0];
-            acc[pp].y += b0[1];
-            acc[pp].z += b0[2];
-            acc[pp].w += b0[3];
-            if (gl == 0) {
-                *reinterpret_cast<float4 *>(t0 + (((size_t)b * H + y) * W + xs + pp) * 4) = acc[pp];
-                // conv2 contribution of this pixel: u[o] += sum_c2 w2[o][c2][pix] * silu(t0[c2])
-                const float4 *w2q = reinterpret_cast<const float4 *>(w2s + (py * w + px0 + pp) * 16);
-                uacc = fma4s(w2q[0], silu(acc[pp].x), uacc);
-                uacc = fma4s(w2q[1], silu(acc[pp].y), uacc);
-                uacc = fma4s(w2q[2], silu(acc[pp].z), uacc);
-                uacc = fma4s(w2q[3], silu(acc[pp].w), uacc);
-            }
+        }
+        if (live && gl < 4) {
+            // lane gl stores pixel gl of the strip (every lane holds all four sums)
+            const float4 r = gl == 0 ? acc[0] : gl == 1 ? acc[1] : gl == 2 ? acc[2] : acc[3];
+            *reinterpret_cast<float4 *>(t0 + (((size_t)b * H + y) * W + xs + gl) * 4) = r + bq;
         }
     }
-    if (gl == 0) *reinterpret_cast<float4 *>(red + grp * 4) = uacc;
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        float s = b2[threadIdx.x];
-        for (int g2 = 0; g2 < CV_THREADS / 16; ++g2) s += red[g2 * 4 + threadIdx.x];
-        u[((size_t)(b * 4 + threadIdx.x) * Hw + wr) * Ww + wc] = s;
+}
+
+// conv2 (kernel = stride = window): u[b,o,wr,wc] = b2[o] + sum_{c2,pix} w2[o][c2][pix] * silu(t0[b,pix,c2]);
+// one block per window, fixed-order block reduction.
+__global__ __launch_bounds__(256) void sd_stage_u_kernel(const float *__restrict__ t0, const float *__restrict__ w2,
+                                                         const float *__restrict__ b2, int H, int W, int w,
+                                                         float *__restrict__ u) {
+    __shared__ float red[4];
+    const int Hw = H / w, Ww = W / w, L = w * w;
+    const int wc = blockIdx.x % Ww, wr = (blockIdx.x / Ww) % Hw, b = blockIdx.x / (Ww * Hw);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pix = threadIdx.x; pix < L; pix += 256) {
+        const int py = pix / w, px = pix - py * w;
+        const float4 t = *reinterpret_cast<const float4 *>(t0 + (((size_t)b * H + wr * w + py) * W + wc * w + px) * 4);
+        const float sv[4] = {silu(t.x), silu(t.y), silu(t.z), silu(t.w)};
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) acc[o] = fmaf(w2[(size_t)(o * 4 + c2) * L + pix], sv[c2], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const float tsum = block_sum(acc[o], red);
+        if (threadIdx.x == 0) u[((size_t)(b * 4 + o) * Hw + wr) * Ww + wc] = tsum + b2[o];
+        __syncthreads();
     }
 }
 
@@ -359,106 +407,132 @@ __global__ __launch_bounds__(256) void sd_bwd_w2_kernel(const float *__restrict_
     }
 }
 
-// dx[b,y,x,ci] = sum_{o,taps} w0[o][ci][tap] * dt0[b, y-(a-1), x-(bb-1), o]   (pixel-centric stream)
+// dx[b,y,x,ci] = sum_{o,taps} w0[o][ci][tap] * dt0[b, y-(a-1), x-(bb-1), o].  Same row-segment / walk-down
+// mapping as the depthwise kernel; the channel quad's 36 weight vectors live in registers and the
+// dt0 window (16 B per pixel, shared by all channel quads of the pixel) comes from the vector cache.
 template <typename TO>
 __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__restrict__ dt0, const float *__restrict__ w0,
-                                                               int H, int W, int C, int tiles, TO *__restrict__ dx) {
+                                                               int H, int W, int C, int segs, TO *__restrict__ dx) {
     extern __shared__ __attribute__((aligned(16))) float w0s[];  // [tap][o][C]
-    for (int i = threadIdx.x; i < 4 * C * 9; i += CV_THREADS) {
-        const int o = i / (C * 9), r = i - o * C * 9, ci = r / 9, t = r - ci * 9;
-        w0s[(t * 4 + o) * C + ci] = w0[i];
+    for (int i = threadIdx.x; i < 4 * C; i += CV_THREADS) {
+        const int o = i / C, ci = i - o * C;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w0s[(t * 4 + o) * C + ci] = w0[(size_t)i * 9 + t];
     }
     __syncthreads();
-    const int tile = blockIdx.x % tiles, h = (blockIdx.x / tiles) % H, b = blockIdx.x / (tiles * H);
-    const int x0 = tile * CV_TILE, npix = min(CV_TILE, W - x0), CV = C >> 2;
-    const float *gimg = dt0 + (size_t)b * H * W * 4;
-    for (int it = threadIdx.x; it < npix * CV; it += CV_THREADS) {
-        const int p = it / CV, c = (it - p * CV) << 2, xx = x0 + p;
+    const int CV = C >> 2, rowq = W * CV, hblocks = (H + CW_ROWS - 1) / CW_ROWS;
+    const int seg = blockIdx.x % segs, hb = (blockIdx.x / segs) % hblocks, b = blockIdx.x / (segs * hblocks);
+    const int i = seg * CV_THREADS + threadIdx.x;
+    if (i >= rowq) return;
+    const int xx = i / CV, c = (i - xx * CV) << 2;
+    float4 wq[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) wq[t][o] = *reinterpret_cast<const float4 *>(w0s + (size_t)(t * 4 + o) * C + c);
+    const float *gimg = dt0 + (size_t)b * H * W * 4 + (size_t)xx * 4;
+    TO *dst = dx + (size_t)b * H * W * C + (size_t)i * 4;
+    const size_t rs = (size_t)W * C;
+    const bool has_l = xx > 0, has_r = xx < W - 1;
+    const int h0 = hb * CW_ROWS, h1 = min(h0 + CW_ROWS, H);
+    // g[k]: dt0 at columns xx-1, xx, xx+1; rows y-1 (r0), y (r1), y+1 (r2).  Tap (a, bb) pairs with row y+1-a, column xx+1-bb.
+    float4 r0[3], r1[3], r2[3];
+    auto load_row = [&](int yy, float4(&r)[3]) {
+        if (yy < 0 || yy >= H) {
+            r[0] = r[1] = r[2] = f4zero();
+        } else {
+            const float *pr = gimg + (size_t)yy * W * 4;
+            r[1] = *reinterpret_cast<const float4 *>(pr);
+            r[0] = has_l ? *reinterpret_cast<const float4 *>(pr - 4) : f4zero();
+            r[2] = has_r ? *reinterpret_cast<const float4 *>(pr + 4) : f4zero();
+        }
+    };
+    load_row(h0 - 1, r0);
+    load_row(h0, r1);
+    for (int h = h0; h < h1; ++h) {
+        load_row(h + 1, r2);
         float4 acc = f4zero();
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int yy = h - (a - 1);
-            if (yy < 0 || yy >= H) continue;
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb) {
-                const int xc = xx - (bb - 1);
-                if (xc < 0 || xc >= W) continue;
-                const float4 g = *reinterpret_cast<const float4 *>(gimg + ((size_t)yy * W + xc) * 4);
-                const float *wt = w0s + (size_t)(a * 3 + bb) * 4 * C + c;
-                acc = fma4s(*reinterpret_cast<const float4 *>(wt), g.x, acc);
-                acc = fma4s(*reinterpret_cast<const float4 *>(wt + C), g.y, acc);
-                acc = fma4s(*reinterpret_cast<const float4 *>(wt + 2 * C), g.z, acc);
-                acc = fma4s(*reinterpret_cast<const float4 *>(wt + 3 * C), g.w, acc);
-            }
+        for (int bb = 0; bb < 3; ++bb) {
+            const float4 g2 = r2[2 - bb], g1 = r1[2 - bb], g0 = r0[2 - bb];  // a = 0, 1, 2
+            acc = fma4s(wq[bb][0], g2.x, acc), acc = fma4s(wq[bb][1], g2.y, acc);
+            acc = fma4s(wq[bb][2], g2.z, acc), acc = fma4s(wq[bb][3], g2.w, acc);
+            acc = fma4s(wq[3 + bb][0], g1.x, acc), acc = fma4s(wq[3 + bb][1], g1.y, acc);
+            acc = fma4s(wq[3 + bb][2], g1.z, acc), acc = fma4s(wq[3 + bb][3], g1.w, acc);
+            acc = fma4s(wq[6 + bb][0], g0.x, acc), acc = fma4s(wq[6 + bb][1], g0.y, acc);
+            acc = fma4s(wq[6 + bb][2], g0.z, acc), acc = fma4s(wq[6 + bb][3], g0.w, acc);
         }
-        io<TO>::st4(dx + (((size_t)b * H + h) * W + xx) * C + c, acc);
+        io<TO>::st4(dst + (size_t)h * rs, acc);
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) r0[bb] = r1[bb], r1[bb] = r2[bb];
     }
 }
 
-// d(w0) partials: block = SD_ROWS image rows; thread = (channel quad, tap row a, pixel part).  Walking
-// along an image row the three tap columns are a sliding window of x, so each pixel costs one new
-// x load and one dt0 load for 48 FMAs.  12 float4 accumulators: [bb][o] x 4 channels.
+// d(w0) / d(b0) partials: block = SD_ROWS image rows; thread = (pixel part, channel quad, tap row a).
+// Walking along an image row the three tap columns are a sliding window of x, so each pixel costs one
+// new x load and one dt0 load for 48 FMAs.  12 float4 accumulators: [bb][o] x 4 channels, plus the
+// dt0 sum for d(b0).  The parts are summed through LDS in part order.
 constexpr int SD_ROWS = 4;
 template <typename TX>
-__global__ __launch_bounds__(CV_THREADS) void sd_bwd_w0_kernel(const float *__restrict__ dt0, const TX *__restrict__ x, int H,
+__global__ __launch_bounds__(WG_THREADS) void sd_bwd_w0_kernel(const float *__restrict__ dt0, const TX *__restrict__ x, int H,
                                                                int W, int C, float *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [PP][CV*3][48]
-    const int CV = C >> 2, rows_per_img = (H + SD_ROWS - 1) / SD_ROWS;
-    const int PP = max(1, CV_THREADS / (CV * 3));  // pixel parts per row
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [CV*3][13][4]
+    const int CV = C >> 2, NI = CV * 3, PP = max(1, WG_THREADS / NI), rows_per_img = (H + SD_ROWS - 1) / SD_ROWS;
     const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x - b * rows_per_img) * SD_ROWS;
     const float *gimg = dt0 + (size_t)b * H * W * 4;
-    const TX *ximg = x + (size_t)b * H * W * C;
     float *dst = partial + (size_t)blockIdx.x * (4 * C * 9 + 4);
-    const int item = threadIdx.x % (CV * 3), part = threadIdx.x / (CV * 3);
-    if (part < PP) {
-        const int cv = item / 3, a = item - cv * 3, c = cv << 2;
-        const int chunk = (W + PP - 1) / PP, p0 = part * chunk, p1 = min(p0 + chunk, W);
-        float4 acc[3][4];
+    const int item = threadIdx.x % NI, part = threadIdx.x / NI;
+    const int cv = item / 3, a = item - cv * 3, c = cv << 2;
+    const int chunk = (W + PP - 1) / PP, p0 = part * chunk, p1 = min(p0 + chunk, W);
+    float4 acc[3][4], gsum = f4zero();
 #pragma unroll
-        for (int bb = 0; bb < 3; ++bb)
+    for (int bb = 0; bb < 3; ++bb)
 #pragma unroll
-            for (int o = 0; o < 4; ++o) acc[bb][o] = f4zero();
+        for (int o = 0; o < 4; ++o) acc[bb][o] = f4zero();
+    if (part < PP && p0 < p1) {
+        const TX *ximg = x + (size_t)b * H * W * C + c;
         for (int h = h0; h < min(h0 + SD_ROWS, H); ++h) {
             const int yy = h + a - 1;
-            if (yy < 0 || yy >= H || p0 >= p1) continue;
-            const TX *xrow = ximg + (size_t)yy * W * C + c;
+            if (yy < 0 || yy >= H) continue;
+            const TX *xrow = ximg + (size_t)yy * W * C;
+            const float *grow = gimg + (size_t)h * W * 4;
             float4 xm = p0 > 0 ? io<TX>::ld4(xrow + (size_t)(p0 - 1) * C) : f4zero();
-            float4 x0 = io<TX>::ld4(xrow + (size_t)p0 * C);
+            float4 xc = io<TX>::ld4(xrow + (size_t)p0 * C);
+#pragma unroll 4
             for (int p = p0; p < p1; ++p) {
                 const float4 xp = (p + 1 < W) ? io<TX>::ld4(xrow + (size_t)(p + 1) * C) : f4zero();
-                const float4 g = *reinterpret_cast<const float4 *>(gimg + ((size_t)h * W + p) * 4);
+                const float4 g = *reinterpret_cast<const float4 *>(grow + (size_t)p * 4);
                 const float gv[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     acc[0][o] = fma4s(xm, gv[o], acc[0][o]);
-                    acc[1][o] = fma4s(x0, gv[o], acc[1][o]);
+                    acc[1][o] = fma4s(xc, gv[o], acc[1][o]);
                     acc[2][o] = fma4s(xp, gv[o], acc[2][o]);
                 }
-                xm = x0;
-                x0 = xp;
+                gsum = gsum + g;
+                xm = xc;
+                xc = xp;
             }
         }
+    }
+    for (int pt = 0; pt < PP; ++pt) {
+        if (part == pt) {
+            float4 *rd = reinterpret_cast<float4 *>(red + (size_t)item * 52);
 #pragma unroll
-        for (int bb = 0; bb < 3; ++bb)
+            for (int bb = 0; bb < 3; ++bb)
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                *reinterpret_cast<float4 *>(red + (((size_t)part * CV * 3 + item) * 12 + bb * 4 + o) * 4) = acc[bb][o];
+                for (int o = 0; o < 4; ++o) rd[bb * 4 + o] = pt == 0 ? acc[bb][o] : rd[bb * 4 + o] + acc[bb][o];
+            rd[12] = pt == 0 ? gsum : rd[12] + gsum;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // dst[o][ci][tap] = sum over pixel parts (in order)
-    for (int i = threadIdx.x; i < 4 * C * 9; i += CV_THREADS) {
-        const int o = i / (C * 9), r = i - o * C * 9, ci = r / 9, t = r - ci * 9, a = t / 3, bb = t - a * 3;
-        const int it2 = (ci >> 2) * 3 + a;
-        float sacc = 0.f;
-        for (int pt = 0; pt < PP; ++pt) sacc += red[(((size_t)pt * CV * 3 + it2) * 12 + bb * 4 + o) * 4 + (ci & 3)];
-        dst[i] = sacc;
+    // dst[o][ci][tap]
+    for (int i = threadIdx.x; i < 4 * C * 9; i += WG_THREADS) {
+        const int o = i / (C * 9), r = i - o * C * 9, ci = r / 9, t = r - ci * 9, a2 = t / 3, bb = t - a2 * 3;
+        dst[i] = red[((size_t)((ci >> 2) * 3 + a2) * 13 + bb * 4 + o) * 4 + (ci & 3)];
     }
-    if (threadIdx.x < 4) {  // d(b0) partial
-        float sb = 0.f;
-        for (int h = h0; h < min(h0 + SD_ROWS, H); ++h)
-            for (int p = 0; p < W; ++p) sb += gimg[((size_t)h * W + p) * 4 + threadIdx.x];
-        dst[4 * C * 9 + threadIdx.x] = sb;
-    }
+    // d(b0): the dt0 sum of the (channel quad 0, a = 1) thread, whose rows are all valid
+    if (threadIdx.x < 4) dst[4 * C * 9 + threadIdx.x] = red[(size_t)(0 * 3 + 1) * 52 + 48 + threadIdx.x];
 }
 
 // packed [C][10] -> d_weight [C][9], d_bias [C]
@@ -483,6 +557,10 @@ static int check_conv(const char *who, int B, int H, int W, int C) {
     return DSW_OK;
 }
 
+// grid of the walk-down kernels: row segments of CV_THREADS float4 x groups of CW_ROWS image rows
+static int walk_segs(int W, int C) { return (W * (C / 4) + CV_THREADS - 1) / CV_THREADS; }
+static unsigned walk_blocks(int B, int H, int segs) { return (unsigned)B * ((H + CW_ROWS - 1) / CW_ROWS) * segs; }
+
 template <typename K> static int set_lds_attr(K kern, size_t lds, const char *who) {
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "%s: needs %zu B of LDS", who, lds);
     if (lds > 48 * 1024) {
@@ -501,11 +579,11 @@ extern "C" int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight
     int rc = check_conv("dsw_dwconv3x3_fwd", B, H, W, C);
     if (rc) return rc;
     DSW_REQUIRE(x && weight && y, "dsw_dwconv3x3_fwd: null pointer");
-    const int tiles = (W + CV_TILE - 1) / CV_TILE;
     const size_t lds = (size_t)C * 10 * sizeof(float);
+    const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(x_dtype, TI, DSW_DISPATCH_DTYPE(y_dtype, TO, {
-        hipLaunchKernelGGL((dwconv_stream_kernel<TI, TO, false>), dim3(B * H * tiles), dim3(CV_THREADS), lds, as_stream(stream),
-                           (const TI *)x, weight, bias, H, W, C, tiles, (TO *)y);
+        hipLaunchKernelGGL((dwconv_stream_kernel<TI, TO, false>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds,
+                           as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, (TO *)y);
     }));
     return check_launch("dwconv_stream_kernel");
 }
@@ -522,23 +600,23 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
     if (rc) return rc;
     DSW_REQUIRE(dy && x && weight && dx && d_weight && d_bias && partial, "dsw_dwconv3x3_bwd: null pointer");
     hipStream_t st = as_stream(stream);
-    const int tiles = (W + CV_TILE - 1) / CV_TILE;
     const size_t lds = (size_t)C * 10 * sizeof(float);
+    const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
-        hipLaunchKernelGGL((dwconv_stream_kernel<TG, TO, true>), dim3(B * H * tiles), dim3(CV_THREADS), lds, st,
-                           (const TG *)dy, weight, (const float *)nullptr, H, W, C, tiles, (TO *)dx);
+        hipLaunchKernelGGL((dwconv_stream_kernel<TG, TO, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds, st,
+                           (const TG *)dy, weight, (const float *)nullptr, H, W, C, segs, (TO *)dx);
     }));
     rc = check_launch("dwconv_stream_kernel<flip>");
     if (rc) return rc;
-    const int CV = C / 4, PG = CV_THREADS / CV;
-    DSW_REQUIRE(PG >= 1, "dsw_dwconv3x3_bwd: too many channels");
+    const int NI = C / 4 * 3;
+    if (NI > WG_THREADS) return fail(DSW_EUNSUPPORTED, "dsw_dwconv3x3_bwd: %d channels > %d", C, WG_THREADS / 3 * 4);
     const int nblocks = dsw_dwconv3x3_bwd_blocks(B, H, W);
-    const size_t lds2 = (size_t)PG * CV * 40 * sizeof(float);
+    const size_t lds2 = (size_t)NI * 16 * sizeof(float);
     DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(x_dtype, TX, {
         auto kern = dwconv_wgrad_kernel<TG, TX>;
         rc = set_lds_attr(kern, lds2, "dsw_dwconv3x3_bwd");
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CV_THREADS), lds2, st, (const TG *)dy, (const TX *)x, H, W, C, partial);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WG_THREADS), lds2, st, (const TG *)dy, (const TX *)x, H, W, C, partial);
     }));
     rc = check_launch("dwconv_wgrad_kernel");
     if (rc) return rc;
@@ -562,14 +640,20 @@ extern "C" int dsw_sparse_disc_fwd(const void *x, int x_dtype, const float *w0, 
     DSW_REQUIRE(x && w0 && b0 && w2 && b2 && w4 && b4 && t0 && u && sd, "dsw_sparse_disc_fwd: null pointer");
     hipStream_t st = as_stream(stream);
     const int Hw = H / w, Ww = W / w;
-    const size_t lds = (size_t)(9 * C * 4 + w * w * 16 + (CV_THREADS / 16) * 4) * sizeof(float);
+    const size_t lds = (size_t)(9 * C * 4) * sizeof(float);
+    const long long nstrips = (long long)B * H * (W / 4);
     DSW_DISPATCH_DTYPE(x_dtype, TX, {
         auto kern = sd_stage_a_kernel<TX>;
         rc = set_lds_attr(kern, lds, "dsw_sparse_disc_fwd");
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(B * Hw * Ww), dim3(CV_THREADS), lds, st, (const TX *)x, w0, b0, w2, b2, H, W, C, w, t0, u);
+        const long long want = (nstrips + CV_THREADS / 16 - 1) / (CV_THREADS / 16);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(CV_THREADS), lds, st,
+                           (const TX *)x, w0, b0, B, H, W, C, t0);
     });
     rc = check_launch("sd_stage_a_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sd_stage_u_kernel, dim3(B * Hw * Ww), dim3(256), 0, st, t0, w2, b2, H, W, w, u);
+    rc = check_launch("sd_stage_u_kernel");
     if (rc) return rc;
     const int n = B * 4 * Hw * Ww;
     DSW_DISPATCH_DTYPE(sd_dtype, TO, {
@@ -608,22 +692,22 @@ extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x
     hipLaunchKernelGGL(sd_bwd_w2_kernel, dim3((4 * L + 1 + 15) / 16), dim3(256), 0, st, du, t0, B, H, W, w, dw2, db2);
     rc = check_launch("sd_bwd_a/w2 kernels");
     if (rc) return rc;
-    const int tiles = (W + CV_TILE - 1) / CV_TILE;
     const size_t lds = (size_t)36 * C * sizeof(float);
     DSW_DISPATCH_DTYPE(dx_dtype, TO, {
         auto kern = sd_bwd_dx_kernel<TO>;
         rc = set_lds_attr(kern, lds, "dsw_sparse_disc_bwd");
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(B * H * tiles), dim3(CV_THREADS), lds, st, dt0, w0, H, W, C, tiles, (TO *)dx);
+        const int segs = walk_segs(W, C);
+        hipLaunchKernelGGL(kern, dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds, st, dt0, w0, H, W, C, segs, (TO *)dx);
     });
     DSW_DISPATCH_DTYPE(x_dtype, TX, {
         auto kern0 = sd_bwd_w0_kernel<TX>;
-        const int CVq = C / 4, PPq = CV_THREADS / (CVq * 3) > 0 ? CV_THREADS / (CVq * 3) : 1;
-        if (CVq * 3 > CV_THREADS) return fail(DSW_EUNSUPPORTED, "dsw_sparse_disc_bwd: %d channels > %d", C, CV_THREADS / 3 * 4);
-        const size_t lds0 = (size_t)PPq * CVq * 3 * 48 * sizeof(float);
+        const int NI = C / 4 * 3;
+        if (NI > WG_THREADS) return fail(DSW_EUNSUPPORTED, "dsw_sparse_disc_bwd: %d channels > %d", C, WG_THREADS / 3 * 4);
+        const size_t lds0 = (size_t)NI * 52 * sizeof(float);
         rc = set_lds_attr(kern0, lds0, "dsw_sparse_disc_bwd");
         if (rc) return rc;
-        hipLaunchKernelGGL(kern0, dim3(nblk), dim3(CV_THREADS), lds0, st, dt0, (const TX *)x, H, W, C, part);
+        hipLaunchKernelGGL(kern0, dim3(nblk), dim3(WG_THREADS), lds0, st, dt0, (const TX *)x, H, W, C, part);
     });
     rc = check_launch("sd_bwd_dx/w0 kernels");
     if (rc) return rc;
