@@ -18,6 +18,9 @@
 
 #include "attn_common.hpp"
 
+#ifndef DSW_ABL
+#define DSW_ABL 0
+#endif
 #pragma clang fp contract(fast)
 
 namespace dsw {
@@ -280,8 +283,12 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                 const int it = tid + i * THREADS;
                 const int row = it / DW, ec = min((it - row * DW) * 2, d - 2);
                 const size_t tr = trow(qb * 32 + row);
+#if DSW_ABL == 15
+                nq[i] = (uint32_t)tr * 77u + ec; ng[i] = (uint32_t)tr * 13u + ec;
+#else
                 nq[i] = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + qoff + ec);
                 ng[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + head * d + ec);
+#endif
             }
         } else {
 #pragma unroll
@@ -342,9 +349,9 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
 
     load_block(0);
     for (int qb = 0; qb < NT; ++qb) {
-        __syncthreads();  // previous block's LDS reads are done (first pass: prologue writes land)
+        lds_barrier();  // previous block's LDS reads are done (first pass: prologue writes land)
         store_block();
-        __syncthreads();
+        lds_barrier();
         if (qb + 1 < NT) load_block(qb + 1);
 
 #pragma unroll
@@ -392,12 +399,16 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             // ---- P = exp2(S'), dS = P * dP' ------------------------------------------------------------
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#if DSW_ABL == 17
+                const float p = sacc[r] * 0.001f;
+#else
                 const float p = __builtin_amdgcn_exp2f(sacc[r]);
+#endif
                 const float ds = p * pacc[r];
                 sacc[r] = p;
                 pacc[r] = ds;
             }
-            if constexpr (BIAS && WS == 16) {
+            if constexpr (BIAS && WS == 16 && DSW_ABL != 13) {
                 float all[2] = {0.f, 0.f}, wrapped[2] = {0.f, 0.f};
                 diag_sums(std::make_integer_sequence<int, 16>{}, pacc, wrapf, all, wrapped);
 #pragma unroll
@@ -421,7 +432,7 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             }
             // ---- dS block to LDS for dQ ---------------------------------------------------------------
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < (DSW_ABL == 14 ? 0 : 16); ++r) {
                 if constexpr (BF) dSs[(rho(r) + 4 * hh) * SS + key] = f32_to_bf16(pacc[r]);
                 else dSs[(rho(r) + 4 * hh) * SS + key] = pacc[r];
             }
@@ -456,7 +467,7 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                 }
             }
         }
-        __syncthreads();  // the whole dS block is in LDS
+        lds_barrier();  // the whole dS block is in LDS
 
         // ---- d(bias table): every thread owns a few table entries (di, dj) and sums the dS elements
         // of this block that map to them, straight from the dS tile - a gather in a fixed order,
@@ -488,6 +499,9 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         }
 
         // ---- dQ block = dS K * scale: 16x16 output tiles, one (or more) per wave, K-dim = all keys ---
+#if DSW_ABL == 11
+        if (scale != 12345.f) continue;
+#endif
 #pragma unroll
         for (int tq = 0; tq < Cfg::QT_PER_WAVE; ++tq) {
             const int tile = wave * Cfg::QT_PER_WAVE + tq;
@@ -511,6 +525,9 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             }
             // C layout: column (head dim) = lane & 15, row (query) = 4*(lane>>4) + reg
             const int e = 16 * nd + l15;
+#if DSW_ABL == 12
+            if (qacc[0] == 12345.f)
+#endif
             if (e < d) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -522,29 +539,58 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     }
 
     // ---- epilogue: dK^T, dV^T (rows = head dim in registers, lane = key) ------------------------
+    if (pair_path) {
+        if constexpr (BF) {
+            // each wave turns its tiles into [key][head dim] rows in a private slice of the (now free)
+            // dS region, so that the global stores are runs of whole rows instead of one dword in each
+            // of 32 rows; a wave's LDS accesses complete in order and nobody else touches its slice
+            __syncthreads();
+#if DSW_ABL == 16
+            if (scale != 12345.f) return;
+#endif
+            T *slice = dSs + wave * (32 * QS);
+            constexpr int DWR = DP / 2, RPI = 64 / DWR;
+            const int dw = lane % DWR, rsub = lane / DWR;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int key = 32 * (wave * KT + kt) + l31;
-        T *dkrow = dqkv + trow(key) * C3 + koff;
-        T *dvrow = dqkv + trow(key) * C3 + voff;
+            for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-        for (int u = 0; u < DP / 32; ++u) {
-            if (BF && (d & 1) == 0) {
+                for (int which = 0; which < 2; ++which) {  // 0: dK, 1: dV
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int e = 32 * u + rho(r) + 4 * hh;
-                    if (e < d) {
-                        float v0 = dVacc[kt][u][r], v1 = dVacc[kt][u][r + 1];
-                        if (delta_in != nullptr) {  // add the LePE share of dV left there by the pre-pass
-                            const uint32_t old = *reinterpret_cast<const uint32_t *>(dvrow + e);
-                            v0 += __uint_as_float(old << 16);
-                            v1 += __uint_as_float(old & 0xffff0000u);
+                    for (int u = 0; u < DP / 32; ++u) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = which == 0 ? dKacc[kt][u][4 * g4 + j] * LN2 : dVacc[kt][u][4 * g4 + j];
+                            *reinterpret_cast<uint2 *>(slice + l31 * QS + 32 * u + 8 * g4 + 4 * hh) =
+                                make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
                         }
-                        *reinterpret_cast<uint32_t *>(dkrow + e) = pack_bf16(dKacc[kt][u][r] * LN2, dKacc[kt][u][r + 1] * LN2);
-                        *reinterpret_cast<uint32_t *>(dvrow + e) = pack_bf16(v0, v1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 32 / RPI; ++i) {
+                        const int row = i * RPI + rsub;
+                        uint32_t v = *reinterpret_cast<const uint32_t *>(slice + row * QS + 2 * dw);
+                        if (2 * dw < d) {
+                            T *dst = dqkv + trow(32 * (wave * KT + kt) + row) * C3 + (which == 0 ? koff : voff) + 2 * dw;
+                            if (which == 1 && delta_in != nullptr) {  // add the LePE share of dV left there by the pre-pass
+                                const uint32_t old = *reinterpret_cast<const uint32_t *>(dst);
+                                v = pack_bf16(__uint_as_float(v << 16) + __uint_as_float(old << 16),
+                                              __uint_as_float(v & 0xffff0000u) + __uint_as_float(old & 0xffff0000u));
+                            }
+                            *reinterpret_cast<uint32_t *>(dst) = v;
+                        }
                     }
                 }
-            } else {
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int key = 32 * (wave * KT + kt) + l31;
+            T *dkrow = dqkv + trow(key) * C3 + koff;
+            T *dvrow = dqkv + trow(key) * C3 + voff;
+#pragma unroll
+            for (int u = 0; u < DP / 32; ++u) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int e = 32 * u + rho(r) + 4 * hh;

@@ -6,6 +6,7 @@ namespace dsw {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -60,6 +61,22 @@ template <> struct lds_traits<bf16_t> { static constexpr int RPAD = 8; };
 template <> struct lds_traits<float> { static constexpr int RPAD = 4; };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory
+// counter, which would stall on global loads that are deliberately left in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+}
+
+// ds_read_b64_tr_b16: within each group of 16 lanes, lane 4q+p passes the address of 4 consecutive
+// 16-bit elements (columns 4p..4p+3) of row q of a 4 x 16 block; lane i receives column i of the
+// block, rows 0..3 in elements 0..3.  Addresses must be 8-byte aligned and EXEC all ones.
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(const void *p) {
+    const i16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4 *)p);
+    return __builtin_bit_cast(uint2, v);
+}
 
 // relative-position table in LDS: [(2w-1)][TS] with TS = 3w, which makes the per-lane lookups of
 // one wave-instruction fall on distinct banks (w = 16: two runs of 16 that are 48 apart; w = 8:

@@ -2,8 +2,9 @@
 // (window, head) per workgroup, on the gfx950 matrix cores.
 // Reference: DSwinT_arch.py:122-125, :135-172, :303-308, :333-337; msft_arch.py:94-139.
 //
-// Structure.  The window's Q, K (row-major) and V (transposed) head slices are staged once in
-// LDS, zero-padded from the head dim d to DP.  Each wave owns 32-query blocks.  For a block it
+// Structure.  The window's Q, K and V head slices are staged once in LDS (row-major; V is
+// transposed for f32 and read with the transposing LDS load for bf16), zero-padded from the head
+// dim d to DP.  Each wave owns 32-query blocks.  For a block it
 // computes S^T = K Q^T for ALL keys of the window (32x32 MFMA tiles: key = row = register,
 // query = column = lane), so a softmax row lives in one lane pair (l, l+32): max and sum are
 // register reductions plus one cross-half exchange, and the bias lookup is one LDS read per
@@ -13,6 +14,9 @@
 // bf16 inputs use v_mfma_f32_32x32x16_bf16, f32 inputs the exact-f32 v_mfma_f32_32x32x2_f32.
 #include "attn_common.hpp"
 
+#ifndef DSW_ABL
+#define DSW_ABL 0
+#endif
 #pragma clang fp contract(fast)
 
 namespace dsw {
@@ -20,14 +24,17 @@ namespace dsw {
 template <typename T, int WS, int DP> struct FwdCfg {
     static constexpr int L = WS * WS;
     static constexpr int NT = L / 32;               // key tiles = query blocks
-    static constexpr int NW = NT < 4 ? NT : 4;      // waves per workgroup
+    static constexpr bool WIDE = WS == 16 && DP == 32 && sizeof(T) == 2;  // one wave per query block
+    static constexpr int NW = WIDE ? 8 : (NT < 4 ? NT : 4);               // waves per workgroup
     static constexpr int THREADS = NW * 64;
     static constexpr int QS = DP + lds_traits<T>::RPAD;  // row-major stride (elements)
     static constexpr int VS = L + 4;                      // transposed stride (elements)
     // two workgroups per CU wherever the LDS footprint allows it
-    static constexpr int MIN_WAVES = (WS == 16 && (DP == 64 || sizeof(T) == 4)) ? 1 : 2;
+    static constexpr int MIN_WAVES = WIDE ? 4 : (WS == 16 && (DP == 64 || sizeof(T) == 4)) ? 1 : 2;
+    static constexpr int TP = WIDE ? 2 : (NT < 4 ? NT : 4);  // key tiles per softmax pass
+    static constexpr int N_V = sizeof(T) == 2 ? L * QS : DP * VS;  // bf16: V row-major; f32: V^T
     static constexpr size_t lds_bytes(bool bias) {
-        return (size_t)(2 * L * QS + DP * VS) * sizeof(T) + (bias ? bias_lds<WS>::FLOATS * sizeof(float) : 0);
+        return (size_t)(2 * L * QS + N_V) * sizeof(T) + (bias ? bias_lds<WS>::FLOATS * sizeof(float) : 0);
     }
 };
 
@@ -38,14 +45,14 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
     float *__restrict__ lse) {
     using Cfg = FwdCfg<T, WS, DP>;
     constexpr int L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, THREADS = Cfg::THREADS, QS = Cfg::QS, VS = Cfg::VS;
-    constexpr int TS = bias_lds<WS>::TS;
+    constexpr int TS = bias_lds<WS>::TS, TMAX = (2 * WS - 2) * (TS + 1);
     constexpr bool BF = sizeof(T) == 2;
-    constexpr int TP = NT < 4 ? NT : 4, NPASS = NT / TP;  // key tiles per softmax pass
+    constexpr int TP = Cfg::TP, NPASS = NT / TP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *Qs = reinterpret_cast<T *>(smem);
     T *Ks = Qs + L * QS;
-    T *Vt = Ks + L * QS;
-    float *tb = reinterpret_cast<float *>(Vt + DP * VS);
+    T *Vt = Ks + L * QS;  // bf16: V [L][QS] row-major;  f32: V^T [DP][VS]
+    float *tb = reinterpret_cast<float *>(Vt + Cfg::N_V);
 
     const int tid = threadIdx.x;
     const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
@@ -67,8 +74,8 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
         pitch = g.W;
     }
 
-    // ---- stage Q (times scale*log2(e)), K (row-major) and V (transposed) ----------------------
-    // When d < DP the first padding row of V^T is set to ones: row d of O^T = V^T P^T is then the
+    // ---- stage Q (times scale*log2(e)), K and V ---------------------------------------------------
+    // When d < DP the first padding column of V is set to ones: row d of O^T = V^T P^T is then the
     // softmax denominator, computed by the matrix core instead of 256 VALU adds per lane.
     // Loads are issued in batches of 8 per thread before any of them is consumed: a loop that
     // loads and stores one item per trip pays a full memory round trip per trip.
@@ -76,29 +83,35 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
     auto rowbase = [&](int row) -> size_t { return (origin + (size_t)(row / WS) * pitch + (row % WS)) * C3; };
     if constexpr (BF) {
         if ((d & 1) == 0) {
-            constexpr int DW = DP / 2, ITER = L * DW / THREADS, BATCH = ITER < 8 ? ITER : 8;
+            // a thread keeps one element pair and one window column; a sweep of all threads covers
+            // RS = THREADS / (DP/2) consecutive tokens (a whole or half window row)
+            constexpr int DW = DP / 2, RS = THREADS / DW, ITER = L / RS, BATCH = ITER < 8 ? ITER : 8;
+            const int r0 = tid / DW, e = (tid - r0 * DW) * 2;
+            const bool ok = e < d;
+            const T *src0 = qkv + origin * C3 + min(e, d - 2);  // clamped: padding lanes re-read a valid pair
+            T *qdst = Qs + r0 * QS + e, *kdst = Ks + r0 * QS + e, *vdst = Vt + r0 * QS + e;
+            const uint32_t vpad = e == d ? 0x3f80u : 0u;  // bf16 1.0 in the low half
             for (int i0 = 0; i0 < ITER; i0 += BATCH) {
                 uint32_t qv[BATCH], kv[BATCH], vv[BATCH];
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
-                    const int it = tid + (i0 + i) * THREADS;
-                    const int row = it / DW, e = (it - row * DW) * 2;
-                    const T *src = qkv + rowbase(row) + min(e, d - 2);  // clamped: padding lanes re-read a valid pair
+                    const int tok = (i0 + i) * RS + r0;
+                    const T *src = src0 + ((size_t)(tok / WS) * pitch + (tok % WS)) * C3;
+#if DSW_ABL == 2
+                    qv[i] = tok * 77u + qoff; kv[i] = tok * 13u + e; vv[i] = tok + koff; (void)src;
+#else
                     qv[i] = *reinterpret_cast<const uint32_t *>(src + qoff);
                     kv[i] = *reinterpret_cast<const uint32_t *>(src + koff);
                     vv[i] = *reinterpret_cast<const uint32_t *>(src + voff);
+#endif
                 }
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
-                    const int it = tid + (i0 + i) * THREADS;
-                    const int row = it / DW, e = (it - row * DW) * 2;
-                    const bool ok = e < d;
+                    const int o = (i0 + i) * RS * QS;
                     const uint32_t q2 = pack_bf16(__uint_as_float(qv[i] << 16) * sc2, __uint_as_float(qv[i] & 0xffff0000u) * sc2);
-                    const uint32_t v2 = ok ? vv[i] : (e == d ? 0x3f80u : 0u);  // bf16 1.0 in the low half
-                    *reinterpret_cast<uint32_t *>(Qs + row * QS + e) = ok ? q2 : 0u;
-                    *reinterpret_cast<uint32_t *>(Ks + row * QS + e) = ok ? kv[i] : 0u;
-                    Vt[e * VS + row] = (T)(v2 & 0xffffu);
-                    Vt[(e + 1) * VS + row] = (T)(v2 >> 16);
+                    *reinterpret_cast<uint32_t *>(qdst + o) = ok ? q2 : 0u;
+                    *reinterpret_cast<uint32_t *>(kdst + o) = ok ? kv[i] : 0u;
+                    *reinterpret_cast<uint32_t *>(vdst + o) = ok ? vv[i] : vpad;
                 }
             }
         } else {
@@ -113,7 +126,7 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
                 }
                 Qs[row * QS + e] = qv;
                 Ks[row * QS + e] = kv;
-                Vt[e * VS + row] = vv;
+                Vt[row * QS + e] = vv;
             }
         }
     } else {
@@ -144,14 +157,21 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
         constexpr int R = bias_lds<WS>::ROWS;
         for (int it = tid; it < R * R; it += THREADS) {
             const int di = it / R, dj = it - di * R;
-            tb[di * TS + dj] = table[(size_t)it * g.heads + head] * LOG2E;
+            tb[TMAX - (di * TS + dj)] = table[(size_t)it * g.heads + head] * LOG2E;  // mirrored, see lane_base
         }
     }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const bool ones_row = d < DP;  // uniform
+    // transposing reads of V: lane 4q+p of a 16-lane group points at key row 4hh + q, head-dim
+    // columns 16*(group & 1) + 4p.. of the 4-key x 16-column block the group receives
+    const T *vtr = Vt + (4 * hh + ((lane >> 2) & 3)) * QS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
+#if DSW_ABL == 1
+    if (tid == 0) out[(origin) * C + head * d] = Qs[5];
+    return;
+#endif
     for (int qb = wave; qb < NT; qb += NW) {
         const int q = qb * 32 + l31;
         const int qi = q / WS, qj = q - qi * WS;
@@ -172,9 +192,11 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[u][r] = 0.f;
         // element (t, r) of this lane is key 32t + rho(r) + 4hh; its table entry is
-        // (qi - ki + w-1)*TS + (qj - kj + w-1) = lane_base - (ki_c*TS + kj_c), with ki_c, kj_c the
-        // compile-time part of the key coordinates
-        const int lane_base = qi * TS + qj + (WS - 1) * (TS + 1) - 4 * hh;
+        // (qi - ki + w-1)*TS + (qj - kj + w-1) = E - (ki_c*TS + kj_c), with ki_c, kj_c the compile-time
+        // part of the key coordinates.  The table is stored mirrored (entry e at TMAX - e), so the
+        // four consecutive keys of registers 4g..4g+3 are four ascending words: paired reads land
+        // directly in the accumulator registers.
+        const int lane_base = TMAX - (qi * TS + qj + (WS - 1) * (TS + 1) - 4 * hh);
         float mx = -INFINITY, sum = 0.f;
 
         // The keys are walked in passes of TP tiles (128 keys) with an online softmax across passes,
@@ -188,7 +210,7 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key_c = 32 * (pass * TP + tt) + rho(r);
-                    if constexpr (BIAS) sacc[tt][r] = tb[lane_base - ((key_c / WS) * TS + (key_c % WS))];
+                    if constexpr (BIAS) sacc[tt][r] = tb[lane_base + ((key_c / WS) * TS + (key_c % WS))];
                     else sacc[tt][r] = 0.f;
                 }
             }
@@ -219,7 +241,11 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
             for (int tt = 0; tt < TP; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pm = fmaxf(pm, sacc[tt][r]);
+#if DSW_ABL == 5
+            pm = 0.f;
+#else
             pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+#endif
             if (pass > 0) {
                 const float alpha = __builtin_amdgcn_exp2f(mx - pm);
                 sum *= alpha;
@@ -234,7 +260,16 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
             for (int tt = 0; tt < TP; ++tt) {
                 const int t = pass * TP + tt;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[tt][r] = __builtin_amdgcn_exp2f(sacc[tt][r] - mx);
+                for (int r = 0; r < 16; r += 2) {  // packed subtract: two elements per instruction
+                    const f32x2 sh = f32x2{sacc[tt][r], sacc[tt][r + 1]} - f32x2{mx, mx};
+#if DSW_ABL == 3
+                    sacc[tt][r] = sh.x * 0.001f;
+                    sacc[tt][r + 1] = sh.y * 0.001f;
+#else
+                    sacc[tt][r] = __builtin_amdgcn_exp2f(sh.x);
+                    sacc[tt][r + 1] = __builtin_amdgcn_exp2f(sh.y);
+#endif
+                }
                 if (!ones_row) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sum += sacc[tt][r];
@@ -248,9 +283,11 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
                                                     pack_bf16(sacc[tt][8 * s + 6], sacc[tt][8 * s + 7]));
 #pragma unroll
                         for (int u = 0; u < DP / 32; ++u) {
-                            const T *vrow = Vt + (32 * u + l31) * VS + 32 * t + 16 * s + 4 * hh;
-                            const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
-                            const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 8);
+                            // A operand = V^T (row = head dim 32u + l31): element j of this lane is key
+                            // 32t + 16s + 8(j>>2) + 4hh + (j&3), fetched as two transposing reads of V
+                            const T *vblk = vtr + (32 * t + 16 * s) * QS + 32 * u;
+                            const uint2 lo = lds_read_tr16(vblk);
+                            const uint2 hi = lds_read_tr16(vblk + 8 * QS);
                             const uint4 va = make_uint4(lo.x, lo.y, hi.x, hi.y);
                             oacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(va), as_bf16x8(pb), oacc[u], 0, 0, 0);
                         }
@@ -284,6 +321,9 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
 
         // ---- epilogue: normalise, LePE, store (lane = query row, registers = head-dim) -------------
         T *orow = out + (origin + (size_t)qi * pitch + qj) * C + head * d;
+#if DSW_ABL == 4
+        if (inv != 12345.f) continue;
+#endif
 #pragma unroll
         for (int u = 0; u < DP / 32; ++u) {
             float o[16];
@@ -301,7 +341,7 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
                             for (int bb = -1; bb <= 1; ++bb) {
                                 const int ni = qi + a, nj = qj + bb;
                                 if (ni >= 0 && ni < WS && nj >= 0 && nj < WS)
-                                    acc += lepe_w[c * 9 + (a + 1) * 3 + (bb + 1)] * io<T>::ld(Vt + dd * VS + ni * WS + nj);
+                                    acc += lepe_w[c * 9 + (a + 1) * 3 + (bb + 1)] * io<T>::ld(BF ? Vt + (ni * WS + nj) * QS + dd : Vt + dd * VS + ni * WS + nj);
                             }
                         }
                         v += acc;
@@ -311,11 +351,12 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
             }
             if constexpr (BF) {
                 if ((d & 1) == 0) {
+                    // through the block's own (spent) Q rows in LDS, so that the global stores below
+                    // are runs of whole output rows instead of one dword in each of 32 rows
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int dd = 32 * u + rho(r) + 4 * hh;
-                        if (dd < d) *reinterpret_cast<uint32_t *>(orow + dd) = pack_bf16(o[r], o[r + 1]);
-                    }
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<uint2 *>(Qs + q * QS + 32 * u + 8 * g4 + 4 * hh) =
+                            make_uint2(pack_bf16(o[4 * g4], o[4 * g4 + 1]), pack_bf16(o[4 * g4 + 2], o[4 * g4 + 3]));
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -328,6 +369,20 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
                 for (int r = 0; r < 16; ++r) {
                     const int dd = 32 * u + rho(r) + 4 * hh;
                     if (dd < d) io<T>::st(orow + dd, o[r]);
+                }
+            }
+        }
+        if constexpr (BF) {
+            if ((d & 1) == 0) {
+                // a wave's LDS accesses complete in order, and only this wave touches these rows
+                constexpr int DWR = DP / 2, RPI = 64 / DWR;  // dwords per row, rows per store instruction
+                const int dw = lane % DWR, rsub = lane / DWR;
+#pragma unroll
+                for (int i = 0; i < 32 / RPI; ++i) {
+                    const int qq = qb * 32 + i * RPI + rsub;
+                    const uint32_t v = *reinterpret_cast<const uint32_t *>(Qs + qq * QS + 2 * dw);
+                    if (2 * dw < d)
+                        *reinterpret_cast<uint32_t *>(out + (origin + (size_t)(qq / WS) * pitch + (qq % WS)) * C + head * d + 2 * dw) = v;
                 }
             }
         }
