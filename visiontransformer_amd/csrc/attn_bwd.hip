@@ -2,52 +2,55 @@
 // (window, head) per workgroup, on the gfx950 matrix cores.
 // Reference ops differentiated: DSwinT_arch.py:122-125, :171-172; msft_arch.py:113-136.
 //
-// Structure.  Each wave owns 32-key tiles of the window and keeps dK^T and dV^T of those keys
+// Structure.  Each wave owns one 32-key tile of the window and keeps dK^T and dV^T of those keys
 // in accumulators for the whole sweep, with its K and V fragments in registers.  The workgroup
-// walks the window's 32-query blocks; a block's Q and dO rows are staged in LDS (row-major, and
-// transposed for the bf16 operand reads).  With the KEY on the MFMA lane, S = Q K^T and
-// dP = dO V^T come out as (query = row = register, key = column = lane), which is already the
-// B operand of dV^T += dO^T P and dK^T += Q^T dS (they sum over the accumulator's row index).
-// Only dS crosses LDS, once per block, for dQ = dS K (16x16 output tiles, one per wave, summed
-// over all keys - no cross-wave reduction).  P is recomputed from the forward's log-sum-exp;
-// delta = rowsum(dO * O) comes from the saved output.  The bias-table gradient is accumulated
-// with LDS float adds into one private table per wave (program order inside a wave => bitwise
-// reproducible), summed in wave order and written as a per-(window, head) partial that a second
-// kernel reduces over windows in a fixed order.
+// walks the window's 32-query blocks; a block's Q and dO rows are staged in LDS (row-major; the
+// transposed operands of the bf16 path come from transposing LDS reads).  With the KEY on the MFMA
+// lane, S = Q K^T and dP = dO V^T come out as (query = row = register, key = column = lane), which is
+// already the B operand of dV^T += dO^T P and dK^T += Q^T dS (they sum over the accumulator's row
+// index).  Only dS crosses LDS, once per block, for dQ = dS K (16x16 output tiles spread over the
+// waves; when there are more waves than tiles the key range of a tile is split over two waves and
+// the halves meet in LDS one barrier later).  P is recomputed from the forward's log-sum-exp;
+// delta = rowsum(dO * O) comes from the saved output.  The bias-table gradient is accumulated in
+// registers along the table's diagonals and added into one private LDS table per wave (program
+// order inside a wave => bitwise reproducible), summed in wave order and written as a
+// per-(window, head) partial that a second kernel reduces over windows in a fixed order.
 #include <utility>
 
 #include "attn_common.hpp"
 
-#ifndef DSW_ABL
-#define DSW_ABL 0
-#endif
 #pragma clang fp contract(fast)
 
 namespace dsw {
+
+constexpr int BGW_STRIDE = 32, BGW_ROWS = 17;  // per-wave bias-gradient table (w = 16): [qi - kip + 1][dj + 15]
 
 template <typename T, int WS, int DP> struct BwdCfg {
     static constexpr bool BF = sizeof(T) == 2;
     static constexpr int L = WS * WS;
     static constexpr int NT = L / 32;                 // key tiles = query blocks
-    static constexpr int NW = NT < 4 ? NT : 4;        // waves
-    static constexpr int KT = NT / NW;                // key tiles per wave
+    static constexpr int NW = NT;                     // waves: one key tile each
     static constexpr int THREADS = NW * 64;
-    static constexpr int QS = DP + lds_traits<T>::RPAD;  // row-major stride of Qb / dOb / Ks
-    static constexpr int TQS = 32 + 4;                    // stride of the transposed block tiles (bf16)
-    static constexpr int KTS = L + 8;                     // stride of Kt (bf16) [DP][L]
-    static constexpr int SS = BF ? L + 8 : L + 4;         // stride of the dS block [32][L]
+    static constexpr int QS = DP + lds_traits<T>::RPAD;  // row-major stride of Qb / dOb (and K, f32)
+    static constexpr int KTS = L + 8;                     // stride of K^T (bf16) [DP][L]
+    static constexpr int DSS = 48;                        // stride of the bf16 dS^T image [L keys][32 queries]
+    static constexpr int SS = L + 4;                      // stride of the f32 dS block [32][L]
     static constexpr int QTILES = (32 / 16) * (DP / 16);  // 16x16 dQ tiles per block
-    static constexpr int QT_PER_WAVE = QTILES / NW;
+    static constexpr int KSPLIT = NW > QTILES ? NW / QTILES : 1;  // waves sharing one dQ tile (key halves)
+    static constexpr int QT_PER_WAVE = NW >= QTILES ? 1 : QTILES / NW;
+    static_assert(KSPLIT <= 2, "a dQ tile is split over at most two waves");
     // element counts (in T) of the LDS regions
     static constexpr int N_K = BF ? DP * KTS : L * QS;
-    static constexpr int N_DS = 32 * SS;
+    static constexpr int N_DS0 = BF ? L * DSS : 32 * SS;
+    static constexpr int N_EPI = BF ? NW * 32 * QS : 0;  // the bf16 epilogue's per-wave row slices reuse the dS region
+    static constexpr int N_DS = N_DS0 > N_EPI ? N_DS0 : N_EPI;
     static constexpr int N_QB = 32 * QS;
-    static constexpr int N_QBT = BF ? DP * TQS : 0;
     static constexpr size_t lds_bytes(bool bias) {
-        return (size_t)(N_K + N_DS + 2 * N_QB + 2 * N_QBT) * sizeof(T) + (size_t)2 * L * sizeof(float) +
-               (bias ? (size_t)(bias_lds<WS>::FLOATS + (WS == 16 ? NW * 31 * 32 : 0)) * sizeof(float) : 0);
+        return (size_t)(N_K + N_DS + 2 * N_QB) * sizeof(T) + (size_t)2 * L * sizeof(float) +
+               (KSPLIT > 1 ? (size_t)QTILES * 64 * 4 * sizeof(float) : 0) +
+               (bias ? (size_t)(bias_lds<WS>::FLOATS + (WS == 16 ? NW * BGW_ROWS * BGW_STRIDE : 0)) * sizeof(float) : 0);
     }
-    static constexpr int MIN_WAVES = (BF && !(WS == 16 && DP == 64)) ? 2 : 1;
+    static constexpr int MIN_WAVES = (WS == 16 && BF && DP == 32) ? 4 : (WS == 16 ? 2 : 2);
 };
 
 // 8 consecutive bf16 (or DP/2 floats handled by the caller) of a global row, zero past d
@@ -69,16 +72,35 @@ __device__ __forceinline__ uint4 load_bf16x8_masked(const bf16_t *row, int e0, i
 
 // ---- d(bias table) for 16 x 16 windows: diagonal sums in registers ---------------------------------
 // In a dS tile (query = row = register, key = column = lane) the table entry of an element is
-// (di, dj) = (qi - ki, qj - kj).  Rotating each register's 16-lane rows by its qj puts every
+// (di, dj) = (qi - ki, qj - kj).  Rotating each register's 16-lane rows left by its qj puts every
 // element with the same dj in the same lane, so the 8 registers of one query row-group add up
-// element-wise; lanes whose rotation wrapped belong to dj + 16 and are kept apart by a 0/1 mask.
-template <int QJ_LO>  // rotate lane rows left by qj: lanes 0-31 hold qj = QJ_LO, lanes 32-63 qj = QJ_LO + 4
-__device__ __forceinline__ float rot_rows_by_qj(float x) {
+// element-wise; lanes whose rotation wrapped belong to dj + 16 and are kept apart by a lane mask.
+// Register R holds qj = QJ_LO(R) in lanes 0-31 and QJ_LO(R) + 4 in lanes 32-63: every register is
+// rotated by QJ_LO only (one DPP operand, the same for all four lane rows) and the upper half's
+// sums get their missing rotation by 4 once, at the end (rotations commute with the sums).
+template <int R>
+__device__ __forceinline__ void diag_step(const f32x16 &ds, const bool (&wrap)[8], float (&all)[2], float (&wrapped)[2]) {
+    constexpr int QJ_LO = (R & 3) + 8 * ((R >> 2) & 1), ROR = (16 - QJ_LO) & 15;
+    float y = ds[R];
+    if constexpr (ROR != 0) y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ds[R]), 0x120 + ROR, 0xF, 0xF, false));
+    all[R >> 3] += y;
+    wrapped[R >> 3] += wrap[R & 7] ? y : 0.f;  // the lane masks live in scalar registers
+}
+template <int... R>
+__device__ __forceinline__ void diag_sums(std::integer_sequence<int, R...>, const f32x16 &ds, const bool (&wrap)[8],
+                                          float (&all)[2], float (&wrapped)[2]) {
+    (diag_step<R>(ds, wrap, all, wrapped), ...);
+}
+// lanes 32-63: rotate the 16-lane rows left by 4 more; lanes 0-31 unchanged
+__device__ __forceinline__ float upper_rows_rot4(float x) {
     const int xi = __float_as_int(x);
-    int y = xi;
-    if constexpr (((16 - QJ_LO) & 15) != 0) y = __builtin_amdgcn_update_dpp(y, xi, 0x120 + ((16 - QJ_LO) & 15), 0x3, 0xF, false);
-    if constexpr (((12 - QJ_LO) & 15) != 0) y = __builtin_amdgcn_update_dpp(y, xi, 0x120 + ((12 - QJ_LO) & 15), 0xC, 0xF, false);
-    return __int_as_float(y);
+    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x120 + 12, 0xC, 0xF, false));
+}
+// lanes 0-15 receive the value of lane + 16, lanes 32-47 that of lane + 16 (v_permlane16_swap)
+__device__ __forceinline__ float rows_odd_to_even(float x) {
+    const unsigned xi = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    return __uint_as_float(r[1]);
 }
 // lanes 0-31 receive the value of lane + 32 (v_permlane32_swap); lanes 32-63 are unspecified
 __device__ __forceinline__ float upper_half_to_lower(float x) {
@@ -86,41 +108,29 @@ __device__ __forceinline__ float upper_half_to_lower(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
     return __uint_as_float(r[1]);
 }
-template <int R>
-__device__ __forceinline__ void diag_step(const f32x16 &ds, const float (&wrapf)[8], float (&all)[2], float (&wrapped)[2]) {
-    constexpr int QJ_LO = (R & 3) + 8 * ((R >> 2) & 1);
-    const float y = rot_rows_by_qj<QJ_LO>(ds[R]);
-    all[R >> 3] += y;
-    wrapped[R >> 3] = fmaf(y, wrapf[R & 7], wrapped[R >> 3]);
-}
-template <int... R>
-__device__ __forceinline__ void diag_sums(std::integer_sequence<int, R...>, const f32x16 &ds, const float (&wrapf)[8],
-                                          float (&all)[2], float (&wrapped)[2]) {
-    (diag_step<R>(ds, wrapf, all, wrapped), ...);
-}
-constexpr int BGW_STRIDE = 32, BGW_FLOATS = 31 * 32;  // per-wave gradient table [di+15][dj+15], w = 16
 
-template <typename T, int WS, int DP, bool BIAS, bool LEPE>
+template <typename T, int WS, int DP, bool BIAS, bool PAIR>
 __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::MIN_WAVES)) void win_attn_bwd_kernel(
     AttnGeom g, const T *__restrict__ qkv, const T *__restrict__ out, const T *__restrict__ dout,
-    const float *__restrict__ table, float scale, const float *__restrict__ lepe_w,
-    const float *__restrict__ lepe_b, const float *__restrict__ lse, T *__restrict__ dqkv,
+    const float *__restrict__ table, float scale, const float *__restrict__ lse, T *__restrict__ dqkv,
     float *__restrict__ ws_table, const float *__restrict__ delta_in) {
     using Cfg = BwdCfg<T, WS, DP>;
     constexpr bool BF = Cfg::BF;
-    constexpr int L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, KT = Cfg::KT, THREADS = Cfg::THREADS;
-    constexpr int QS = Cfg::QS, TQS = Cfg::TQS, KTS = Cfg::KTS, SS = Cfg::SS;
+    static_assert(BF || !PAIR, "the pair path moves two bf16 per lane");
+    constexpr int L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, THREADS = Cfg::THREADS;
+    constexpr int QS = Cfg::QS, KTS = Cfg::KTS, DSS = Cfg::DSS, SS = Cfg::SS;
+    constexpr int QTILES = Cfg::QTILES, KSPLIT = Cfg::KSPLIT, QTW = Cfg::QT_PER_WAVE;
     constexpr int TS = bias_lds<WS>::TS, TBF = bias_lds<WS>::FLOATS, TR = bias_lds<WS>::ROWS;
+    constexpr int BGW_FLOATS = BGW_ROWS * BGW_STRIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *Kl = reinterpret_cast<T *>(smem);   // bf16: K^T [DP][KTS];  f32: K [L][QS]
-    T *dSs = Kl + Cfg::N_K;                // [32][SS]
+    T *dSs = Kl + Cfg::N_K;                // bf16: dS^T [L][DSS], 8-byte chunks swizzled;  f32: dS [32][SS]
     T *Qb = dSs + Cfg::N_DS;               // [32][QS]
     T *dOb = Qb + Cfg::N_QB;               // [32][QS]
-    T *Qbt = dOb + Cfg::N_QB;              // bf16 only: [DP][TQS]
-    T *dObt = Qbt + Cfg::N_QBT;            // bf16 only: [DP][TQS]
-    float *delta_s = reinterpret_cast<float *>(dObt + Cfg::N_QBT);  // [L]
-    float *lse_s = delta_s + L;                                     // [L], already times log2(e)
-    float *tb = lse_s + L;                                          // BIAS: [TBF]
+    float *ndelta_s = reinterpret_cast<float *>(dOb + Cfg::N_QB);  // [L]  -delta
+    float *nlse_s = ndelta_s + L;                                   // [L]  -lse * log2(e)
+    float *qpart = nlse_s + L;                                      // KSPLIT = 2: [QTILES][64] float4
+    float *tb = qpart + (KSPLIT > 1 ? QTILES * 64 * 4 : 0);         // BIAS: [TBF]
     float *bgw = tb + TBF;                                          // BIAS, w = 16: [NW][BGW_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -142,353 +152,352 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         pitch = g.W;
     }
     auto trow = [&](int l) -> size_t { return origin + (size_t)(l / WS) * pitch + (l % WS); };
-
-    // Loads are issued in batches before any of them is consumed (a load-use-per-trip loop pays a
-    // full memory round trip per trip); the "pair" path moves two bf16 per lane and needs an even
-    // head dim, the "element" path is the general one (f32, odd head dims).
-    constexpr int DW = DP / 2;
-    const bool pair_path = BF && ((d & 1) == 0);  // uniform
     const float sc2 = scale * LOG2E;
-    auto tof = [](T v) -> float {
-        if constexpr (BF) return bf16_to_f32(v);
-        else return v;
-    };
     auto bits = [](T v) -> uint32_t {
         if constexpr (BF) return (uint32_t)v;
         else return __float_as_uint(v);
     };
+    // staging geometry: a thread keeps one element (pair) column and a token row of each sweep of
+    // RS consecutive tokens; loads are issued in batches before any of them is consumed
+    constexpr int EPT = PAIR ? 2 : 1;             // elements per thread item
+    constexpr int DW = DP / EPT, RS = THREADS / DW;  // items per row, rows per sweep
+    const int r0 = tid / DW, e = (tid - r0 * DW) * EPT;
+    const int ec = min(e, d - EPT);               // clamped: padding lanes re-read valid data
+    const bool eok = e < d;
+    const size_t hd = (size_t)head * d;
 
-    // ---- prologue: K into LDS, delta = rowsum(dO * O), lse, bias tables -------------------------
-    if (pair_path) {
-        if constexpr (BF) {
-            constexpr int ITER = L * DW / THREADS, BATCH = ITER < 8 ? ITER : 8;
-            for (int i0 = 0; i0 < ITER; i0 += BATCH) {
-                uint32_t kv[BATCH], ov[BATCH], gv[BATCH];
+    // ---- prologue: K into LDS, -delta = -rowsum(dO * O), -lse, bias tables ------------------------
+    {
+        constexpr int ITER = L / RS, BATCH = ITER < 8 ? ITER : 8;
+        for (int i0 = 0; i0 < ITER; i0 += BATCH) {
+            uint32_t kv[BATCH], ov[BATCH], gv[BATCH];
 #pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const int it = tid + (i0 + i) * THREADS;
-                    const int row = it / DW, ec = min((it - row * DW) * 2, d - 2);
-                    const size_t tr = trow(row);
+            for (int i = 0; i < BATCH; ++i) {
+                const size_t tr = trow((i0 + i) * RS + r0);
+                if constexpr (PAIR) {
                     kv[i] = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + koff + ec);
-                    ov[i] = *reinterpret_cast<const uint32_t *>(out + tr * C + head * d + ec);
-                    gv[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + head * d + ec);
+                    ov[i] = *reinterpret_cast<const uint32_t *>(out + tr * C + hd + ec);
+                    gv[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + hd + ec);
+                } else {
+                    kv[i] = bits(qkv[tr * C3 + koff + ec]);
+                    ov[i] = bits(out[tr * C + hd + ec]);
+                    gv[i] = bits(dout[tr * C + hd + ec]);
                 }
+            }
 #pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const int it = tid + (i0 + i) * THREADS;
-                    const int row = it / DW, e = (it - row * DW) * 2;
-                    const bool ok = e < d;
-                    const uint32_t k2 = ok ? kv[i] : 0u;
+            for (int i = 0; i < BATCH; ++i) {
+                const int row = (i0 + i) * RS + r0;
+                float part;
+                if constexpr (PAIR) {
+                    const uint32_t k2 = eok ? kv[i] : 0u;
                     Kl[e * KTS + row] = (T)(k2 & 0xffffu);
                     Kl[(e + 1) * KTS + row] = (T)(k2 >> 16);
-                    float part = ok ? __uint_as_float(ov[i] << 16) * __uint_as_float(gv[i] << 16) +
-                                          __uint_as_float(ov[i] & 0xffff0000u) * __uint_as_float(gv[i] & 0xffff0000u)
-                                    : 0.f;
-#pragma unroll
-                    for (int o = 1; o < DW; o <<= 1) part += __shfl_xor(part, o, 64);
-                    if (e == 0) delta_s[row] = part;
+                    part = eok ? __uint_as_float(ov[i] << 16) * __uint_as_float(gv[i] << 16) +
+                                     __uint_as_float(ov[i] & 0xffff0000u) * __uint_as_float(gv[i] & 0xffff0000u)
+                               : 0.f;
+                } else if constexpr (BF) {
+                    Kl[e * KTS + row] = eok ? (T)kv[i] : (T)0;
+                    part = eok ? bf16_to_f32((T)ov[i]) * bf16_to_f32((T)gv[i]) : 0.f;
+                } else {
+                    Kl[row * QS + e] = eok ? __uint_as_float(kv[i]) : 0.f;
+                    part = eok ? __uint_as_float(ov[i]) * __uint_as_float(gv[i]) : 0.f;
                 }
-            }
-        }
-    } else {
-        constexpr int ITER = L * DP / THREADS, BATCH = 8;
-        for (int i0 = 0; i0 < ITER; i0 += BATCH) {
-            T kv[BATCH], ov[BATCH], gv[BATCH];
 #pragma unroll
-            for (int i = 0; i < BATCH; ++i) {
-                const int it = tid + (i0 + i) * THREADS;
-                const int row = it / DP, ec = min(it - row * DP, d - 1);
-                const size_t tr = trow(row);
-                kv[i] = qkv[tr * C3 + koff + ec];
-                ov[i] = out[tr * C + head * d + ec];
-                gv[i] = dout[tr * C + head * d + ec];
-            }
-#pragma unroll
-            for (int i = 0; i < BATCH; ++i) {
-                const int it = tid + (i0 + i) * THREADS;
-                const int row = it / DP, e = it - row * DP;
-                const bool ok = e < d;
-                if constexpr (BF) Kl[e * KTS + row] = ok ? kv[i] : (T)0;
-                else Kl[row * QS + e] = ok ? kv[i] : (T)0;
-                float part = ok ? tof(ov[i]) * tof(gv[i]) : 0.f;
-#pragma unroll
-                for (int o = 1; o < DP; o <<= 1) part += __shfl_xor(part, o, 64);
-                if (e == 0) delta_s[row] = part;
+                for (int o = 1; o < DW; o <<= 1) part += __shfl_xor(part, o, 64);
+                if (e == 0) ndelta_s[row] = -part;
             }
         }
     }
-    for (int row = tid; row < L; row += THREADS) lse_s[row] = lse[((size_t)win * g.heads + head) * L + row] * LOG2E;
+    for (int row = tid; row < L; row += THREADS) nlse_s[row] = -lse[((size_t)win * g.heads + head) * L + row] * LOG2E;
     if (delta_in != nullptr) {
         // LePE: `out` holds SDPA + LePE, so rowsum(dO * O_sdpa) was computed by the LePE pre-pass
         __syncthreads();
-        for (int row = tid; row < L; row += THREADS) delta_s[row] = delta_in[((size_t)win * g.heads + head) * L + row];
+        for (int row = tid; row < L; row += THREADS) ndelta_s[row] = -delta_in[((size_t)win * g.heads + head) * L + row];
     }
     if constexpr (BIAS) {
         for (int it = tid; it < TR * TR; it += THREADS) {
             const int di = it / TR, dj = it - di * TR;
             tb[di * TS + dj] = table[(size_t)it * g.heads + head] * LOG2E;
         }
-        if constexpr (WS == 16) {
-            for (int it = tid; it < NW * BGW_FLOATS; it += THREADS) bgw[it] = 0.f;
-        }
     }
-    // 1.0 where rotating a register's lane row by its qj wrapped around (those elements belong
-    // to dj + 16); index = register & 7, whose qj is (j & 3) + 8 (j >> 2) + 4 hh
-    float wrapf[8];
+    // true where the full rotation of a register's lane row (by qj = QJ_LO + 4 hh) wraps around (those
+    // elements belong to dj + 16), seen after the partial rotation by QJ_LO = (j & 3) + 8 (j >> 2):
+    // lane m then holds kj = (m + QJ_LO) mod 16, and it wrapped if kj < qj.  Index = register & 7.
+    bool wrapf[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wrapf[j] = ((lane & 15) + (j & 3) + 8 * (j >> 2) + 4 * hh >= 16) ? 1.f : 0.f;
+    for (int j = 0; j < 8; ++j) {
+        const int qlo = (j & 3) + 8 * (j >> 2);
+        wrapf[j] = (((lane & 15) + qlo) & 15) < qlo + 4 * hh;
+    }
 
     // this wave's K and V fragments (B operands: k-dim = head dim, column = key on the lane)
-    uint4 kfb[BF ? KT : 1][DP / 16], vfb[BF ? KT : 1][DP / 16];
-    float kff[BF ? 1 : KT][BF ? 1 : DP / 2], vff[BF ? 1 : KT][BF ? 1 : DP / 2];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int key = 32 * (wave * KT + kt) + l31;
+    const int tile = wave;                    // key tile of this wave
+    const int key = 32 * tile + l31;
+    uint4 kfb[BF ? DP / 16 : 1], vfb[BF ? DP / 16 : 1];
+    float kff[BF ? 1 : DP / 2], vff[BF ? 1 : DP / 2];
+    {
         const T *krow = qkv + trow(key) * C3 + koff;
         const T *vrow = qkv + trow(key) * C3 + voff;
         if constexpr (BF) {
 #pragma unroll
             for (int s = 0; s < DP / 16; ++s) {
-                kfb[kt][s] = load_bf16x8_masked(krow, 16 * s + 8 * hh, d);
-                vfb[kt][s] = load_bf16x8_masked(vrow, 16 * s + 8 * hh, d);
+                kfb[s] = load_bf16x8_masked(krow, 16 * s + 8 * hh, d);
+                vfb[s] = load_bf16x8_masked(vrow, 16 * s + 8 * hh, d);
             }
         } else {
 #pragma unroll
             for (int s = 0; s < DP / 2; ++s) {
-                const int e = hh * (DP / 2) + s;
-                kff[kt][s] = (e < d) ? krow[e] : 0.f;
-                vff[kt][s] = (e < d) ? vrow[e] : 0.f;
+                const int ee = hh * (DP / 2) + s;
+                kff[s] = (ee < d) ? krow[ee] : 0.f;
+                vff[s] = (ee < d) ? vrow[ee] : 0.f;
             }
         }
     }
 
-    f32x16 dKacc[KT][DP / 32], dVacc[KT][DP / 32];
+    f32x16 dKacc[DP / 32], dVacc[DP / 32];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int u = 0; u < DP / 32; ++u)
 #pragma unroll
-        for (int u = 0; u < DP / 32; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dKacc[kt][u][r] = 0.f;
-                dVacc[kt][u][r] = 0.f;
-            }
+        for (int r = 0; r < 16; ++r) {
+            dKacc[u][r] = 0.f;
+            dVacc[u][r] = 0.f;
+        }
 
     // ---- the next block's Q and dO rows travel in registers while the current block computes ----
-    constexpr int NI_P = 32 * DW / THREADS, NI_E = 32 * DP / THREADS;
-    uint32_t nq[NI_E], ng[NI_E];
+    constexpr int NI = 32 / RS > 0 ? 32 / RS : 1;  // sweeps per 32-row block
+    static_assert(32 % RS == 0 || RS > 32, "block sweeps");
+    const bool stager = RS <= 32 || r0 < 32;       // with more than 32 rows per sweep only the first 32 take part
+    uint32_t nq[NI], ng[NI];
     auto load_block = [&](int qb) {
-        if (pair_path) {
+        if (!stager) return;
 #pragma unroll
-            for (int i = 0; i < NI_P; ++i) {
-                const int it = tid + i * THREADS;
-                const int row = it / DW, ec = min((it - row * DW) * 2, d - 2);
-                const size_t tr = trow(qb * 32 + row);
-#if DSW_ABL == 15
-                nq[i] = (uint32_t)tr * 77u + ec; ng[i] = (uint32_t)tr * 13u + ec;
-#else
+        for (int i = 0; i < NI; ++i) {
+            const size_t tr = trow(qb * 32 + i * RS + r0);
+            if constexpr (PAIR) {
                 nq[i] = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + qoff + ec);
-                ng[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + head * d + ec);
-#endif
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NI_E; ++i) {
-                const int it = tid + i * THREADS;
-                const int row = it / DP, ec = min(it - row * DP, d - 1);
-                const size_t tr = trow(qb * 32 + row);
+                ng[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + hd + ec);
+            } else {
                 nq[i] = bits(qkv[tr * C3 + qoff + ec]);
-                ng[i] = bits(dout[tr * C + head * d + ec]);
+                ng[i] = bits(dout[tr * C + hd + ec]);
             }
         }
     };
     // Q is stored times scale*log2(e): S comes out of the MFMA in the base-2 domain, and dK picks
     // up the inverse factor once, in the epilogue.
     auto store_block = [&]() {
-        if (pair_path) {
-            if constexpr (BF) {
+        if (!stager) return;
 #pragma unroll
-                for (int i = 0; i < NI_P; ++i) {
-                    const int it = tid + i * THREADS;
-                    const int row = it / DW, e = (it - row * DW) * 2;
-                    const bool ok = e < d;
-                    const uint32_t q2 = ok ? pack_bf16(__uint_as_float(nq[i] << 16) * sc2, __uint_as_float(nq[i] & 0xffff0000u) * sc2) : 0u;
-                    const uint32_t g2 = ok ? ng[i] : 0u;
-                    *reinterpret_cast<uint32_t *>(Qb + row * QS + e) = q2;
-                    *reinterpret_cast<uint32_t *>(dOb + row * QS + e) = g2;
-                    Qbt[e * TQS + row] = (T)(q2 & 0xffffu);
-                    Qbt[(e + 1) * TQS + row] = (T)(q2 >> 16);
-                    dObt[e * TQS + row] = (T)(g2 & 0xffffu);
-                    dObt[(e + 1) * TQS + row] = (T)(g2 >> 16);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NI_E; ++i) {
-                const int it = tid + i * THREADS;
-                const int row = it / DP, e = it - row * DP;
-                const bool ok = e < d;
-                if constexpr (BF) {
-                    const T qv = ok ? f32_to_bf16(bf16_to_f32((T)nq[i]) * sc2) : (T)0;
-                    const T gv = ok ? (T)ng[i] : (T)0;
-                    Qb[row * QS + e] = qv;
-                    dOb[row * QS + e] = gv;
-                    Qbt[e * TQS + row] = qv;
-                    dObt[e * TQS + row] = gv;
-                } else {
-                    Qb[row * QS + e] = ok ? __uint_as_float(nq[i]) * sc2 : 0.f;
-                    dOb[row * QS + e] = ok ? __uint_as_float(ng[i]) : 0.f;
-                }
+        for (int i = 0; i < NI; ++i) {
+            const int row = i * RS + r0;
+            if constexpr (PAIR) {
+                const uint32_t q2 = eok ? pack_bf16(__uint_as_float(nq[i] << 16) * sc2, __uint_as_float(nq[i] & 0xffff0000u) * sc2) : 0u;
+                *reinterpret_cast<uint32_t *>(Qb + row * QS + e) = q2;
+                *reinterpret_cast<uint32_t *>(dOb + row * QS + e) = eok ? ng[i] : 0u;
+            } else if constexpr (BF) {
+                Qb[row * QS + e] = eok ? f32_to_bf16(bf16_to_f32((T)nq[i]) * sc2) : (T)0;
+                dOb[row * QS + e] = eok ? (T)ng[i] : (T)0;
+            } else {
+                Qb[row * QS + e] = eok ? __uint_as_float(nq[i]) * sc2 : 0.f;
+                dOb[row * QS + e] = eok ? __uint_as_float(ng[i]) : 0.f;
             }
         }
     };
 
-    constexpr int BG_N = (2 * WS - 1 + 7) / 8;  // bias-gradient entries (di values) per thread
+    // lane geometry of the transposing reads (bf16): lane 4q+p of a 16-lane group passes row q, columns 4p..
+    const int trq = (lane >> 2) & 3, trp = lane & 3, trg = (lane >> 4) & 1;
+    const T *qtr = Qb + (4 * hh + trq) * QS + 16 * trg + 4 * trp;   // Q^T / dO^T operands: rows = queries
+    const T *gtr = dOb + (4 * hh + trq) * QS + 16 * trg + 4 * trp;
+    // dQ work unit of this wave: 16x16 tile(s) and key range
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int qtile0 = KSPLIT > 1 ? wave % QTILES : wave * QTW, khalf = KSPLIT > 1 ? wave / QTILES : 0;
+    constexpr int KEYS_PER_UNIT = L / KSPLIT;
+    f32x4 qkeep[QTW];  // KSPLIT = 2: the lower key half's partial dQ waits here for the upper half
+    auto finish_dq = [&](int qb, const f32x4(&qa)[QTW], bool add_partner) {
+#pragma unroll
+        for (int tq = 0; tq < QTW; ++tq) {
+            const int t16 = qtile0 + tq;
+            const int mq = t16 / (DP / 16), nd = t16 - mq * (DP / 16);
+            f32x4 v = qa[tq];
+            if constexpr (KSPLIT > 1) {
+                if (add_partner) {
+                    const float4 pp = *reinterpret_cast<const float4 *>(qpart + (t16 * 64 + lane) * 4);
+                    v[0] += pp.x, v[1] += pp.y, v[2] += pp.z, v[3] += pp.w;
+                }
+            }
+            // C layout: column (head dim) = lane & 15, row (query) = 4*(lane>>4) + reg
+            const int ee = 16 * nd + l15;
+            if (ee < d) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) io<T>::st(dqkv + trow(qb * 32 + 16 * mq + 4 * l4 + r) * C3 + qoff + ee, v[r] * scale);
+            }
+        }
+    };
+
+    constexpr int BG_N = (2 * WS - 1 + 7) / 8;  // w = 8: bias-gradient entries (di values) per thread
     float bgacc[BG_N];
 #pragma unroll
     for (int n = 0; n < BG_N; ++n) bgacc[n] = 0.f;
+    const int ki = key / WS, kj = key - ki * WS;
 
+    float bg_carry_a = 0.f, bg_carry_w = 0.f;  // w = 16 bias gradient: (G = 1, kip = 0) sums of the previous block
     load_block(0);
     for (int qb = 0; qb < NT; ++qb) {
         lds_barrier();  // previous block's LDS reads are done (first pass: prologue writes land)
+        if constexpr (KSPLIT > 1) {
+            if (qb > 0 && khalf == 0) finish_dq(qb - 1, qkeep, true);  // the upper key half's partial has landed
+        }
         store_block();
         lds_barrier();
         if (qb + 1 < NT) load_block(qb + 1);
 
+        // table entry of (q, key): (qi-ki+w-1)*TS + (qj-kj+w-1); q = qb*32 + rho(r) + 4hh
+        const int lane_base = (WS - 1) * (TS + 1) - ki * TS - kj + 4 * hh + (qb * 32 / WS) * TS;
+        // accumulators start from the row constants: S' = S*log2e + bias - lse, dP' = dP - delta
+        f32x16 sacc, pacc;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int tile = wave * KT + kt;
-            const int key = 32 * tile + l31;
-            // table entry of (q, key): (qi-ki+w-1)*TS + (qj-kj+w-1); q = qb*32 + rho(r) + 4hh
-            const int ki = key / WS, kj = key - ki * WS;
-            const int lane_base = (WS - 1) * (TS + 1) - ki * TS - kj + 4 * hh + (qb * 32 / WS) * TS;
-            // accumulators start from the row constants: S' = S*log2e + bias - lse, dP' = dP - delta
-            f32x16 sacc, pacc;
+        for (int r = 0; r < 16; ++r) {
+            const int q_c = rho(r);
+            float v0 = nlse_s[qb * 32 + q_c + 4 * hh];
+            if constexpr (BIAS) v0 += tb[lane_base + (q_c / WS) * TS + (q_c % WS)];
+            sacc[r] = v0;
+            pacc[r] = ndelta_s[qb * 32 + q_c + 4 * hh];
+        }
+        // ---- S = Q K^T and dP = dO V^T (rows = queries, lane = key) ---------------------------------
+        if constexpr (BF) {
+#pragma unroll
+            for (int s = 0; s < DP / 16; ++s) {
+                const uint4 qa = *reinterpret_cast<const uint4 *>(Qb + l31 * QS + 16 * s + 8 * hh);
+                const uint4 ga = *reinterpret_cast<const uint4 *>(dOb + l31 * QS + 16 * s + 8 * hh);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(qa), as_bf16x8(kfb[s]), sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ga), as_bf16x8(vfb[s]), pacc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < DP / 8; ++s4) {
+                const float4 qa = *reinterpret_cast<const float4 *>(Qb + l31 * QS + hh * (DP / 2) + 4 * s4);
+                const float4 ga = *reinterpret_cast<const float4 *>(dOb + l31 * QS + hh * (DP / 2) + 4 * s4);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kff[4 * s4 + 0], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kff[4 * s4 + 1], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kff[4 * s4 + 2], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kff[4 * s4 + 3], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vff[4 * s4 + 0], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.y, vff[4 * s4 + 1], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.z, vff[4 * s4 + 2], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vff[4 * s4 + 3], pacc, 0, 0, 0);
+            }
+        }
+        // ---- P = exp2(S'), dS = P * dP' ------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(sacc[r]);
+            const float ds = p * pacc[r];
+            sacc[r] = p;
+            pacc[r] = ds;
+        }
+        // ---- d(bias table), w = 16 ------------------------------------------------------------------------
+        if constexpr (BIAS && WS == 16) {
+            float all[2] = {0.f, 0.f}, wrapped[2] = {0.f, 0.f};
+            diag_sums(std::make_integer_sequence<int, 16>{}, pacc, wrapf, all, wrapped);
+#pragma unroll
+            for (int G = 0; G < 2; ++G) {  // lanes 0-31 += lanes 32-63 (one VALU swap, no LDS round trip)
+                all[G] = upper_rows_rot4(all[G]);
+                wrapped[G] = upper_rows_rot4(wrapped[G]);
+                all[G] += upper_half_to_lower(all[G]);
+                wrapped[G] += upper_half_to_lower(wrapped[G]);
+            }
+            // Lanes 0-15 now hold key row kip = 0, lanes 16-31 kip = 1 (m = lane & 15 is -dj, or 16 - dj for
+            // wrapped elements).  Row-group G of this block belongs to table row di = 2qb + G - kip - 2*tile,
+            // the wave's row 2qb + G - kip + 1: the odd row 2qb+1 gets (G=0, kip=0) + (G=1, kip=1) and is
+            // complete; the even row 2qb gets (G=0, kip=1) plus (G=1, kip=0) of the previous block, which
+            // is carried in a register.  Every entry of the wave's table is thus stored exactly once.
+            {
+                const float a0 = all[0] - wrapped[0], a1 = all[1] - wrapped[1];
+                const float a0k1 = rows_odd_to_even(a0), a1k1 = rows_odd_to_even(a1);
+                const float w0k1 = rows_odd_to_even(wrapped[0]), w1k1 = rows_odd_to_even(wrapped[1]);
+                if (lane < 16) {
+                    float *ent = bgw + wave * BGW_FLOATS + (2 * qb) * BGW_STRIDE + 15 - lane;
+                    ent[0] = a0k1 + bg_carry_a;              // row 2qb
+                    ent[16] = w0k1 + bg_carry_w;
+                    ent[BGW_STRIDE] = a0 + a1k1;             // row 2qb + 1
+                    ent[BGW_STRIDE + 16] = wrapped[0] + w1k1;
+                }
+                bg_carry_a = a1;
+                bg_carry_w = wrapped[1];
+            }
+        }
+        if constexpr (BF) {
+            // ---- dS^T to LDS for dQ, and dV^T += dO^T P, dK^T += Q^T dS (sum over the accumulator rows) --
+            // registers 4g..4g+3 are queries 8g + 4hh + 0..3 of this lane's key: one 8-byte chunk of the
+            // key's row; chunk c sits at position (c & 4) | ((c & 3) ^ ((key >> 2) & 3)), which keeps
+            // both these writes and the transposing reads below off each other's banks
+            T *dsrow = dSs + key * DSS;
+            const int fk = (l31 >> 2) & 3;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint4 pb = make_uint4(pack_bf16(sacc[8 * s + 0], sacc[8 * s + 1]), pack_bf16(sacc[8 * s + 2], sacc[8 * s + 3]),
+                                            pack_bf16(sacc[8 * s + 4], sacc[8 * s + 5]), pack_bf16(sacc[8 * s + 6], sacc[8 * s + 7]));
+                const uint4 db = make_uint4(pack_bf16(pacc[8 * s + 0], pacc[8 * s + 1]), pack_bf16(pacc[8 * s + 2], pacc[8 * s + 3]),
+                                            pack_bf16(pacc[8 * s + 4], pacc[8 * s + 5]), pack_bf16(pacc[8 * s + 6], pacc[8 * s + 7]));
+                {
+                    const int c0 = 4 * s + hh, c1 = 4 * s + 2 + hh;  // chunks of registers 8s..8s+3 and 8s+4..8s+7
+                    *reinterpret_cast<uint2 *>(dsrow + 4 * ((c0 & 4) | ((c0 & 3) ^ fk))) = make_uint2(db.x, db.y);
+                    *reinterpret_cast<uint2 *>(dsrow + 4 * ((c1 & 4) | ((c1 & 3) ^ fk))) = make_uint2(db.z, db.w);
+                }
+#pragma unroll
+                for (int u = 0; u < DP / 32; ++u) {
+                    // A operands dO^T, Q^T (row = head dim 32u + l31): element j is query
+                    // 16s + 8(j>>2) + 4hh + (j&3), fetched as two transposing reads of the row-major block
+                    const uint2 g0 = lds_read_tr16(gtr + (16 * s) * QS + 32 * u), g1 = lds_read_tr16(gtr + (16 * s + 8) * QS + 32 * u);
+                    const uint2 q0 = lds_read_tr16(qtr + (16 * s) * QS + 32 * u), q1 = lds_read_tr16(qtr + (16 * s + 8) * QS + 32 * u);
+                    dVacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(g0.x, g0.y, g1.x, g1.y)), as_bf16x8(pb), dVacc[u], 0, 0, 0);
+                    dKacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(q0.x, q0.y, q1.x, q1.y)), as_bf16x8(db), dKacc[u], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dSs[(rho(r) + 4 * hh) * SS + key] = pacc[r];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int q_c = rho(r);
-                // per-row constants of accumulator row r: query qb*32 + rho(r) + 4hh
-                float v0 = -lse_s[qb * 32 + q_c + 4 * hh];
-                if constexpr (BIAS) v0 += tb[lane_base + (q_c / WS) * TS + (q_c % WS)];
-                sacc[r] = v0;
-                pacc[r] = -delta_s[qb * 32 + q_c + 4 * hh];
-            }
-            // ---- S = Q K^T and dP = dO V^T (rows = queries, lane = key) ---------------------------
-            if constexpr (BF) {
 #pragma unroll
-                for (int s = 0; s < DP / 16; ++s) {
-                    const uint4 qa = *reinterpret_cast<const uint4 *>(Qb + l31 * QS + 16 * s + 8 * hh);
-                    const uint4 ga = *reinterpret_cast<const uint4 *>(dOb + l31 * QS + 16 * s + 8 * hh);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(qa), as_bf16x8(kfb[kt][s]), sacc, 0, 0, 0);
-                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ga), as_bf16x8(vfb[kt][s]), pacc, 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int s4 = 0; s4 < DP / 8; ++s4) {
-                    const float4 qa = *reinterpret_cast<const float4 *>(Qb + l31 * QS + hh * (DP / 2) + 4 * s4);
-                    const float4 ga = *reinterpret_cast<const float4 *>(dOb + l31 * QS + hh * (DP / 2) + 4 * s4);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kff[kt][4 * s4 + 0], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kff[kt][4 * s4 + 1], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kff[kt][4 * s4 + 2], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kff[kt][4 * s4 + 3], sacc, 0, 0, 0);
-                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vff[kt][4 * s4 + 0], pacc, 0, 0, 0);
-                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.y, vff[kt][4 * s4 + 1], pacc, 0, 0, 0);
-                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.z, vff[kt][4 * s4 + 2], pacc, 0, 0, 0);
-                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vff[kt][4 * s4 + 3], pacc, 0, 0, 0);
-                }
-            }
-            // ---- P = exp2(S'), dS = P * dP' ------------------------------------------------------------
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-#if DSW_ABL == 17
-                const float p = sacc[r] * 0.001f;
-#else
-                const float p = __builtin_amdgcn_exp2f(sacc[r]);
-#endif
-                const float ds = p * pacc[r];
-                sacc[r] = p;
-                pacc[r] = ds;
-            }
-            if constexpr (BIAS && WS == 16 && DSW_ABL != 13) {
-                float all[2] = {0.f, 0.f}, wrapped[2] = {0.f, 0.f};
-                diag_sums(std::make_integer_sequence<int, 16>{}, pacc, wrapf, all, wrapped);
-#pragma unroll
-                for (int G = 0; G < 2; ++G) {  // lanes 0-31 += lanes 32-63 (one VALU swap, no LDS round trip)
-                    all[G] += upper_half_to_lower(all[G]);
-                    wrapped[G] += upper_half_to_lower(wrapped[G]);
-                }
-                if (hh == 0) {
-                    // lane (kip, m): entries (di, -m) and, for wrapped elements, (di, 16 - m).  Plain
-                    // read-add-write on the wave's own table (no two lanes of one instruction share an
-                    // entry; LDS float atomics cost hundreds of cycles each on this chip)
-                    const int m = lane & 15, kip = (lane >> 4) & 1;
-                    float *tw = bgw + wave * BGW_FLOATS;
-#pragma unroll
-                    for (int G = 0; G < 2; ++G) {
-                        const int row = (2 * (qb - tile) + G - kip + 15) * BGW_STRIDE;
-                        tw[row + 15 - m] += all[G] - wrapped[G];
-                        if (m > 0) tw[row + 31 - m] += wrapped[G];
-                    }
-                }
-            }
-            // ---- dS block to LDS for dQ ---------------------------------------------------------------
-#pragma unroll
-            for (int r = 0; r < (DSW_ABL == 14 ? 0 : 16); ++r) {
-                if constexpr (BF) dSs[(rho(r) + 4 * hh) * SS + key] = f32_to_bf16(pacc[r]);
-                else dSs[(rho(r) + 4 * hh) * SS + key] = pacc[r];
-            }
-            // ---- dV^T += dO^T P,  dK^T += Q^T dS  (sum over the accumulator rows = queries) -----------
-            if constexpr (BF) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint4 pb = make_uint4(pack_bf16(sacc[8 * s + 0], sacc[8 * s + 1]), pack_bf16(sacc[8 * s + 2], sacc[8 * s + 3]),
-                                                pack_bf16(sacc[8 * s + 4], sacc[8 * s + 5]), pack_bf16(sacc[8 * s + 6], sacc[8 * s + 7]));
-                    const uint4 db = make_uint4(pack_bf16(pacc[8 * s + 0], pacc[8 * s + 1]), pack_bf16(pacc[8 * s + 2], pacc[8 * s + 3]),
-                                                pack_bf16(pacc[8 * s + 4], pacc[8 * s + 5]), pack_bf16(pacc[8 * s + 6], pacc[8 * s + 7]));
-#pragma unroll
-                    for (int u = 0; u < DP / 32; ++u) {
-                        const T *gr = dObt + (32 * u + l31) * TQS + 16 * s + 4 * hh;
-                        const T *qr = Qbt + (32 * u + l31) * TQS + 16 * s + 4 * hh;
-                        const uint2 g0 = *reinterpret_cast<const uint2 *>(gr), g1 = *reinterpret_cast<const uint2 *>(gr + 8);
-                        const uint2 q0 = *reinterpret_cast<const uint2 *>(qr), q1 = *reinterpret_cast<const uint2 *>(qr + 8);
-                        dVacc[kt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(g0.x, g0.y, g1.x, g1.y)), as_bf16x8(pb), dVacc[kt][u], 0, 0, 0);
-                        dKacc[kt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(q0.x, q0.y, q1.x, q1.y)), as_bf16x8(db), dKacc[kt][u], 0, 0, 0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-#pragma unroll
-                    for (int u = 0; u < DP / 32; ++u) {
-                        const float ga = dOb[(rho(r) + 4 * hh) * QS + 32 * u + l31];
-                        const float qa = Qb[(rho(r) + 4 * hh) * QS + 32 * u + l31];
-                        dVacc[kt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, sacc[r], dVacc[kt][u], 0, 0, 0);
-                        dKacc[kt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, pacc[r], dKacc[kt][u], 0, 0, 0);
-                    }
+                for (int u = 0; u < DP / 32; ++u) {
+                    const float ga = dOb[(rho(r) + 4 * hh) * QS + 32 * u + l31];
+                    const float qa = Qb[(rho(r) + 4 * hh) * QS + 32 * u + l31];
+                    dVacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, sacc[r], dVacc[u], 0, 0, 0);
+                    dKacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, pacc[r], dKacc[u], 0, 0, 0);
                 }
             }
         }
         lds_barrier();  // the whole dS block is in LDS
 
-        // ---- d(bias table): every thread owns a few table entries (di, dj) and sums the dS elements
-        // of this block that map to them, straight from the dS tile - a gather in a fixed order,
-        // so no atomics and bitwise reproducible.  Lanes that differ in dj read neighbouring keys.
+        // element (query q of the block, key k) of the dS image
+        auto ds_at = [&](int q, int k) -> float {
+            if constexpr (BF) {
+                const int c = q >> 2;
+                return bf16_to_f32(dSs[k * DSS + 4 * ((c & 4) | ((c & 3) ^ ((k >> 2) & 3))) + (q & 3)]);
+            } else {
+                return dSs[q * SS + k];
+            }
+        };
+        // ---- d(bias table), w = 8: every thread owns a few table entries (di, dj) and sums the dS
+        // elements of this block that map to them, straight from the dS image - a gather in a fixed
+        // order, so no atomics and bitwise reproducible.
         if constexpr (BIAS && WS != 16) {
             const int dj = (tid % (2 * WS)) - (WS - 1);   // lane WS*2-1 of each group is idle
-            const int dig = tid / (2 * WS);                // 8 groups of di values
+            const int dig = tid / (2 * WS);                // groups of di values
             if (dj < WS) {
 #pragma unroll
                 for (int n = 0; n < BG_N; ++n) {
-                    const int di = dig + 8 * n - (WS - 1);
+                    const int di = dig + (THREADS / (2 * WS)) * n - (WS - 1);
                     if (di < WS) {
                         float acc = 0.f;
 #pragma unroll
                         for (int qr = 0; qr < 32 / WS; ++qr) {
-                            const int ki = qb * (32 / WS) + qr - di;
-                            if (ki >= 0 && ki < WS) {
+                            const int ki2 = qb * (32 / WS) + qr - di;
+                            if (ki2 >= 0 && ki2 < WS) {
 #pragma unroll
                                 for (int qj = 0; qj < WS; ++qj) {
-                                    const int kj = qj - dj;
-                                    if (kj >= 0 && kj < WS) acc += tof(dSs[(qr * WS + qj) * SS + ki * WS + kj]);
+                                    const int kj2 = qj - dj;
+                                    if (kj2 >= 0 && kj2 < WS) acc += ds_at(qr * WS + qj, ki2 * WS + kj2);
                                 }
                             }
                         }
@@ -498,108 +507,110 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             }
         }
 
-        // ---- dQ block = dS K * scale: 16x16 output tiles, one (or more) per wave, K-dim = all keys ---
-#if DSW_ABL == 11
-        if (scale != 12345.f) continue;
-#endif
+        // ---- dQ block = dS K * scale: 16x16 output tiles, K-dim = this wave's key range ------------------
+        f32x4 qacc[QTW];
 #pragma unroll
-        for (int tq = 0; tq < Cfg::QT_PER_WAVE; ++tq) {
-            const int tile = wave * Cfg::QT_PER_WAVE + tq;
-            const int mq = tile / (DP / 16), nd = tile - mq * (DP / 16);
-            const int l15 = lane & 15, l4 = lane >> 4;
-            f32x4 qacc = {0.f, 0.f, 0.f, 0.f};
+        for (int tq = 0; tq < QTW; ++tq) {
+            const int t16 = qtile0 + tq;
+            const int mq = t16 / (DP / 16), nd = t16 - mq * (DP / 16);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if constexpr (BF) {
+                // k-slot j of lane group l4 in a 32-key step is key 4*l4 + (j&3) + 16*(j>>2): a half wave's
+                // two transposing reads then cover 8 consecutive key rows (conflict-free at DSS = 48)
+                const T *abase = dSs + (khalf * KEYS_PER_UNIT + 4 * l4 + trq) * DSS + 4 * (4 * mq + (trp ^ l4));
+                const T *bbase = Kl + (16 * nd + l15) * KTS + khalf * KEYS_PER_UNIT + 4 * l4;
 #pragma unroll 4
-                for (int s = 0; s < L / 32; ++s) {
-                    const uint4 a = *reinterpret_cast<const uint4 *>(dSs + (16 * mq + l15) * SS + 32 * s + 8 * l4);
-                    const uint4 b = *reinterpret_cast<const uint4 *>(Kl + (16 * nd + l15) * KTS + 32 * s + 8 * l4);
-                    qacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), qacc, 0, 0, 0);
+                for (int s = 0; s < KEYS_PER_UNIT / 32; ++s) {
+                    const uint2 a0 = lds_read_tr16(abase + (32 * s) * DSS), a1 = lds_read_tr16(abase + (32 * s + 16) * DSS);
+                    const uint2 b0 = *reinterpret_cast<const uint2 *>(bbase + 32 * s), b1 = *reinterpret_cast<const uint2 *>(bbase + 32 * s + 16);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(make_uint4(a0.x, a0.y, a1.x, a1.y)),
+                                                                  as_bf16x8(make_uint4(b0.x, b0.y, b1.x, b1.y)), acc, 0, 0, 0);
                 }
             } else {
 #pragma unroll 4
-                for (int s = 0; s < L / 4; ++s) {
-                    const float a = dSs[(16 * mq + l15) * SS + 4 * s + l4];
-                    const float b = Kl[(4 * s + l4) * QS + 16 * nd + l15];
-                    qacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, qacc, 0, 0, 0);
+                for (int s = 0; s < KEYS_PER_UNIT / 4; ++s) {
+                    const int k0 = khalf * KEYS_PER_UNIT + 4 * s + l4;
+                    const float a = dSs[(16 * mq + l15) * SS + k0];
+                    const float b = Kl[k0 * QS + 16 * nd + l15];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
                 }
             }
-            // C layout: column (head dim) = lane & 15, row (query) = 4*(lane>>4) + reg
-            const int e = 16 * nd + l15;
-#if DSW_ABL == 12
-            if (qacc[0] == 12345.f)
-#endif
-            if (e < d) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = qb * 32 + 16 * mq + 4 * l4 + r;
-                    io<T>::st(dqkv + trow(q) * C3 + qoff + e, qacc[r] * scale);
-                }
-            }
+            qacc[tq] = acc;
         }
+        if constexpr (KSPLIT > 1) {
+            if (khalf == 0) {
+#pragma unroll
+                for (int tq = 0; tq < QTW; ++tq) qkeep[tq] = qacc[tq];
+            } else {
+#pragma unroll
+                for (int tq = 0; tq < QTW; ++tq)
+                    *reinterpret_cast<float4 *>(qpart + ((qtile0 + tq) * 64 + lane) * 4) = make_float4(qacc[tq][0], qacc[tq][1], qacc[tq][2], qacc[tq][3]);
+            }
+        } else {
+            finish_dq(qb, qacc, false);
+        }
+    }
+    if constexpr (BIAS && WS == 16) {
+        if (lane < 16) {  // the last even row of the wave's table
+            float *ent = bgw + wave * BGW_FLOATS + (2 * NT) * BGW_STRIDE + 15 - lane;
+            ent[0] = bg_carry_a;
+            ent[16] = bg_carry_w;
+        }
+    }
+    __syncthreads();  // the last block's LDS reads are done, the upper halves' partials have landed
+    if constexpr (KSPLIT > 1) {
+        if (khalf == 0) finish_dq(NT - 1, qkeep, true);
     }
 
     // ---- epilogue: dK^T, dV^T (rows = head dim in registers, lane = key) ------------------------
-    if (pair_path) {
-        if constexpr (BF) {
-            // each wave turns its tiles into [key][head dim] rows in a private slice of the (now free)
-            // dS region, so that the global stores are runs of whole rows instead of one dword in each
-            // of 32 rows; a wave's LDS accesses complete in order and nobody else touches its slice
-            __syncthreads();
-#if DSW_ABL == 16
-            if (scale != 12345.f) return;
-#endif
-            T *slice = dSs + wave * (32 * QS);
-            constexpr int DWR = DP / 2, RPI = 64 / DWR;
-            const int dw = lane % DWR, rsub = lane / DWR;
+    if constexpr (PAIR) {
+        // each wave turns its tiles into [key][head dim] rows in a private slice of the (now free)
+        // dS region, so that the global stores are runs of whole rows instead of one dword in each
+        // of 32 rows; a wave's LDS accesses complete in order and nobody else touches its slice
+        T *slice = dSs + wave * (32 * QS);
+        constexpr int DWR = DP / 2, RPI = 64 / DWR;
+        const int dw = lane % DWR, rsub = lane / DWR;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
+        for (int which = 0; which < 2; ++which) {  // 0: dK, 1: dV
 #pragma unroll
-                for (int which = 0; which < 2; ++which) {  // 0: dK, 1: dV
+            for (int u = 0; u < DP / 32; ++u) {
 #pragma unroll
-                    for (int u = 0; u < DP / 32; ++u) {
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v[4];
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            float v[4];
+                    for (int j = 0; j < 4; ++j) v[j] = which == 0 ? dKacc[u][4 * g4 + j] * LN2 : dVacc[u][4 * g4 + j];
+                    *reinterpret_cast<uint2 *>(slice + l31 * QS + 32 * u + 8 * g4 + 4 * hh) =
+                        make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                }
+            }
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = which == 0 ? dKacc[kt][u][4 * g4 + j] * LN2 : dVacc[kt][u][4 * g4 + j];
-                            *reinterpret_cast<uint2 *>(slice + l31 * QS + 32 * u + 8 * g4 + 4 * hh) =
-                                make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-                        }
+            for (int i = 0; i < 32 / RPI; ++i) {
+                const int row = i * RPI + rsub;
+                uint32_t v = *reinterpret_cast<const uint32_t *>(slice + row * QS + 2 * dw);
+                if (2 * dw < d) {
+                    T *dst = dqkv + trow(32 * tile + row) * C3 + (which == 0 ? koff : voff) + 2 * dw;
+                    if (which == 1 && delta_in != nullptr) {  // add the LePE share of dV left there by the pre-pass
+                        const uint32_t old = *reinterpret_cast<const uint32_t *>(dst);
+                        v = pack_bf16(__uint_as_float(v << 16) + __uint_as_float(old << 16),
+                                      __uint_as_float(v & 0xffff0000u) + __uint_as_float(old & 0xffff0000u));
                     }
-#pragma unroll
-                    for (int i = 0; i < 32 / RPI; ++i) {
-                        const int row = i * RPI + rsub;
-                        uint32_t v = *reinterpret_cast<const uint32_t *>(slice + row * QS + 2 * dw);
-                        if (2 * dw < d) {
-                            T *dst = dqkv + trow(32 * (wave * KT + kt) + row) * C3 + (which == 0 ? koff : voff) + 2 * dw;
-                            if (which == 1 && delta_in != nullptr) {  // add the LePE share of dV left there by the pre-pass
-                                const uint32_t old = *reinterpret_cast<const uint32_t *>(dst);
-                                v = pack_bf16(__uint_as_float(v << 16) + __uint_as_float(old << 16),
-                                              __uint_as_float(v & 0xffff0000u) + __uint_as_float(old & 0xffff0000u));
-                            }
-                            *reinterpret_cast<uint32_t *>(dst) = v;
-                        }
-                    }
+                    *reinterpret_cast<uint32_t *>(dst) = v;
                 }
             }
         }
     } else {
+        T *dkrow = dqkv + trow(key) * C3 + koff;
+        T *dvrow = dqkv + trow(key) * C3 + voff;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int key = 32 * (wave * KT + kt) + l31;
-            T *dkrow = dqkv + trow(key) * C3 + koff;
-            T *dvrow = dqkv + trow(key) * C3 + voff;
+        for (int u = 0; u < DP / 32; ++u) {
 #pragma unroll
-            for (int u = 0; u < DP / 32; ++u) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int e = 32 * u + rho(r) + 4 * hh;
-                    if (e < d) {
-                        float v0 = dVacc[kt][u][r];
-                        if (delta_in != nullptr) v0 += io<T>::ld(dvrow + e);
-                        io<T>::st(dkrow + e, dKacc[kt][u][r] * LN2);
-                        io<T>::st(dvrow + e, v0);
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int ee = 32 * u + rho(r) + 4 * hh;
+                if (ee < d) {
+                    float v0 = dVacc[u][r];
+                    if (delta_in != nullptr) v0 += io<T>::ld(dvrow + ee);
+                    io<T>::st(dkrow + ee, dKacc[u][r] * LN2);
+                    io<T>::st(dvrow + ee, v0);
                 }
             }
         }
@@ -609,12 +620,15 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         // the table entered the logits times log2(e) inside exp2, so d/dtable is dS itself
         float *dst = ws_table + ((size_t)win * g.heads + head) * (TR * TR);
         if constexpr (WS == 16) {
-            __syncthreads();
+            // entry (di, dj): wave wv holds it in row di + 2*wv + 1 of its table when that row exists
             for (int it = tid; it < TR * TR; it += THREADS) {
-                const int di = it / TR, dj = it - di * TR;
+                const int di = it / TR - (WS - 1), dj = it - (it / TR) * TR;
                 float acc = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < NW; ++wv) acc += bgw[wv * BGW_FLOATS + di * BGW_STRIDE + dj];
+                for (int wv = 0; wv < NW; ++wv) {
+                    const int row = di + 2 * wv + 1;
+                    if (row >= 0 && row < BGW_ROWS) acc += bgw[wv * BGW_FLOATS + row * BGW_STRIDE + dj];
+                }
                 dst[it] = acc;
             }
         } else {
@@ -623,7 +637,7 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             if (dj < WS) {
 #pragma unroll
                 for (int n = 0; n < BG_N; ++n) {
-                    const int di = dig + 8 * n - (WS - 1);
+                    const int di = dig + (THREADS / (2 * WS)) * n - (WS - 1);
                     if (di < WS) dst[(di + WS - 1) * TR + dj + WS - 1] = bgacc[n];
                 }
             }
@@ -782,18 +796,27 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
         rc = check_launch("lepe_bwd_pre_kernel");
         if (rc) return rc;
     }
-#define DSW_BWD_LAUNCH(B_)                                                                                       \
+#define DSW_BWD_LAUNCH(B_, P_)                                                                                   \
     do {                                                                                                         \
-        auto kern = win_attn_bwd_kernel<T, WS, DP, B_, false>;                                                   \
+        auto kern = win_attn_bwd_kernel<T, WS, DP, B_, P_>;                                                      \
         if (lds > 48 * 1024) {                                                                                   \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); \
         }                                                                                                        \
         hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const T *)qkv, (const T *)out, (const T *)dout, table, \
-                           scale, lepe_w, lepe_b, lse, (T *)dqkv, ws_table, lepe ? ws_delta : (const float *)nullptr); \
+                           scale, lse, (T *)dqkv, ws_table, lepe ? ws_delta : (const float *)nullptr);          \
     } while (0)
-    if (bias) DSW_BWD_LAUNCH(true);
-    else DSW_BWD_LAUNCH(false);
+    constexpr bool BF16 = sizeof(T) == 2;
+    const bool pair = BF16 && (g.d % 2 == 0);
+    if constexpr (BF16) {
+        if (bias && pair) DSW_BWD_LAUNCH(true, true);
+        else if (bias) DSW_BWD_LAUNCH(true, false);
+        else if (pair) DSW_BWD_LAUNCH(false, true);
+        else DSW_BWD_LAUNCH(false, false);
+    } else {
+        if (bias) DSW_BWD_LAUNCH(true, false);
+        else DSW_BWD_LAUNCH(false, false);
+    }
 #undef DSW_BWD_LAUNCH
     rc = check_launch("win_attn_bwd_kernel");
     if (rc) return rc;

@@ -14,9 +14,6 @@
 // bf16 inputs use v_mfma_f32_32x32x16_bf16, f32 inputs the exact-f32 v_mfma_f32_32x32x2_f32.
 #include "attn_common.hpp"
 
-#ifndef DSW_ABL
-#define DSW_ABL 0
-#endif
 #pragma clang fp contract(fast)
 
 namespace dsw {
@@ -97,13 +94,9 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
                 for (int i = 0; i < BATCH; ++i) {
                     const int tok = (i0 + i) * RS + r0;
                     const T *src = src0 + ((size_t)(tok / WS) * pitch + (tok % WS)) * C3;
-#if DSW_ABL == 2
-                    qv[i] = tok * 77u + qoff; kv[i] = tok * 13u + e; vv[i] = tok + koff; (void)src;
-#else
                     qv[i] = *reinterpret_cast<const uint32_t *>(src + qoff);
                     kv[i] = *reinterpret_cast<const uint32_t *>(src + koff);
                     vv[i] = *reinterpret_cast<const uint32_t *>(src + voff);
-#endif
                 }
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
@@ -168,10 +161,6 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
     // columns 16*(group & 1) + 4p.. of the 4-key x 16-column block the group receives
     const T *vtr = Vt + (4 * hh + ((lane >> 2) & 3)) * QS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
-#if DSW_ABL == 1
-    if (tid == 0) out[(origin) * C + head * d] = Qs[5];
-    return;
-#endif
     for (int qb = wave; qb < NT; qb += NW) {
         const int q = qb * 32 + l31;
         const int qi = q / WS, qj = q - qi * WS;
@@ -241,11 +230,7 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
             for (int tt = 0; tt < TP; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pm = fmaxf(pm, sacc[tt][r]);
-#if DSW_ABL == 5
-            pm = 0.f;
-#else
             pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
-#endif
             if (pass > 0) {
                 const float alpha = __builtin_amdgcn_exp2f(mx - pm);
                 sum *= alpha;
@@ -262,13 +247,8 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {  // packed subtract: two elements per instruction
                     const f32x2 sh = f32x2{sacc[tt][r], sacc[tt][r + 1]} - f32x2{mx, mx};
-#if DSW_ABL == 3
-                    sacc[tt][r] = sh.x * 0.001f;
-                    sacc[tt][r + 1] = sh.y * 0.001f;
-#else
                     sacc[tt][r] = __builtin_amdgcn_exp2f(sh.x);
                     sacc[tt][r + 1] = __builtin_amdgcn_exp2f(sh.y);
-#endif
                 }
                 if (!ones_row) {
 #pragma unroll
@@ -321,9 +301,6 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
 
         // ---- epilogue: normalise, LePE, store (lane = query row, registers = head-dim) -------------
         T *orow = out + (origin + (size_t)qi * pitch + qj) * C + head * d;
-#if DSW_ABL == 4
-        if (inv != 12345.f) continue;
-#endif
 #pragma unroll
         for (int u = 0; u < DP / 32; ++u) {
             float o[16];
