@@ -218,6 +218,13 @@ int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x, int x_dty
                         int H, int W, int C, int w, void *dx, int dx_dtype, float *dw0, float *db0,
                         float *dw2, float *db2, float *dw4, float *db4, float *scratch, void *stream);
 
+/* Column sums of a row-major [rows][cols] matrix, out[c] = sum_r x[r][c] in fp32: the bias gradient of
+ * the path's Linear layers (torch.nn.Linear backward behind DSwinT_arch.py:188,190,325,327 and
+ * msft_arch.py:88,92), summed in a fixed order (bitwise reproducible).  cols % 4 == 0.
+ *   partial: caller scratch of dsw_colsum_blocks(rows) * cols floats. */
+int dsw_colsum_blocks(long long rows);
+int dsw_colsum(const void *x, int dtype, long long rows, int cols, float *out, float *partial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -312,3 +312,18 @@ def test_sparse_discriminator(cuda0, dtype, B, H, W, C, w):
     assert rel_err(xg.grad, xc.grad) < tol
     for k, p in convs.state_dict(keep_vars=True).items():
         assert rel_err(p.grad, P["sparse_discriminator." + k].grad) < tol, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(1, 4), (131, 180), (4096 + 77, 540), (1000, 2048)])
+def test_colsum(cuda0, rows, cols, dtype):
+    """Column sums (Linear bias gradients) against torch, and bitwise reproducible."""
+    from visiontransformer_amd import functional as K
+    g = torch.Generator(device=cuda0).manual_seed(rows * 7 + cols)
+    x = torch.randn(rows, cols, device=cuda0, generator=g).to(dtype)
+    got = K.colsum(x)
+    ref = x.double().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (cols,)
+    assert rel_err(got, ref.float()) < 1e-5
+    assert torch.equal(got, K.colsum(x))

@@ -165,6 +165,39 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// column sums of a row-major [rows][cols] matrix (the bias gradients of the path's Linear layers):
+// block = CS_ROWS consecutive rows, thread = (row lane, column quad), partial sums per block reduced
+// by partial_reduce_kernel in a fixed order.
+// ---------------------------------------------------------------------------------------------
+constexpr int CS_ROWS = 128, CS_THREADS = 512;
+template <typename T>
+__global__ __launch_bounds__(CS_THREADS) void colsum_kernel(const T *__restrict__ x, long long rows, int cols,
+                                                            float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [RL][cols]
+    const int CQ = cols >> 2, RL = CS_THREADS / CQ;  // row lanes
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+    const long long r0 = (long long)blockIdx.x * CS_ROWS, r1 = min(r0 + CS_ROWS, rows);
+    float4 acc = f4zero();
+    if (rl < RL) {
+        const T *p = x + (size_t)(r0 + rl) * cols + (cq << 2);
+        const size_t step = (size_t)RL * cols;
+        long long r = r0 + rl;
+        for (; r + 3 * RL < r1; r += 4 * RL, p += 4 * step) {  // four loads in flight
+            const float4 a = io<T>::ld4(p), b = io<T>::ld4(p + step), c = io<T>::ld4(p + 2 * step), d4 = io<T>::ld4(p + 3 * step);
+            acc = acc + ((a + b) + (c + d4));
+        }
+        for (; r < r1; r += RL, p += step) acc = acc + io<T>::ld4(p);
+        *reinterpret_cast<float4 *>(red + (size_t)rl * cols + (cq << 2)) = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += CS_THREADS) {
+        float s = 0.f;
+        for (int k = 0; k < RL; ++k) s += red[(size_t)k * cols + c];
+        partial[(size_t)blockIdx.x * cols + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // sparse discriminator
 //   stage A (per window block): t0 = conv0(x) [saved, pre-SiLU], u = conv2(silu(t0)) [saved, pre-SiLU]
 //   stage B (tiny):            sd = conv4(silu(u))
@@ -724,4 +757,26 @@ extern "C" size_t dsw_sparse_disc_bwd_scratch(int B, int H, int W, int C, int w)
     const int n = B * 4 * (H / w) * (W / w);
     const size_t np = (size_t)4 * C * 9 + 4;
     return (size_t)((n + 3) & ~3) + (size_t)B * H * W * 4 + (size_t)dsw_sparse_disc_bwd_blocks(B, H) * np + np;
+}
+
+extern "C" int dsw_colsum_blocks(long long rows) { return rows > 0 ? (int)((rows + CS_ROWS - 1) / CS_ROWS) : 0; }
+
+extern "C" int dsw_colsum(const void *x, int dtype, long long rows, int cols, float *out, float *partial, void *stream) {
+    if (rows <= 0 || cols <= 0) return fail(DSW_EINVAL, "dsw_colsum: bad sizes rows=%lld cols=%d", rows, cols);
+    if (cols % 4 || cols / 4 > CS_THREADS) return fail(DSW_EUNSUPPORTED, "dsw_colsum: %d columns (multiples of 4 up to %d)", cols, 4 * CS_THREADS);
+    DSW_REQUIRE(x && out && partial, "dsw_colsum: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int nblk = dsw_colsum_blocks(rows);
+    const size_t lds = (size_t)(CS_THREADS / (cols / 4)) * cols * sizeof(float);
+    int rc;
+    DSW_DISPATCH_DTYPE(dtype, T, {
+        auto kern = colsum_kernel<T>;
+        rc = set_lds_attr(kern, lds, "dsw_colsum");
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(CS_THREADS), lds, st, (const T *)x, rows, cols, partial);
+    });
+    rc = check_launch("colsum_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 15) / 16), dim3(256), 0, st, partial, nblk, cols, out);
+    return check_launch("partial_reduce_kernel");
 }

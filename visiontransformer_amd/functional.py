@@ -426,6 +426,19 @@ def sparse_discriminator_nhwc(x, convs, w, out_dtype=None):
 _WGRAD_CHUNK = 2048
 
 
+def colsum(x2):
+    """fp32 column sums of a contiguous 2-D tensor (bias gradients), in a fixed summation order."""
+    rows, cols = x2.shape
+    if cols % 4 or cols > 2048 or x2.dtype not in (torch.float32, torch.bfloat16):
+        return x2.sum(0, dtype=torch.float32)
+    _lib.require_cuda(x2)
+    x2 = x2.contiguous()
+    out = torch.empty(cols, device=x2.device, dtype=torch.float32)
+    part = torch.empty(_lib.load().dsw_colsum_blocks(rows) * cols, device=x2.device, dtype=torch.float32)
+    _lib.call("dsw_colsum", _lib.ptr(x2), _lib.dtype_code(x2.dtype), rows, cols, _lib.ptr(out), _lib.ptr(part), _lib.stream(x2.device))
+    return out
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b through the stock GEMM library, with one change in the backward: the weight
     gradient dY^T X has a tiny output ([3C, C]) and a huge reduction dimension (all tokens), which
@@ -456,7 +469,7 @@ class _LinearFn(torch.autograd.Function):
                 dw = part.sum(0, dtype=torch.float32)
             else:
                 dw = (dy2.t() @ x2).float()
-            db = None if bdt is None else dy2.sum(0, dtype=torch.float32).to(bdt)
+            db = None if bdt is None else colsum(dy2).to(bdt)
         return dx, dw.to(wdt), db, None
 
 
