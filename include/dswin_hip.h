@@ -92,10 +92,13 @@ int dsw_gather_fwd(const void *x, int x_dtype, const int *win_b, const int *win_
 
 /* Backward of (2), atomic-free and bitwise reproducible: every pixel gathers from the <= 4
  * windows that cover each of its <= 4 sample positions (torchvision's roi_align backward
- * scatters with atomicAdd).  dout [n_win, w*w, C] -> dx [B,H,W,C] (every element written). */
+ * scatters with atomicAdd).  dout [n_win, w*w, C] -> dx [B,H,W,C].
+ * accumulate = 0: every element of dx is written.  accumulate != 0: the result is added into the
+ * dx the caller passes (the gradient another consumer of x already produced) and pixels that no
+ * window touches are neither read nor written. */
 int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellmap, const int *win_h1,
                    const int *win_w1, int n_win, int B, int H, int W, int C, int w,
-                   void *dx, int dx_dtype, void *stream);
+                   void *dx, int dx_dtype, int accumulate, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (4) Gated delta, mean of overlapping windows, residual add.  Replaces DSwinT_arch.py:308-315:
@@ -113,13 +116,13 @@ int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int afte
 /* Backward of (4).  dy [B,H,W,C] -> dx [B,H,W,C] (identity path + the -roi_align path),
  * d_after [n_win, w*w, C], d_gates_delta / d_scores_delta [n_win] fp32.
  * partial: caller-provided scratch of 2*n_win*w floats (per window-row partial sums, reduced
- * in a fixed order). */
+ * in a fixed order).  accumulate_dx != 0: dx is added into the buffer passed instead of written. */
 int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype,
                          const void *after, int after_dtype, const float *gates_delta,
                          const float *scores_delta, const int *cellmap, const int *win_b,
                          const int *win_h1, const int *win_w1, int n_win,
                          int B, int H, int W, int C, int w,
-                         void *dx, int dx_dtype, void *d_after, int d_after_dtype,
+                         void *dx, int dx_dtype, int accumulate_dx, void *d_after, int d_after_dtype,
                          float *d_gates_delta, float *d_scores_delta, float *partial, void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -215,8 +218,9 @@ int dsw_sparse_disc_bwd_blocks(int B, int H);
 size_t dsw_sparse_disc_bwd_scratch(int B, int H, int W, int C, int w);
 int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x, int x_dtype, const float *w0,
                         const float *w2, const float *w4, const float *t0, const float *u, int B,
-                        int H, int W, int C, int w, void *dx, int dx_dtype, float *dw0, float *db0,
-                        float *dw2, float *db2, float *dw4, float *db4, float *scratch, void *stream);
+                        int H, int W, int C, int w, void *dx, int dx_dtype, int accumulate_dx, float *dw0,
+                        float *db0, float *dw2, float *db2, float *dw4, float *db4, float *scratch,
+                        void *stream);
 
 /* Column sums of a row-major [rows][cols] matrix, out[c] = sum_r x[r][c] in fp32: the bias gradient of
  * the path's Linear layers (torch.nn.Linear backward behind DSwinT_arch.py:188,190,325,327 and

@@ -69,6 +69,38 @@ def test_dswt_dsmsa_golden(cuda0, name):
     _check_grads(mod, g, x, y, cuda0)
 
 
+@pytest.mark.parametrize("autocast", [False, True])
+def test_dsmsa_fused_input_gradient(cuda0, autocast):
+    """The in-kernel accumulation of the three gradients of x (sparse discriminator, gather, scatter
+    residual) against letting autograd add them: same values up to fp32 summation order, twice
+    in a row (the meeting buffer resets), and with x also feeding a residual outside the module."""
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    torch.manual_seed(3)
+    mod = DeformableSparseWindowAttention(16, 180, 6).to(cuda0).train()
+    with torch.no_grad():
+        mod.sparse_discriminator[4].weight.mul_(8.0)
+        mod.sparse_discriminator[4].bias[1] += 1.0
+        mod.pe.relative_position_bias_table.normal_(0, 0.5)
+    x = torch.randn(3, 64, 48, 180, device=cuda0, requires_grad=True)
+    mod.gumbel_noise = -torch.empty(3, 12, device=cuda0).exponential_().log()
+    dy = torch.randn(3, 64, 48, 180, device=cuda0)
+    res = {}
+    for fuse in (False, True, True):
+        mod.fuse_input_grads = fuse
+        mod.zero_grad(set_to_none=True)
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            y = x + mod(x)
+        (y.float() * dy).sum().backward()
+        assert mod.last_selection.n > 0
+        got = {"x": x.grad.clone(), **{k: p.grad.clone() for k, p in mod.named_parameters()}}
+        if not fuse:
+            res = got
+        else:
+            for k in res:
+                assert rel_err(got[k], res[k]) < (2e-2 if autocast else 1e-5), k
+
+
 def test_dsmsa_bf16_autocast_against_fp32(cuda0):
     """the trainer's mode: bf16 autocast.  Same module, same weights: selection must be a valid
     selection (k candidates per image, distinct cells) and values within 2e-2 of the fp32 run

@@ -29,10 +29,10 @@ SIGNATURES = {
     "dsw_select_fwd": (_I, [_P, _P, _I, _P, _F] + [_I] * 7 + [_P] * 12 + [_P]),
     "dsw_select_bwd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
     "dsw_gather_fwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _P]),
-    "dsw_gather_bwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _P]),
+    "dsw_gather_bwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _I, _P]),
     "dsw_scatter_mean_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 6 + [_P, _I, _P]),
     "dsw_scatter_mean_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 6 +
-                             [_P, _I, _P, _I, _P, _P, _P, _P]),
+                             [_P, _I, _I, _P, _I, _P, _P, _P, _P]),
     "dsw_win_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "dsw_win_attn_bwd_workspace": (_Z, [_I] * 8),
     "dsw_win_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P,
@@ -50,7 +50,7 @@ SIGNATURES = {
     "dsw_sparse_disc_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "dsw_sparse_disc_bwd_blocks": (_I, [_I, _I]),
     "dsw_sparse_disc_bwd_scratch": (_Z, [_I, _I, _I, _I, _I]),
-    "dsw_sparse_disc_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I,
+    "dsw_sparse_disc_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I,
                                  _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

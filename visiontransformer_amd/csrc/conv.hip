@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void sd_bwd_w2_kernel(const float *__restrict_
 // dx[b,y,x,ci] = sum_{o,taps} w0[o][ci][tap] * dt0[b, y-(a-1), x-(bb-1), o].  Same row-segment / walk-down
 // mapping as the depthwise kernel; the channel quad's 36 weight vectors live in registers and the
 // dt0 window (16 B per pixel, shared by all channel quads of the pixel) comes from the vector cache.
-template <typename TO>
+template <typename TO, bool ACC>
 __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__restrict__ dt0, const float *__restrict__ w0,
                                                                int H, int W, int C, int segs, TO *__restrict__ dx) {
     extern __shared__ __attribute__((aligned(16))) float w0s[];  // [tap][o][C]
@@ -495,6 +495,7 @@ __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__re
             acc = fma4s(wq[6 + bb][0], g0.x, acc), acc = fma4s(wq[6 + bb][1], g0.y, acc);
             acc = fma4s(wq[6 + bb][2], g0.z, acc), acc = fma4s(wq[6 + bb][3], g0.w, acc);
         }
+        if constexpr (ACC) acc = acc + io<TO>::ld4(dst + (size_t)h * rs);  // add into an existing dx
         io<TO>::st4(dst + (size_t)h * rs, acc);
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb) r0[bb] = r1[bb], r1[bb] = r2[bb];
@@ -699,8 +700,8 @@ extern "C" int dsw_sparse_disc_bwd_blocks(int B, int H) { return B > 0 && H > 0 
 
 extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x, int x_dtype, const float *w0,
                                    const float *w2, const float *w4, const float *t0, const float *u, int B, int H, int W,
-                                   int C, int w, void *dx, int dx_dtype, float *dw0, float *db0, float *dw2, float *db2,
-                                   float *dw4, float *db4, float *scratch, void *stream) {
+                                   int C, int w, void *dx, int dx_dtype, int accumulate_dx, float *dw0, float *db0,
+                                   float *dw2, float *db2, float *dw4, float *db4, float *scratch, void *stream) {
     int rc = check_conv("dsw_sparse_disc_bwd", B, H, W, C);
     if (rc) return rc;
     DSW_REQUIRE(w > 0 && H % w == 0 && W % w == 0, "dsw_sparse_disc_bwd: H,W (%d,%d) must be multiples of %d", H, W, w);
@@ -727,7 +728,7 @@ extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x
     if (rc) return rc;
     const size_t lds = (size_t)36 * C * sizeof(float);
     DSW_DISPATCH_DTYPE(dx_dtype, TO, {
-        auto kern = sd_bwd_dx_kernel<TO>;
+        auto kern = accumulate_dx ? sd_bwd_dx_kernel<TO, true> : sd_bwd_dx_kernel<TO, false>;
         rc = set_lds_attr(kern, lds, "dsw_sparse_disc_bwd");
         if (rc) return rc;
         const int segs = walk_segs(W, C);

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(GS_THREADS) void gather_fwd_kernel(
 // ---- gather backward: one block per TILE_PIX pixels of an image row -------------------------------
 // dx(y,x) = sum over the sample positions (y',x') in {y-1,y} x {x-1,x} whose taps include (y,x) of
 //           weight * sum over windows covering (y',x') of dout[window, token(y',x')].
-template <typename TG, typename TO>
+// ACC: add into an existing dx (pixels no window touches are left alone) instead of writing all of it.
+template <typename TG, typename TO, bool ACC>
 __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
     const TG *__restrict__ dout, const int *__restrict__ cellmap, const int *__restrict__ win_h1,
     const int *__restrict__ win_w1, int H, int W, int C, int w, int tiles_per_row, TO *__restrict__ dx) {
@@ -136,17 +137,24 @@ __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
         const int x = x0 + p;
         const float wx_self = (x < W - 1) ? 0.5f : 1.0f;
         float4 acc = f4zero();
+        int touched = 0;
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
 #pragma unroll
             for (int col = 0; col < 2; ++col) {
                 const Cover &cv = cov[row][p + col];
                 const float wt = (row ? wy_self : 0.5f) * (col ? wx_self : 0.5f);
+                touched += cv.n;
                 for (int s = 0; s < cv.n; ++s)
                     acc = acc + io<TG>::ld4(dout + ((size_t)cv.id[s] * L + cv.tok[s]) * C + c) * wt;
             }
         }
-        io<TO>::st4(dx + (((size_t)b * H + y) * W + x) * C + c, acc);
+        TO *dst = dx + (((size_t)b * H + y) * W + x) * C + c;
+        if constexpr (ACC) {
+            if (touched) io<TO>::st4(dst, io<TO>::ld4(dst) + acc);
+        } else {
+            io<TO>::st4(dst, acc);
+        }
     }
 }
 
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_fwd_kernel(
 }
 
 // ---- scatter backward, pixel side: dx = dy - boxT( dy/count * sum_n(s_n*g_n) ) --------------------
-template <typename TG, typename TO>
+template <typename TG, typename TO, bool ACC>
 __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
     const TG *__restrict__ dy, const float *__restrict__ gates_delta, const float *__restrict__ scores_delta,
     const int *__restrict__ cellmap, const int *__restrict__ win_h1, const int *__restrict__ win_w1, int H,
@@ -232,7 +240,9 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
                 }
             }
         }
-        io<TO>::st4(dx + (((size_t)b * H + y) * W + x) * C + c, acc);
+        TO *dst = dx + (((size_t)b * H + y) * W + x) * C + c;
+        if constexpr (ACC) acc = acc + io<TO>::ld4(dst);
+        io<TO>::st4(dst, acc);
     }
 }
 
@@ -322,14 +332,18 @@ extern "C" int dsw_gather_fwd(const void *x, int x_dtype, const int *win_b, cons
 
 extern "C" int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellmap, const int *win_h1,
                               const int *win_w1, int n_win, int B, int H, int W, int C, int w,
-                              void *dx, int dx_dtype, void *stream) {
+                              void *dx, int dx_dtype, int accumulate, void *stream) {
     int rc = check_geometry("dsw_gather_bwd", B, H, W, C, w);
     if (rc) return rc;
     DSW_REQUIRE(cellmap && dx && (n_win == 0 || (dout && win_h1 && win_w1)), "dsw_gather_bwd: null pointer");
     const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
     DSW_DISPATCH_DTYPE(dout_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
-        hipLaunchKernelGGL((gather_bwd_kernel<TG, TO>), dim3(B * H * tiles), dim3(GS_THREADS), 0, as_stream(stream),
-                           (const TG *)dout, cellmap, win_h1, win_w1, H, W, C, w, tiles, (TO *)dx);
+        if (accumulate)
+            hipLaunchKernelGGL((gather_bwd_kernel<TG, TO, true>), dim3(B * H * tiles), dim3(GS_THREADS), 0, as_stream(stream),
+                               (const TG *)dout, cellmap, win_h1, win_w1, H, W, C, w, tiles, (TO *)dx);
+        else
+            hipLaunchKernelGGL((gather_bwd_kernel<TG, TO, false>), dim3(B * H * tiles), dim3(GS_THREADS), 0, as_stream(stream),
+                               (const TG *)dout, cellmap, win_h1, win_w1, H, W, C, w, tiles, (TO *)dx);
     }));
     return check_launch("gather_bwd_kernel");
 }
@@ -355,9 +369,9 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
                                     const void *after, int after_dtype, const float *gates_delta,
                                     const float *scores_delta, const int *cellmap, const int *win_b,
                                     const int *win_h1, const int *win_w1, int n_win, int B, int H, int W,
-                                    int C, int w, void *dx, int dx_dtype, void *d_after, int d_after_dtype,
-                                    float *d_gates_delta, float *d_scores_delta, float *partial,
-                                    void *stream) {
+                                    int C, int w, void *dx, int dx_dtype, int accumulate_dx, void *d_after,
+                                    int d_after_dtype, float *d_gates_delta, float *d_scores_delta,
+                                    float *partial, void *stream) {
     int rc = check_geometry("dsw_scatter_mean_bwd", B, H, W, C, w);
     if (rc) return rc;
     DSW_REQUIRE(dy && dx && cellmap, "dsw_scatter_mean_bwd: null pointer");
@@ -368,9 +382,14 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
     const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
     hipStream_t st = as_stream(stream);
     DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
-        hipLaunchKernelGGL((scatter_bwd_dx_kernel<TG, TO>), dim3(B * H * tiles), dim3(GS_THREADS), 0, st,
-                           (const TG *)dy, gates_delta, scores_delta, cellmap, win_h1, win_w1, H, W, C, w, tiles,
-                           (TO *)dx);
+        if (accumulate_dx)
+            hipLaunchKernelGGL((scatter_bwd_dx_kernel<TG, TO, true>), dim3(B * H * tiles), dim3(GS_THREADS), 0, st,
+                               (const TG *)dy, gates_delta, scores_delta, cellmap, win_h1, win_w1, H, W, C, w, tiles,
+                               (TO *)dx);
+        else
+            hipLaunchKernelGGL((scatter_bwd_dx_kernel<TG, TO, false>), dim3(B * H * tiles), dim3(GS_THREADS), 0, st,
+                               (const TG *)dy, gates_delta, scores_delta, cellmap, win_h1, win_w1, H, W, C, w, tiles,
+                               (TO *)dx);
     }));
     rc = check_launch("scatter_bwd_dx_kernel");
     if (rc || n_win == 0) return rc;

@@ -145,6 +145,9 @@ class DeformableSparseWindowAttention(WindowedAttention):
         # True: run the sparse discriminator and out_conv through torch (MIOpen, NCHW copies)
         # instead of the NHWC HIP kernels
         self.use_torch_convs = False
+        # True: the gradients of the three readers of x (sparse discriminator, gather, scatter
+        # residual) are accumulated in one buffer inside the kernels instead of being added by autograd
+        self.fuse_input_grads = True
 
     def _noise(self, scores_flat):
         if not self.training:
@@ -160,11 +163,17 @@ class DeformableSparseWindowAttention(WindowedAttention):
         act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
         if act not in (torch.float32, torch.bfloat16):
             act = x.dtype
+        # the three readers of x meet in one gradient buffer (only when all three are certain to run
+        # in the backward pass: the early returns below leave the sparse discriminator alone)
+        Hw0, Ww0 = H // w, W // w
+        fuse = (self.fuse_input_grads and not self.use_torch_convs and x.requires_grad and
+                int(Hw0 * Ww0 * self.num_win_selected) > 0)
+        sink = K.GradSink(3) if fuse else None
         if self.use_torch_convs:
             sd = self.sparse_discriminator(x.permute(0, 3, 1, 2).contiguous()).contiguous()
         else:
             sd = K.sparse_discriminator_nhwc(x, (self.sparse_discriminator[0], self.sparse_discriminator[2],
-                                                 self.sparse_discriminator[4]), w, out_dtype=act)
+                                                 self.sparse_discriminator[4]), w, out_dtype=act, sink=sink)
         Hw, Ww = sd.shape[2], sd.shape[3]
         k = int((Hw * Ww) * self.num_win_selected)
         self.last_selection = None
@@ -175,12 +184,14 @@ class DeformableSparseWindowAttention(WindowedAttention):
         sel = K.select_windows(sd, sig, noise, self.temperature, k, w, H, W)
         self.last_selection = sel
         if sel.n == 0:  # DSwinT_arch.py:291-292
+            if sink is not None:
+                sink.expected = 1  # only the sparse discriminator saw x
             return x
-        before = K.gather_windows(x, sel, w, out_dtype=act)              # [n, L, C]
+        before = K.gather_windows(x, sel, w, out_dtype=act, sink=sink)   # [n, L, C]
         qkv = K.linear(before, self.in_proj)
         z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED)
         after = K.linear(z, self.out_proj)
-        y = K.scatter_mean_residual(x, after, sel, w)                     # [B,H,W,C]
+        y = K.scatter_mean_residual(x, after, sel, w, sink=sink)          # [B,H,W,C]
         if self.use_torch_convs:
             return self.out_conv(y.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
         return K.dwconv3x3_nhwc(y, self.out_conv.weight, self.out_conv.bias, out_dtype=act)

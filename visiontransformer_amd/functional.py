@@ -104,9 +104,49 @@ def select_windows(sd, sig, noise, tau, k, w, H, W):
                      cand_pass=cand_pass, probs=probs)
 
 
+class GradSink:
+    """Meeting point for the gradients that several custom ops send to the SAME input tensor.
+
+    DS-MSA reads its input three times (sparse discriminator, window gather, scatter residual).
+    Left to autograd, each backward writes a dense gradient and the engine adds them with two more
+    full passes over memory.  With a sink shared by the `expected` ops, the first backward to run
+    writes its gradient into a fresh buffer, the later ones add theirs into that buffer inside
+    their own kernels (the gather touches only the pixels its windows cover), and only the last
+    one returns the buffer to autograd; the others return None.  All `expected` ops must take part
+    in every backward pass that needs the input's gradient - true when they consume one tensor
+    inside one module's forward - and the order in which they run does not matter."""
+
+    def __init__(self, expected):
+        self.expected = expected
+        self.count = 0
+        self.buf = None
+
+    def target(self, shape, dtype, device):
+        """(buffer to write / add into, accumulate flag)"""
+        if self.buf is None:
+            return torch.empty(shape, dtype=dtype, device=device), 0
+        return self.buf, 1
+
+    def deliver(self, buf):
+        self.count += 1
+        if self.count == self.expected:
+            self.count, self.buf = 0, None
+            return buf
+        self.buf = buf
+        return None
+
+
+def _dx_target(sink, shape, dtype, device):
+    return (torch.empty(shape, dtype=dtype, device=device), 0) if sink is None else sink.target(shape, dtype, device)
+
+
+def _dx_deliver(sink, buf):
+    return buf if sink is None else sink.deliver(buf)
+
+
 class _GatherFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, win_b, win_h1, win_w1, cellmap, w, out_dtype):
+    def forward(ctx, x, win_b, win_h1, win_w1, cellmap, w, out_dtype, sink):
         _lib.require_cuda(x)
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -115,29 +155,31 @@ class _GatherFn(torch.autograd.Function):
         call("dsw_gather_fwd", ptr(x), dtype_code(x.dtype), ptr(win_b), ptr(win_h1), ptr(win_w1), n,
              B, H, W, C, w, ptr(out), dtype_code(out_dtype), stream(x.device))
         ctx.save_for_backward(cellmap, win_h1, win_w1)
-        ctx.meta = (B, H, W, C, w, n, x.dtype)
+        ctx.meta = (B, H, W, C, w, n, x.dtype, sink)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         cellmap, win_h1, win_w1 = ctx.saved_tensors
-        B, H, W, C, w, n, xdt = ctx.meta
+        B, H, W, C, w, n, xdt, sink = ctx.meta
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 8
         dout = dout.contiguous()
-        dx = torch.empty(B, H, W, C, dtype=xdt, device=dout.device)
+        dx, acc = _dx_target(sink, (B, H, W, C), xdt, dout.device)
         call("dsw_gather_bwd", ptr(dout), dtype_code(dout.dtype), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
-             B, H, W, C, w, ptr(dx), dtype_code(xdt), stream(dout.device))
-        return dx, None, None, None, None, None, None
+             B, H, W, C, w, ptr(dx), dtype_code(xdt), acc, stream(dout.device))
+        return (_dx_deliver(sink, dx),) + (None,) * 7
 
 
-def gather_windows(x, sel, w, out_dtype=None):
+def gather_windows(x, sel, w, out_dtype=None, sink=None):
     """roi_align of the selected windows straight from NHWC to [n, w*w, C]
-    (DSwinT_arch.py:259, :297, :303)."""
-    return _GatherFn.apply(x, sel.win_b, sel.win_h1, sel.win_w1, sel.cellmap, int(w), out_dtype or x.dtype)
+    (DSwinT_arch.py:259, :297, :303).  `sink`: see GradSink."""
+    return _GatherFn.apply(x, sel.win_b, sel.win_h1, sel.win_w1, sel.cellmap, int(w), out_dtype or x.dtype, sink)
 
 
 class _ScatterMeanFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, w):
+    def forward(ctx, x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, w, sink):
         _lib.require_cuda(x, after)
         x = x.contiguous()
         after = after.contiguous()
@@ -151,6 +193,7 @@ class _ScatterMeanFn(torch.autograd.Function):
              B, H, W, C, w, ptr(y), dtype_code(y.dtype), stream(x.device))
         ctx.save_for_backward(x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1)
         ctx.w = w
+        ctx.sink = sink
         return y
 
     @staticmethod
@@ -161,22 +204,23 @@ class _ScatterMeanFn(torch.autograd.Function):
         n = win_b.numel()
         dy = dy.contiguous()
         dev = dy.device
-        dx = torch.empty_like(x)
+        sink = ctx.sink if ctx.needs_input_grad[0] else None
+        dx, acc = _dx_target(sink, x.shape, x.dtype, x.device)
         d_after = torch.empty_like(after)
         dg = torch.empty(2, n, dtype=torch.float32, device=dev)
         partial = torch.empty(2 * n * w, dtype=torch.float32, device=dev)
         call("dsw_scatter_mean_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype),
              ptr(after), dtype_code(after.dtype), ptr(gates_delta), ptr(scores_delta), ptr(cellmap),
-             ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, ptr(dx), dtype_code(dx.dtype),
+             ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, ptr(dx), dtype_code(dx.dtype), acc,
              ptr(d_after), dtype_code(d_after.dtype), ptr(dg[0]), ptr(dg[1]), ptr(partial), stream(dev))
-        return dx, d_after, dg[0], dg[1], None, None, None, None, None
+        return _dx_deliver(sink, dx), d_after, dg[0], dg[1], None, None, None, None, None, None
 
 
-def scatter_mean_residual(x, after, sel, w):
+def scatter_mean_residual(x, after, sel, w, sink=None):
     """x + mean over covering windows of (after - roi_align(x)) * gates * scores
-    (DSwinT_arch.py:308-315), NHWC in and out."""
+    (DSwinT_arch.py:308-315), NHWC in and out.  `sink`: see GradSink."""
     return _ScatterMeanFn.apply(x, after, sel.gates_delta, sel.scores_delta, sel.cellmap, sel.win_b,
-                                sel.win_h1, sel.win_w1, int(w))
+                                sel.win_h1, sel.win_w1, int(w), sink)
 
 
 class _WinAttnFn(torch.autograd.Function):
@@ -377,7 +421,7 @@ def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None):
 
 class _SparseDiscFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w0, b0, w2, b2, w4, b4, w, out_dtype):
+    def forward(ctx, x, w0, b0, w2, b2, w4, b4, w, out_dtype, sink):
         _lib.require_cuda(x)
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -389,35 +433,38 @@ class _SparseDiscFn(torch.autograd.Function):
         call("dsw_sparse_disc_fwd", ptr(x), dtype_code(x.dtype), *[ptr(p) for p in ps], B, H, W, C, w, ptr(t0), ptr(u),
              ptr(sd), dtype_code(out_dtype), stream(dev))
         ctx.save_for_backward(x, ps[0], ps[2], ps[4], t0, u)
-        ctx.meta = (w, [(p.shape, p.dtype) for p in (w0, b0, w2, b2, w4, b4)])
+        ctx.meta = (w, [(p.shape, p.dtype) for p in (w0, b0, w2, b2, w4, b4)], sink)
         return sd
 
     @staticmethod
     def backward(ctx, dsd):
         x, w0, w2, w4, t0, u = ctx.saved_tensors
-        w, pmeta = ctx.meta
+        w, pmeta, sink = ctx.meta
         B, H, W, C = x.shape
         dev = x.device
         dsd = dsd.contiguous()
-        dx = torch.empty_like(x)
+        if not ctx.needs_input_grad[0]:
+            sink = None
+        dx, acc = _dx_target(sink, x.shape, x.dtype, x.device)
         f32 = dict(dtype=torch.float32, device=dev)
         g = [torch.empty(4 * C * 9, **f32), torch.empty(4, **f32), torch.empty(16 * w * w, **f32), torch.empty(4, **f32),
              torch.empty(144, **f32), torch.empty(4, **f32)]
         nfl = _lib.load().dsw_sparse_disc_bwd_scratch(B, H, W, C, w)
         scratch = torch.empty(int(nfl), **f32)
         call("dsw_sparse_disc_bwd", ptr(dsd), dtype_code(dsd.dtype), ptr(x), dtype_code(x.dtype), ptr(w0), ptr(w2), ptr(w4),
-             ptr(t0), ptr(u), B, H, W, C, w, ptr(dx), dtype_code(dx.dtype), *[ptr(t) for t in g], ptr(scratch), stream(dev))
+             ptr(t0), ptr(u), B, H, W, C, w, ptr(dx), dtype_code(dx.dtype), acc, *[ptr(t) for t in g], ptr(scratch),
+             stream(dev))
         grads = [t.view(shape).to(dt) for t, (shape, dt) in zip(g, pmeta)]
-        return (dx, *grads, None, None)
+        return (_dx_deliver(sink, dx), *grads, None, None, None)
 
 
-def sparse_discriminator_nhwc(x, convs, w, out_dtype=None):
+def sparse_discriminator_nhwc(x, convs, w, out_dtype=None, sink=None):
     """The DS-MSA sparse discriminator on an NHWC tensor: conv C->4 3x3 + SiLU + conv 4->4 k=w
     stride w + SiLU + conv 4->4 3x3 (DSwinT_arch.py:180-186, :266).  `convs` = the three Conv2d
     modules; returns sd [B,4,H/w,W/w]."""
     c0, c2, c4 = convs
     return _SparseDiscFn.apply(x, c0.weight, c0.bias, c2.weight, c2.bias, c4.weight, c4.bias, int(w),
-                               out_dtype or x.dtype)
+                               out_dtype or x.dtype, sink)
 
 
 # ---------------------------------------------------------------------------------------------
