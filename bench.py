@@ -142,7 +142,7 @@ def pmc_traffic(kernel):
     `bench.py --pmc-target` (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE; see
     tools/pmc_summary.py).  Counters cannot be read from inside this process, so the figure is
     the one measured by those passes at the same shapes; None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
     try:
         with open(path) as f:
             return json.load(f)[kernel]["traffic"]
@@ -269,7 +269,7 @@ def main():
             dom = ks["win_attn_bwd"]
             line["roofline"] = {"bound": "mfma", "kernel": "win_attn_bwd_kernel<bf16,w16,d32>", "achieved": dom["achieved"],
                                 "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"],
-                                "traffic": pmc_traffic("win_attn_bwd_kernel<unsigned short, 16, 32, true, false>"),
+                                "traffic": pmc_traffic("win_attn_bwd_kernel<unsigned short, 16, 32, true, true>"),
                                 "us_per_launch": dom["us"]}
             line["kernels"] = ks
         if world == 1 and not args.no_cpu_baseline:

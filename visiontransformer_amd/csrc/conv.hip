@@ -145,21 +145,31 @@ __global__ __launch_bounds__(WG_THREADS) void dwconv_wgrad_kernel(const TG *__re
     }
 }
 
-// out[i] = sum over blocks of partial[blk][i], 16 interleaved groups then the 16 partials in order
+// out[i] = sum over blocks of partial[blk][i]: 64 interleaved block groups (block index mod 64) summed
+// by 64 threads each with four running sums, then the 64 x 4 partials in a fixed order.
+constexpr int PR_COLS = 4, PR_GROUPS = 64;
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float *__restrict__ partial, int nblocks, int n,
                                                              float *__restrict__ out) {
-    __shared__ float part[16][17];
-    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + e;
-    float acc = 0.f;
-    if (i < n)
-        for (int bl = grp; bl < nblocks; bl += 16) acc += partial[(size_t)bl * n + i];
-    part[grp][e] = acc;
+    __shared__ float part[PR_GROUPS][PR_COLS + 1];
+    const int e = threadIdx.x & (PR_COLS - 1), grp = threadIdx.x / PR_COLS;
+    const int i = blockIdx.x * PR_COLS + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int bl = grp;
+        for (; bl + 3 * PR_GROUPS < nblocks; bl += 4 * PR_GROUPS) {
+            a0 += partial[(size_t)bl * n + i];
+            a1 += partial[(size_t)(bl + PR_GROUPS) * n + i];
+            a2 += partial[(size_t)(bl + 2 * PR_GROUPS) * n + i];
+            a3 += partial[(size_t)(bl + 3 * PR_GROUPS) * n + i];
+        }
+        for (; bl < nblocks; bl += PR_GROUPS) a0 += partial[(size_t)bl * n + i];
+    }
+    part[grp][e] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (grp == 0 && i < n) {
         float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += part[k][e];
+#pragma unroll 8
+        for (int k = 0; k < PR_GROUPS; ++k) t += part[k][e];
         out[i] = t;
     }
 }
@@ -657,7 +667,7 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
     // partial rows are [C][10] = 9 taps + bias; reduce into a packed [C*10] staging area at the
     // end of `partial`, then split (the split is a strided copy done by the caller's view)
     float *packed = partial + (size_t)nblocks * C * 10;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((C * 10 + 15) / 16), dim3(256), 0, st, partial, nblocks, C * 10, packed);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((C * 10 + PR_COLS - 1) / PR_COLS), dim3(256), 0, st, partial, nblocks, C * 10, packed);
     rc = check_launch("partial_reduce_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(split10_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, packed, C, d_weight, d_bias);
@@ -745,7 +755,7 @@ extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x
     });
     rc = check_launch("sd_bwd_dx/w0 kernels");
     if (rc) return rc;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((np + 15) / 16), dim3(256), 0, st, part, nblk, np, packed);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((np + PR_COLS - 1) / PR_COLS), dim3(256), 0, st, part, nblk, np, packed);
     rc = check_launch("partial_reduce_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(copy2_kernel, dim3((np + 255) / 256), dim3(256), 0, st, packed, 4 * C * 9, 4, dw0, db0);
@@ -778,6 +788,6 @@ extern "C" int dsw_colsum(const void *x, int dtype, long long rows, int cols, fl
     });
     rc = check_launch("colsum_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 15) / 16), dim3(256), 0, st, partial, nblk, cols, out);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + PR_COLS - 1) / PR_COLS), dim3(256), 0, st, partial, nblk, cols, out);
     return check_launch("partial_reduce_kernel");
 }
