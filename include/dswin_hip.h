@@ -139,12 +139,15 @@ int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtyp
  *        and added to the output (msft_arch.py:113-125, :136), or NULL.
  * out    [rows, C] same token order as qkv, dtype = qkv dtype.
  * lse    [n_windows, heads, w*w] fp32 log-sum-exp of every softmax row (saved for backward).
+ * ld_qkv, ld_out: row strides in elements of qkv (>= 3C) and out (>= C), even; 0 = dense rows.
+ *        With ld_out > C the columns C..ld_out-1 of every out row are set to zero (rows padded
+ *        to the widths the GEMM library is fast at go to the next projection as they are).
  * Supported: w in {8,16}; head dim C/heads <= 64; dtype f32 (exact f32 MFMA) or bf16.
  */
 int dsw_win_attn_fwd(const void *qkv, int dtype, int layout, int n_img, int H, int W, int w,
-                     int C, int heads, const float *bias_table, float scale,
-                     const float *lepe_w, const float *lepe_b, void *out, float *lse,
-                     void *stream);
+                     int C, int heads, int ld_qkv, int ld_out, const float *bias_table,
+                     float scale, const float *lepe_w, const float *lepe_b, void *out,
+                     float *lse, void *stream);
 
 /* bytes of scratch dsw_win_attn_bwd needs (per-(window,head) partial bias-table and LePE
  * weight gradients, reduced in a fixed order by a second kernel inside the call). */
@@ -153,13 +156,15 @@ size_t dsw_win_attn_bwd_workspace(int n_img, int H, int W, int w, int C, int hea
 
 /* Backward of (3).  dout [rows, C] -> dqkv [rows, 3C] (same layout as qkv), d_bias_table
  * [(2w-1)^2, heads] fp32 (NULL if no bias), d_lepe_w [C,9] / d_lepe_b [C] fp32 (NULL if no
- * LePE).  `out` is the forward result WITHOUT the LePE term when LePE is used it is not
- * needed: pass the forward output as it was returned. */
+ * LePE).  `out` is the forward output as it was returned (with LePE the pre-pass removes that
+ * term itself).  ld_qkv: row stride of qkv AND dqkv; ld_out, ld_dout: row strides of out and
+ * dout; 0 = dense.  With ld_qkv > 3C the padding columns of every dqkv row are set to zero. */
 int dsw_win_attn_bwd(const void *qkv, const void *out, const void *dout, int dtype, int layout,
-                     int n_img, int H, int W, int w, int C, int heads, const float *bias_table,
-                     float scale, const float *lepe_w, const float *lepe_b, const float *lse,
-                     void *dqkv, float *d_bias_table, float *d_lepe_w, float *d_lepe_b,
-                     void *workspace, size_t workspace_bytes, void *stream);
+                     int n_img, int H, int W, int w, int C, int heads, int ld_qkv, int ld_out,
+                     int ld_dout, const float *bias_table, float scale, const float *lepe_w,
+                     const float *lepe_b, const float *lse, void *dqkv, float *d_bias_table,
+                     float *d_lepe_w, float *d_lepe_b, void *workspace, size_t workspace_bytes,
+                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (5) MSFT multi-scale reshapes, one pass each, no intermediate copies.
@@ -228,6 +233,15 @@ int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x, int x_dty
  *   partial: caller scratch of dsw_colsum_blocks(rows) * cols floats. */
 int dsw_colsum_blocks(long long rows);
 int dsw_colsum(const void *x, int dtype, long long rows, int cols, float *out, float *partial, void *stream);
+
+/* Row copy with dtype conversion between two row strides (in elements): dst[r][c] = src[r][c] for
+ * c < cols; with zero_pad != 0 the columns cols..dst_ld-1 of every dst row are set to zero.  Used
+ * around the projection GEMMs (the nn.Linear calls at DSwinT_arch.py:303,308,334,337 and
+ * msft_arch.py:128,141) to hand the GEMM library rows padded to multiples of 64 elements and to
+ * take padded results apart, in place of torch's cast + fill + strided copy.  cols and both row
+ * strides are multiples of 4 elements. */
+int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, int dst_dtype,
+                  long long dst_ld, long long rows, int cols, int zero_pad, void *stream);
 
 #ifdef __cplusplus
 }

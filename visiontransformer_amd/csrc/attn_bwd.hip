@@ -136,7 +136,7 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
     const int win = id / g.heads, head = id - win * g.heads;
-    const int d = g.d, C = g.C, C3 = 3 * g.C;
+    const int d = g.d, C = g.ldo, CG = g.ldg, C3 = g.ldq;  // row strides of out, dout and qkv / dqkv
     int qoff, koff, voff;
     qkv_offsets(g, head, qoff, koff, voff);
     size_t origin;
@@ -177,11 +177,11 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                 if constexpr (PAIR) {
                     kv[i] = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + koff + ec);
                     ov[i] = *reinterpret_cast<const uint32_t *>(out + tr * C + hd + ec);
-                    gv[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + hd + ec);
+                    gv[i] = *reinterpret_cast<const uint32_t *>(dout + tr * CG + hd + ec);
                 } else {
                     kv[i] = bits(qkv[tr * C3 + koff + ec]);
                     ov[i] = bits(out[tr * C + hd + ec]);
-                    gv[i] = bits(dout[tr * C + hd + ec]);
+                    gv[i] = bits(dout[tr * CG + hd + ec]);
                 }
             }
 #pragma unroll
@@ -275,10 +275,10 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             const size_t tr = trow(qb * 32 + i * RS + r0);
             if constexpr (PAIR) {
                 nq[i] = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + qoff + ec);
-                ng[i] = *reinterpret_cast<const uint32_t *>(dout + tr * C + hd + ec);
+                ng[i] = *reinterpret_cast<const uint32_t *>(dout + tr * CG + hd + ec);
             } else {
                 nq[i] = bits(qkv[tr * C3 + qoff + ec]);
-                ng[i] = bits(dout[tr * C + hd + ec]);
+                ng[i] = bits(dout[tr * CG + hd + ec]);
             }
         }
     };
@@ -562,6 +562,10 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         if (khalf == 0) finish_dq(NT - 1, qkeep, true);
     }
 
+    if (head == g.heads - 1 && C3 > 3 * g.C) {  // the padding columns of this window's dqkv rows
+        const int npad = C3 - 3 * g.C;
+        for (int i = tid; i < L * npad; i += THREADS) dqkv[trow(i / npad) * C3 + 3 * g.C + i % npad] = (T)0;
+    }
     // ---- epilogue: dK^T, dV^T (rows = head dim in registers, lane = key) ------------------------
     if constexpr (PAIR) {
         // each wave turns its tiles into [key][head dim] rows in a private slice of the (now free)
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(256) void lepe_bwd_pre_kernel(AttnGeom g, const T *
                                                            float *__restrict__ delta_out, float *__restrict__ ws_lepe) {
     constexpr int L = WS * WS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int d = g.d, C = g.C, C3 = 3 * g.C;
+    const int d = g.d, C = g.C, C3 = g.ldq;
     T *Vs = reinterpret_cast<T *>(smem);  // [L][d]
     T *Gs = Vs + L * d;                   // dO
     T *Os = Gs + L * d;                   // out
@@ -704,8 +708,8 @@ __global__ __launch_bounds__(256) void lepe_bwd_pre_kernel(AttnGeom g, const T *
         const int row = it / d, e = it - row * d;
         const size_t tr = trow(row);
         Vs[it] = qkv[tr * C3 + voff + e];
-        Gs[it] = dout[tr * C + head * d + e];
-        Os[it] = out[tr * C + head * d + e];
+        Gs[it] = dout[tr * g.ldg + head * d + e];
+        Os[it] = out[tr * g.ldo + head * d + e];
     }
     for (int it = tid; it < d * 10; it += 256) {
         const int e = it / 10, k = it - e * 10;
@@ -835,7 +839,8 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
     return rc;
 }
 
-int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads, int layout, AttnGeom &g);
+int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads, int layout, int ld_qkv, int ld_out,
+              int ld_dout, AttnGeom &g);
 
 }  // namespace dsw
 
@@ -848,7 +853,7 @@ static size_t delta_ws_floats(const AttnGeom &g, int w) { return (size_t)g.n_win
 extern "C" size_t dsw_win_attn_bwd_workspace(int n_img, int H, int W, int w, int C, int heads, int has_bias,
                                              int has_lepe) {
     AttnGeom g;
-    if (make_geom("dsw_win_attn_bwd_workspace", n_img, H, W, w, C, heads, DSW_QKV_CHUNKED, g)) return 0;
+    if (make_geom("dsw_win_attn_bwd_workspace", n_img, H, W, w, C, heads, DSW_QKV_CHUNKED, 0, 0, 0, g)) return 0;
     size_t fl = 0;
     if (has_bias) fl += table_ws_floats(g, w);
     if (has_lepe) fl += lepe_ws_floats(g) + delta_ws_floats(g, w);
@@ -856,12 +861,12 @@ extern "C" size_t dsw_win_attn_bwd_workspace(int n_img, int H, int W, int w, int
 }
 
 extern "C" int dsw_win_attn_bwd(const void *qkv, const void *out, const void *dout, int dtype, int layout,
-                                int n_img, int H, int W, int w, int C, int heads, const float *bias_table,
-                                float scale, const float *lepe_w, const float *lepe_b, const float *lse,
+                                int n_img, int H, int W, int w, int C, int heads, int ld_qkv, int ld_out, int ld_dout,
+                                const float *bias_table, float scale, const float *lepe_w, const float *lepe_b, const float *lse,
                                 void *dqkv, float *d_bias_table, float *d_lepe_w, float *d_lepe_b,
                                 void *workspace, size_t workspace_bytes, void *stream) {
     AttnGeom g;
-    int rc = make_geom("dsw_win_attn_bwd", n_img, H, W, w, C, heads, layout, g);
+    int rc = make_geom("dsw_win_attn_bwd", n_img, H, W, w, C, heads, layout, ld_qkv, ld_out, ld_dout, g);
     if (rc) return rc;
     DSW_REQUIRE(qkv && out && dout && lse && dqkv, "dsw_win_attn_bwd: null pointer");
     DSW_REQUIRE((bias_table == nullptr) == (d_bias_table == nullptr), "dsw_win_attn_bwd: bias_table and d_bias_table go together");

@@ -18,6 +18,7 @@ struct AttnGeom {
     int nWh, nWw;    // windows per image column / row (grid mode)
     int C, heads, d; // channels, heads, head dim
     int layout;      // DSW_QKV_*
+    int ldq, ldo, ldg;  // row strides in elements: qkv / dqkv (>= 3C), out (>= C), dout (>= C)
 };
 
 // Row of the C layout of a 32x32 MFMA result held in register r by lane half hh.

@@ -54,7 +54,7 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
     const int tid = threadIdx.x;
     const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
     const int win = id / g.heads, head = id - win * g.heads;
-    const int d = g.d, C = g.C, C3 = 3 * g.C;
+    const int d = g.d, C = g.ldo, C3 = g.ldq;  // row strides of out and qkv
     int qoff, koff, voff;
     qkv_offsets(g, head, qoff, koff, voff);
     // token (i, j) of this window sits at row origin + i*pitch + j
@@ -349,6 +349,12 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
                 }
             }
         }
+        if (head == g.heads - 1 && C > g.C) {  // this block's share of the output rows' padding columns
+            for (int i = lane; i < 32 * (C - g.C); i += 64) {
+                const int qq = qb * 32 + i / (C - g.C);
+                out[(origin + (size_t)(qq / WS) * pitch + (qq % WS)) * C + g.C + i % (C - g.C)] = (T)0;
+            }
+        }
         if constexpr (BF) {
             if ((d & 1) == 0) {
                 // a wave's LDS accesses complete in order, and only this wave touches these rows
@@ -391,7 +397,8 @@ static int launch_fwd(const AttnGeom &g, const void *qkv, const float *table, fl
     return check_launch("win_attn_fwd_kernel");
 }
 
-int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads, int layout, AttnGeom &g) {
+int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads, int layout, int ld_qkv, int ld_out,
+              int ld_dout, AttnGeom &g) {
     if (n_img <= 0 || C <= 0 || heads <= 0 || C % heads) return fail(DSW_EINVAL, "%s: bad sizes n_img=%d C=%d heads=%d", who, n_img, C, heads);
     if (w != 8 && w != 16) return fail(DSW_EUNSUPPORTED, "%s: window size %d (built: 8, 16)", who, w);
     if (C / heads > 64) return fail(DSW_EUNSUPPORTED, "%s: head dim %d > 64", who, C / heads);
@@ -406,6 +413,12 @@ int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads,
     g.heads = heads;
     g.d = C / heads;
     g.layout = layout;
+    g.ldq = ld_qkv ? ld_qkv : 3 * C;
+    g.ldo = ld_out ? ld_out : C;
+    g.ldg = ld_dout ? ld_dout : C;
+    if (g.ldq < 3 * C || g.ldo < C || g.ldg < C || (g.d % 2 == 0 && ((g.ldq | g.ldo | g.ldg) & 1)))
+        return fail(DSW_EINVAL, "%s: row strides (%d, %d, %d) must be >= 3C, C, C (and even for an even head dim)", who,
+                    g.ldq, g.ldo, g.ldg);
     return DSW_OK;
 }
 
@@ -414,10 +427,10 @@ int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads,
 using namespace dsw;
 
 extern "C" int dsw_win_attn_fwd(const void *qkv, int dtype, int layout, int n_img, int H, int W, int w, int C,
-                                int heads, const float *bias_table, float scale, const float *lepe_w,
-                                const float *lepe_b, void *out, float *lse, void *stream) {
+                                int heads, int ld_qkv, int ld_out, const float *bias_table, float scale,
+                                const float *lepe_w, const float *lepe_b, void *out, float *lse, void *stream) {
     AttnGeom g;
-    int rc = make_geom("dsw_win_attn_fwd", n_img, H, W, w, C, heads, layout, g);
+    int rc = make_geom("dsw_win_attn_fwd", n_img, H, W, w, C, heads, layout, ld_qkv, ld_out, 0, g);
     if (rc) return rc;
     DSW_REQUIRE(qkv && out && lse, "dsw_win_attn_fwd: null pointer");
     DSW_REQUIRE((lepe_w == nullptr) == (lepe_b == nullptr), "dsw_win_attn_fwd: lepe_w and lepe_b go together");

@@ -105,13 +105,18 @@ class WindowedMSA(WindowedAttention):
         self.qkv = nn.Linear(dim, 3 * dim)
         self.pe = RelativePositionalEncoding(q_size=self.win, k_size=self.win, num_heads=num_heads)
         self.out_proj = nn.Linear(dim, dim)
+        # True: when dim is not a multiple of 64 the result is a view of a buffer whose rows are
+        # padded to one (what the GEMM library runs fastest on); values and shape are the same, but
+        # the tensor is not contiguous.  False: always return a contiguous tensor.
+        self.padded_output = True
 
     def forward(self, x):
         B, H, W, C = x.shape
         _check_no_attn_dropout(self.attn_drop, self.training)
-        qkv = K.linear(x, self.qkv)
-        z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W))
-        return K.linear(z, self.out_proj)
+        qkv = K.linear(x, self.qkv, pad_out=True)
+        z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W),
+                               pad_out=True)
+        return K.linear(z, self.out_proj, pad_out=self.padded_output)
 
 
 class DeformableSparseWindowAttention(WindowedAttention):

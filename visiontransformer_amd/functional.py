@@ -223,14 +223,32 @@ def scatter_mean_residual(x, after, sel, w, sink=None):
                                 sel.win_h1, sel.win_w1, int(w), sink)
 
 
+def _row_view(t, n):
+    """(2-D tensor to hand to the kernels, row stride in elements) for a tensor whose last dim is n.
+    A tensor whose rows are contiguous and evenly spaced (a dense tensor, or a view of the first n
+    columns of a buffer with padded rows) is taken as it is; anything else is made dense."""
+    t2 = t.reshape(-1, n)
+    rows = t2.shape[0]
+    ok = t2.stride(1) == 1 and (rows == 1 or t2.stride(0) == n or (t2.stride(0) > n and t2.stride(0) % 2 == 0)) and \
+        (t2.stride(0) == n or t2.data_ptr() % 4 == 0)
+    if not ok:
+        t2 = t2.contiguous()
+    return t2, (t2.stride(0) if rows > 1 else n)
+
+
+def _dptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
 class _WinAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, table, lepe_w, lepe_b, layout, n_img, H, W, w, heads, scale):
+    def forward(ctx, qkv, table, lepe_w, lepe_b, layout, n_img, H, W, w, heads, scale, pad_out):
         _lib.require_cuda(qkv)
-        qkv = qkv.contiguous()
         C3 = qkv.shape[-1]
         C = C3 // 3
-        rows = qkv.numel() // C3
+        lead = qkv.shape[:-1]
+        qkv2, ldq = _row_view(qkv, C3)
+        rows = qkv2.shape[0]
         L = w * w
         n_win = n_img * (H // w) * (W // w) if H else n_img
         assert rows == n_win * L, "qkv rows %d != windows %d * %d" % (rows, n_win, L)
@@ -238,47 +256,53 @@ class _WinAttnFn(torch.autograd.Function):
         tab = None if table is None else table.detach().to(torch.float32).contiguous()
         lw = None if lepe_w is None else lepe_w.detach().to(torch.float32).reshape(C, 9).contiguous()
         lb = None if lepe_b is None else lepe_b.detach().to(torch.float32).contiguous()
-        out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=dev)
+        ldo = _ceil_pad(C) if pad_out else C
+        out = torch.empty(rows, ldo, dtype=qkv.dtype, device=dev)
         lse = torch.empty(n_win, heads, L, dtype=torch.float32, device=dev)
-        call("dsw_win_attn_fwd", ptr(qkv), dtype_code(qkv.dtype), layout, n_img, H, W, w, C, heads, ptr(tab),
-             _c_float(scale), ptr(lw), ptr(lb), ptr(out), ptr(lse), stream(dev))
-        ctx.save_for_backward(qkv, out, lse, tab, lw, lb)
-        ctx.meta = (layout, n_img, H, W, w, C, heads, scale,
+        call("dsw_win_attn_fwd", _dptr(qkv2), dtype_code(qkv.dtype), layout, n_img, H, W, w, C, heads, ldq, ldo,
+             ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(out), ptr(lse), stream(dev))
+        ctx.save_for_backward(qkv2, out, lse, tab, lw, lb)
+        ctx.meta = (layout, n_img, H, W, w, C, heads, scale, ldq, ldo, lead,
                     None if table is None else (table.shape, table.dtype),
                     None if lepe_w is None else (lepe_w.shape, lepe_w.dtype, lepe_b.dtype))
-        return out
+        return out[:, :C].view(lead + (C,))
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out, lse, tab, lw, lb = ctx.saved_tensors
-        layout, n_img, H, W, w, C, heads, scale, tmeta, lmeta = ctx.meta
-        dev = qkv.device
-        dout = dout.contiguous()
-        if dout.dtype != qkv.dtype:
-            dout = dout.to(qkv.dtype)
-        dqkv = torch.empty_like(qkv)
+        qkv2, out, lse, tab, lw, lb = ctx.saved_tensors
+        layout, n_img, H, W, w, C, heads, scale, ldq, ldo, lead, tmeta, lmeta = ctx.meta
+        dev = qkv2.device
+        if dout.dtype != qkv2.dtype:
+            dout = dout.to(qkv2.dtype)
+        dout2, ldg = _row_view(dout, C)
+        rows = qkv2.shape[0]
+        # dqkv keeps the row stride of qkv: a padded qkv (from a projection that left its result in
+        # padded rows) gets a padded gradient, padding columns zeroed by the kernel
+        dqkv = torch.empty(rows, ldq, dtype=qkv2.dtype, device=dev)
         d_tab = None if tab is None else torch.empty_like(tab)
         d_lw = None if lw is None else torch.empty_like(lw)
         d_lb = None if lb is None else torch.empty_like(lb)
         lib = _lib.load()
         nbytes = lib.dsw_win_attn_bwd_workspace(n_img, H, W, w, C, heads, int(tab is not None), int(lw is not None))
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
-        call("dsw_win_attn_bwd", ptr(qkv), ptr(out), ptr(dout), dtype_code(qkv.dtype), layout, n_img, H, W, w, C,
-             heads, ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(lse), ptr(dqkv), ptr(d_tab), ptr(d_lw),
-             ptr(d_lb), ptr(ws), ctypes.c_size_t(int(nbytes)), stream(dev))
+        call("dsw_win_attn_bwd", _dptr(qkv2), ptr(out), _dptr(dout2), dtype_code(qkv2.dtype), layout, n_img, H, W, w, C,
+             heads, ldq, ldo, ldg, ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(lse), ptr(dqkv), ptr(d_tab),
+             ptr(d_lw), ptr(d_lb), ptr(ws), ctypes.c_size_t(int(nbytes)), stream(dev))
         g_tab = None if tab is None else d_tab.view(tmeta[0]).to(tmeta[1])
         g_lw = None if lw is None else d_lw.view(lmeta[0]).to(lmeta[1])
         g_lb = None if lb is None else d_lb.to(lmeta[2])
-        return dqkv, g_tab, g_lw, g_lb, None, None, None, None, None, None, None
+        return (dqkv[:, :3 * C].view(lead + (3 * C,)), g_tab, g_lw, g_lb) + (None,) * 8
 
 
-def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w=None, lepe_b=None):
+def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w=None, lepe_b=None, pad_out=False):
     """softmax(q k^T * scale + bias) v per (window, head), de-headified.
 
     qkv [..., 3C].  grid=(B, H, W): tokens are the pixels of B images, windows are cut out by
     address arithmetic and the result keeps the image layout.  grid=None: qkv is [n, w*w, 3C],
     windows already contiguous.  table: [(2w-1)^2, heads] relative-position bias or None.
     lepe_w/lepe_b: depthwise 3x3 conv [C,1,3,3]/[C] applied to V inside each window and added.
+    qkv may be a view of the first 3C columns of a buffer with padded rows (see `linear`); with
+    pad_out the result is such a view too (rows padded to a multiple of 64 elements, zeros).
     """
     C = qkv.shape[-1] // 3
     if scale is None:
@@ -288,7 +312,7 @@ def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w
     else:
         n_img, H, W = grid
     return _WinAttnFn.apply(qkv, table, lepe_w, lepe_b, int(layout), int(n_img), int(H), int(W), int(w),
-                            int(heads), float(scale))
+                            int(heads), float(scale), bool(pad_out))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -486,41 +510,118 @@ def colsum(x2):
     return out
 
 
+_PAD = 64
+
+
+def _ceil_pad(n):
+    return (n + _PAD - 1) // _PAD * _PAD
+
+
+def _padded_rows(t2, act):
+    """If the 2-D view t2 [T, n] has its rows spaced ceil64(n) > n elements apart inside its storage,
+    return the [T, ceil64(n)] view that includes the padding columns, else None.  The GEMMs below
+    multiply padding columns by zero weights, so all that is asked of them is to be finite; the
+    buffers this module creates keep them at zero."""
+    T, n = t2.shape
+    ld = _ceil_pad(n)
+    if ld == n or t2.dtype != act or t2.stride(1) != 1 or (T > 1 and t2.stride(0) != ld):
+        return None
+    if (t2.storage_offset() + T * ld) * t2.element_size() > t2.untyped_storage().nbytes():
+        return None
+    return t2.as_strided((T, ld), (ld, 1))
+
+
+def cast_rows(t2, dtype, ld=None):
+    """[T, n] (rows contiguous, any row stride) -> [T, ld or n] of `dtype`; with ld > n the result has
+    zero padding columns.  One vectorised pass (dsw_cast_rows); torch ops for shapes it does not take."""
+    T, n = t2.shape
+    ld = n if ld is None else ld
+    ok = (t2.is_cuda and T > 0 and n % 4 == 0 and ld % 4 == 0 and t2.stride(1) == 1 and (T == 1 or t2.stride(0) % 4 == 0)
+          and t2.dtype in (torch.float32, torch.bfloat16) and dtype in (torch.float32, torch.bfloat16)
+          and t2.storage_offset() % 4 == 0)
+    if not ok:
+        out = torch.zeros(T, ld, dtype=dtype, device=t2.device)
+        out[:, :n].copy_(t2)
+        return out
+    out = torch.empty(T, ld, dtype=dtype, device=t2.device)
+    src_ld = t2.stride(0) if T > 1 else n
+    _lib.call("dsw_cast_rows", ctypes.c_void_p(t2.data_ptr()), _lib.dtype_code(t2.dtype), src_ld, _lib.ptr(out),
+              _lib.dtype_code(dtype), ld, T, n, 1 if ld > n else 0, _lib.stream(t2.device))
+    return out
+
+
+def _cast_padded(t2, act):
+    """[T, n] -> a fresh [T, ceil64(n)] tensor of dtype act with zero padding columns"""
+    return cast_rows(t2, act, _ceil_pad(t2.shape[1]))
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b through the stock GEMM library, with one change in the backward: the weight
-    gradient dY^T X has a tiny output ([3C, C]) and a huge reduction dimension (all tokens), which
-    the library runs on a handful of CUs; it is issued as a batched GEMM over token chunks and
-    the chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
+    """y = x W^T + b through the stock GEMM library, shaped for it in two ways.
+
+    * The library's kernels for this path's widths (180, 540: rows that are not multiples of 64
+      elements) run 2-4x slower than for 192 / 576.  Operands are therefore used at widths rounded
+      up to 64 wherever that costs no extra pass: an input that has to be cast anyway is cast into a
+      zero-padded buffer, an input or gradient that already sits in padded rows (a view produced
+      here or by the attention kernels) is taken with its padding, the weight is zero-padded in
+      both dimensions, and outputs keep their padded width (the caller sees a view of the first n
+      columns).
+    * The weight gradient dY^T X has a tiny output and a huge reduction dimension (all tokens),
+      which the library runs on a handful of CUs; it is issued as a batched GEMM over token chunks
+      and the chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act_dtype):
+    def forward(ctx, x, weight, bias, act_dtype, pad_out):
+        N, Kd = weight.shape
         with torch.autocast("cuda", enabled=False):
-            x2 = x.reshape(-1, x.shape[-1]).to(act_dtype)
-            w = weight.to(act_dtype)
-            y = torch.addmm(bias.to(act_dtype), x2, w.t()) if bias is not None else x2 @ w.t()
-        ctx.save_for_backward(x2, w)
-        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
-        return y.view(x.shape[:-1] + (weight.shape[0],))
+            x2 = x.reshape(-1, Kd)
+            xk = _padded_rows(x2, act_dtype)
+            if xk is None:
+                xk = _cast_padded(x2, act_dtype) if x2.dtype != act_dtype else x2.contiguous()
+            Kx, Np, Kp = xk.shape[1], _ceil_pad(N), _ceil_pad(Kd)
+            w_p = torch.zeros(Np, Kp, dtype=act_dtype, device=x.device)
+            w_p[:N, :Kd].copy_(weight)
+            Nout = Np if pad_out else N
+            if bias is not None:
+                b_p = torch.zeros(Nout, dtype=act_dtype, device=x.device)
+                b_p[:N].copy_(bias)
+                y_p = torch.addmm(b_p, xk, w_p[:Nout, :Kx].t())
+            else:
+                y_p = xk @ w_p[:Nout, :Kx].t()
+        ctx.save_for_backward(xk, w_p)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, N, Kd)
+        return y_p[:, :N].view(x.shape[:-1] + (N,))
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
-        xshape, xdt, wdt, bdt = ctx.meta
+        xk, w_p = ctx.saved_tensors
+        xshape, xdt, wdt, bdt, N, Kd = ctx.meta
+        act = w_p.dtype
         with torch.autocast("cuda", enabled=False):
-            dy2 = dy.reshape(-1, dy.shape[-1]).to(w.dtype)
-            dx = (dy2 @ w).view(xshape).to(xdt)
-            T, N, Kd = x2.shape[0], dy2.shape[1], x2.shape[1]
+            dy2 = dy.reshape(-1, N)
+            dyk = _padded_rows(dy2, act)
+            if dyk is None:
+                dyk = _cast_padded(dy2, act) if dy2.dtype != act else dy2.contiguous()
+            Ndy, Kx, T = dyk.shape[1], xk.shape[1], xk.shape[0]
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = (dyk @ w_p[:Ndy]).as_strided((T, Kd), (w_p.shape[1], 1))
+                if xdt != act:
+                    dx = cast_rows(dx, xdt)
+                dx = dx.view(xshape)
             if T >= 8 * _WGRAD_CHUNK and T % _WGRAD_CHUNK == 0:
                 S = T // _WGRAD_CHUNK
-                part = torch.bmm(dy2.view(S, _WGRAD_CHUNK, N).transpose(1, 2), x2.view(S, _WGRAD_CHUNK, Kd))
+                part = torch.bmm(dyk.view(S, _WGRAD_CHUNK, Ndy).transpose(1, 2), xk.view(S, _WGRAD_CHUNK, Kx))
                 dw = part.sum(0, dtype=torch.float32)
             else:
-                dw = (dy2.t() @ x2).float()
-            db = None if bdt is None else colsum(dy2).to(bdt)
-        return dx, dw.to(wdt), db, None
+                dw = (dyk.t() @ xk).float()
+            dw = dw[:N, :Kd]
+            db = None if bdt is None else colsum(dyk)[:N].to(bdt)
+        return dx, dw.to(wdt), db, None, None
 
 
-def linear(x, lin):
-    """`lin(x)` for an nn.Linear `lin`, honouring CUDA autocast like F.linear does."""
+def linear(x, lin, pad_out=False):
+    """`lin(x)` for an nn.Linear `lin`, honouring CUDA autocast like F.linear does.  pad_out: leave
+    the result in rows padded to a multiple of 64 elements (returned as a view of the first
+    out_features columns); for callers whose consumers accept such views."""
     act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-    return _LinearFn.apply(x, lin.weight, lin.bias, act)
+    return _LinearFn.apply(x, lin.weight, lin.bias, act, bool(pad_out))
