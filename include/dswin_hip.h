@@ -85,10 +85,12 @@ int dsw_select_bwd(const float *probs, const float *d_scores_delta, const float 
  *     out[n, i*w+j, :] = 2x2 box mean of x[b] at (h1+i, w1+j) with torchvision's border rule
  *     (last row / column: 2x1 mean, corner: the pixel).
  * x [B,H,W,C] x_dtype -> out [n_win, w*w, C] out_dtype.
+ * Row strides (ld_*, here and in (4)): elements between consecutive token rows of the window
+ * matrices, a multiple of 4 and >= C; 0 = dense.  Outputs with ld > C get zero padding columns.
  */
 int dsw_gather_fwd(const void *x, int x_dtype, const int *win_b, const int *win_h1,
                    const int *win_w1, int n_win, int B, int H, int W, int C, int w,
-                   void *out, int out_dtype, void *stream);
+                   void *out, int out_dtype, int ld_out, void *stream);
 
 /* Backward of (2), atomic-free and bitwise reproducible: every pixel gathers from the <= 4
  * windows that cover each of its <= 4 sample positions (torchvision's roi_align backward
@@ -97,7 +99,7 @@ int dsw_gather_fwd(const void *x, int x_dtype, const int *win_b, const int *win_
  * dx the caller passes (the gradient another consumer of x already produced) and pixels that no
  * window touches are neither read nor written. */
 int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellmap, const int *win_h1,
-                   const int *win_w1, int n_win, int B, int H, int W, int C, int w,
+                   const int *win_w1, int n_win, int B, int H, int W, int C, int w, int ld_dout,
                    void *dx, int dx_dtype, int accumulate, void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -111,7 +113,8 @@ int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellmap, const i
 int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int after_dtype,
                          const float *gates_delta, const float *scores_delta,
                          const int *cellmap, const int *win_h1, const int *win_w1, int n_win,
-                         int B, int H, int W, int C, int w, void *y, int y_dtype, void *stream);
+                         int B, int H, int W, int C, int w, int ld_after, void *y, int y_dtype,
+                         void *stream);
 
 /* Backward of (4).  dy [B,H,W,C] -> dx [B,H,W,C] (identity path + the -roi_align path),
  * d_after [n_win, w*w, C], d_gates_delta / d_scores_delta [n_win] fp32.
@@ -121,9 +124,10 @@ int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtyp
                          const void *after, int after_dtype, const float *gates_delta,
                          const float *scores_delta, const int *cellmap, const int *win_b,
                          const int *win_h1, const int *win_w1, int n_win,
-                         int B, int H, int W, int C, int w,
+                         int B, int H, int W, int C, int w, int ld_after,
                          void *dx, int dx_dtype, int accumulate_dx, void *d_after, int d_after_dtype,
-                         float *d_gates_delta, float *d_scores_delta, float *partial, void *stream);
+                         int ld_d_after, float *d_gates_delta, float *d_scores_delta, float *partial,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (3)+(5) Fused window attention on MFMA: softmax(q k^T * scale + bias) v per (window, head),
@@ -241,7 +245,8 @@ int dsw_colsum(const void *x, int dtype, long long rows, int cols, float *out, f
  * take padded results apart, in place of torch's cast + fill + strided copy.  cols and both row
  * strides are multiples of 4 elements. */
 int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, int dst_dtype,
-                  long long dst_ld, long long rows, int cols, int zero_pad, void *stream);
+                  long long dst_ld, long long rows, long long src_rows, int cols, int zero_pad,
+                  void *stream);
 
 #ifdef __cplusplus
 }

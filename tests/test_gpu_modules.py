@@ -101,6 +101,29 @@ def test_dsmsa_fused_input_gradient(cuda0, autocast):
                 assert rel_err(got[k], res[k]) < (2e-2 if autocast else 1e-5), k
 
 
+def test_padded_rows_travel_between_kernels_and_projections(cuda0):
+    """C = 180 is not a multiple of 64: the projections run on rows padded to 192 / 576.  Buffers
+    made by this package are handed on with their padding (no copies between qkv projection,
+    attention and output projection, forward or backward); the module input and the incoming
+    gradient are foreign and get copied once.  Values are covered by the golden tests."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd.dswin import WindowedMSA
+    torch.manual_seed(0)
+    mod = WindowedMSA(16, 180, 6).to(cuda0)
+    x = torch.randn(2, 32, 32, 180, device=cuda0, requires_grad=True)
+    K.PAD_STATS.update(taken=0, copied=0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = mod(x)
+    assert y.shape == x.shape and not y.is_contiguous() and y.stride(-2) == 192
+    (y.float() * torch.randn_like(x)).sum().backward()
+    # forward: x copied (cast), attention output taken; backward: dy copied (foreign), dqkv taken
+    assert K.PAD_STATS == {"taken": 2, "copied": 2}
+    assert torch.isfinite(x.grad).all()
+    mod.padded_output = False
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert mod(x).is_contiguous()
+
+
 def test_dsmsa_bf16_autocast_against_fp32(cuda0):
     """the trainer's mode: bf16 autocast.  Same module, same weights: selection must be a valid
     selection (k candidates per image, distinct cells) and values within 2e-2 of the fp32 run

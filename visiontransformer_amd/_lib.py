@@ -28,11 +28,11 @@ SIGNATURES = {
     "dswin_last_error_string": (ctypes.c_char_p, []),
     "dsw_select_fwd": (_I, [_P, _P, _I, _P, _F] + [_I] * 7 + [_P] * 12 + [_P]),
     "dsw_select_bwd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
-    "dsw_gather_fwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _P]),
-    "dsw_gather_bwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _I, _P]),
-    "dsw_scatter_mean_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 6 + [_P, _I, _P]),
-    "dsw_scatter_mean_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 6 +
-                             [_P, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "dsw_gather_fwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _I, _P]),
+    "dsw_gather_bwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 7 + [_P, _I, _I, _P]),
+    "dsw_scatter_mean_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 7 + [_P, _I, _P]),
+    "dsw_scatter_mean_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 7 +
+                             [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
     "dsw_win_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "dsw_win_attn_bwd_workspace": (_Z, [_I] * 8),
     "dsw_win_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P,
@@ -43,7 +43,8 @@ SIGNATURES = {
     "dsw_shuffle_nchw_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dsw_unshuffle_nhwc_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dsw_dwconv3x3_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
-    "dsw_cast_rows": (_I, [_P, _I, ctypes.c_longlong, _P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _I, _P]),
+    "dsw_cast_rows": (_I, [_P, _I, ctypes.c_longlong, _P, _I, ctypes.c_longlong, ctypes.c_longlong,
+                           ctypes.c_longlong, _I, _I, _P]),
     "dsw_colsum_blocks": (_I, [ctypes.c_longlong]),
     "dsw_colsum": (_I, [_P, _I, ctypes.c_longlong, _I, _P, _P, _P]),
     "dsw_dwconv3x3_bwd_blocks": (_I, [_I, _I, _I]),

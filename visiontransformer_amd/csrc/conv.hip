@@ -208,21 +208,22 @@ __global__ __launch_bounds__(CS_THREADS) void colsum_kernel(const T *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// row copy with dtype conversion between two row strides: dst[r][c] = src[r][c] for c < cols, and
-// zero for cols <= c < dst_ld when zero_pad is set.  Feeds the projection GEMMs with rows padded to
+// row copy with dtype conversion between two row strides: dst[r][c] = src[r][c] for c < cols and
+// r < src_rows, zero in the other rows and, when zero_pad is set, in the columns cols..dst_ld-1.  Feeds the projection GEMMs with rows padded to
 // the widths the GEMM library is fast at (and takes their padded results apart again), in one
 // vectorised pass instead of a cast, a fill and a strided copy.
 // ---------------------------------------------------------------------------------------------
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast_rows_kernel(const TS *__restrict__ src, long long src_ld, TD *__restrict__ dst,
-                                                        long long dst_ld, long long rows, int cols, int width) {
+                                                        long long dst_ld, long long rows, long long src_rows, int cols,
+                                                        int width) {
     // width = columns written per row (cols, or dst_ld with zero fill), a multiple of 4
     const int WQ = width >> 2;
     const long long items = rows * WQ;
     for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
         const long long r = it / WQ;
         const int c = (int)(it - r * WQ) << 2;
-        const float4 v = c < cols ? io<TS>::ld4(src + r * src_ld + c) : f4zero();
+        const float4 v = (c < cols && r < src_rows) ? io<TS>::ld4(src + r * src_ld + c) : f4zero();
         io<TD>::st4(dst + r * dst_ld + c, v);
     }
 }
@@ -813,8 +814,8 @@ extern "C" int dsw_colsum(const void *x, int dtype, long long rows, int cols, fl
 }
 
 extern "C" int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, int dst_dtype, long long dst_ld,
-                             long long rows, int cols, int zero_pad, void *stream) {
-    if (rows <= 0 || cols <= 0 || src_ld < cols || dst_ld < cols)
+                             long long rows, long long src_rows, int cols, int zero_pad, void *stream) {
+    if (rows <= 0 || cols <= 0 || src_ld < cols || dst_ld < cols || src_rows < 0 || src_rows > rows)
         return fail(DSW_EINVAL, "dsw_cast_rows: bad sizes rows=%lld cols=%d src_ld=%lld dst_ld=%lld", rows, cols, src_ld, dst_ld);
     if (cols % 4 || src_ld % 4 || dst_ld % 4)
         return fail(DSW_EUNSUPPORTED, "dsw_cast_rows: cols and row strides must be multiples of 4 (%d, %lld, %lld)", cols, src_ld, dst_ld);
@@ -824,7 +825,7 @@ extern "C" int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, v
     const unsigned nblk = (unsigned)((items + 255) / 256 < 8192 ? (items + 255) / 256 : 8192);
     DSW_DISPATCH_DTYPE(src_dtype, TS, DSW_DISPATCH_DTYPE(dst_dtype, TD, {
         hipLaunchKernelGGL((cast_rows_kernel<TS, TD>), dim3(nblk), dim3(256), 0, as_stream(stream), (const TS *)src, src_ld,
-                           (TD *)dst, dst_ld, rows, cols, width);
+                           (TD *)dst, dst_ld, rows, src_rows, cols, width);
     }));
     return check_launch("cast_rows_kernel");
 }

@@ -94,16 +94,18 @@ __device__ __forceinline__ float4 box_sample(const T *__restrict__ img, int y, i
 template <typename TI, typename TO>
 __global__ __launch_bounds__(GS_THREADS) void gather_fwd_kernel(
     const TI *__restrict__ x, const int *__restrict__ win_b, const int *__restrict__ win_h1,
-    const int *__restrict__ win_w1, int H, int W, int C, int w, TO *__restrict__ out) {
+    const int *__restrict__ win_w1, int H, int W, int C, int w, int ldo, TO *__restrict__ out) {
+    // out rows are ldo >= C elements apart; the columns C..ldo-1 are set to zero
     const int n = blockIdx.x / w, i = blockIdx.x - n * w;
     const int b = win_b[n], y = win_h1[n] + i, x0 = win_w1[n];
     const TI *img = x + (size_t)b * H * W * C;
-    TO *dst = out + ((size_t)n * w * w + (size_t)i * w) * C;
-    const int CV = C >> 2;
-    for (int it = threadIdx.x; it < w * CV; it += GS_THREADS) {
-        const int j = it / CV, c = (it - j * CV) << 2;
-        io<TO>::st4(dst + (size_t)j * C + c, box_sample<TI>(img, y, x0 + j, H, W, C, c));
+    TO *dst = out + ((size_t)n * w * w + (size_t)i * w) * ldo;
+    const int CV = C >> 2, OV = ldo >> 2;
+    for (int it = threadIdx.x; it < w * OV; it += GS_THREADS) {
+        const int j = it / OV, c = (it - j * OV) << 2;
+        io<TO>::st4(dst + (size_t)j * ldo + c, c < C ? box_sample<TI>(img, y, x0 + j, H, W, C, c) : f4zero());
     }
+    (void)CV;
 }
 
 // ---- gather backward: one block per TILE_PIX pixels of an image row -------------------------------
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_fwd_kernel(
 template <typename TG, typename TO, bool ACC>
 __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
     const TG *__restrict__ dout, const int *__restrict__ cellmap, const int *__restrict__ win_h1,
-    const int *__restrict__ win_w1, int H, int W, int C, int w, int tiles_per_row, TO *__restrict__ dx) {
+    const int *__restrict__ win_w1, int H, int W, int C, int w, int ldg, int tiles_per_row, TO *__restrict__ dx) {
     __shared__ Cover cov[2][TILE_PIX + 1];
     const int Hw = H / w, Ww = W / w;
     const int tile = blockIdx.x % tiles_per_row;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
                 const float wt = (row ? wy_self : 0.5f) * (col ? wx_self : 0.5f);
                 touched += cv.n;
                 for (int s = 0; s < cv.n; ++s)
-                    acc = acc + io<TG>::ld4(dout + ((size_t)cv.id[s] * L + cv.tok[s]) * C + c) * wt;
+                    acc = acc + io<TG>::ld4(dout + ((size_t)cv.id[s] * L + cv.tok[s]) * ldg + c) * wt;
             }
         }
         TO *dst = dx + (((size_t)b * H + y) * W + x) * C + c;
@@ -163,7 +165,7 @@ template <typename TX, typename TA, typename TY>
 __global__ __launch_bounds__(GS_THREADS) void scatter_fwd_kernel(
     const TX *__restrict__ x, const TA *__restrict__ after, const float *__restrict__ gates_delta,
     const float *__restrict__ scores_delta, const int *__restrict__ cellmap, const int *__restrict__ win_h1,
-    const int *__restrict__ win_w1, int H, int W, int C, int w, int tiles_per_row, TY *__restrict__ yout) {
+    const int *__restrict__ win_w1, int H, int W, int C, int w, int lda, int tiles_per_row, TY *__restrict__ yout) {
     __shared__ Cover cov[TILE_PIX];
     const int Hw = H / w, Ww = W / w;
     const int tile = blockIdx.x % tiles_per_row;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_fwd_kernel(
             float4 acc = f4zero();
             for (int s = 0; s < cv.n; ++s) {
                 const int id = cv.id[s];
-                const float4 a = io<TA>::ld4(after + ((size_t)id * L + cv.tok[s]) * C + c);
+                const float4 a = io<TA>::ld4(after + ((size_t)id * L + cv.tok[s]) * lda + c);
                 acc = acc + ((a - before) * gates_delta[id]) * scores_delta[id];
             }
             v = v + acc / (float)cv.n;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_win_kernel(
     const TG *__restrict__ dy, const TX *__restrict__ x, const TA *__restrict__ after,
     const float *__restrict__ gates_delta, const float *__restrict__ scores_delta,
     const int *__restrict__ cellmap, const int *__restrict__ win_b, const int *__restrict__ win_h1,
-    const int *__restrict__ win_w1, int H, int W, int C, int w, TO *__restrict__ d_after,
+    const int *__restrict__ win_w1, int H, int W, int C, int w, int lda, int ldd, TO *__restrict__ d_after,
     float *__restrict__ partial) {
     __shared__ float inv_cnt[64];
     __shared__ float red[GS_THREADS / 64];
@@ -275,12 +277,16 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_win_kernel(
         const int j = it / CV, c = (it - j * CV) << 2;
         const float4 dgated = io<TG>::ld4(gimg + ((size_t)y * W + x0 + j) * C + c) / inv_cnt[j];
         const float4 u = dgated * s;  // d(delta*g)
-        io<TO>::st4(d_after + (tok0 + j) * C + c, u * g);
+        io<TO>::st4(d_after + (tok0 + j) * ldd + c, u * g);
         const float4 before = box_sample<TX>(img, y, x0 + j, H, W, C, c);
-        const float4 delta = io<TA>::ld4(after + (tok0 + j) * C + c) - before;
+        const float4 delta = io<TA>::ld4(after + (tok0 + j) * lda + c) - before;
         pg += (u.x * delta.x + u.y * delta.y) + (u.z * delta.z + u.w * delta.w);
         const float4 dg = delta * g;
         ps += (dgated.x * dg.x + dgated.y * dg.y) + (dgated.z * dg.z + dgated.w * dg.w);
+    }
+    for (int it = threadIdx.x; it < w * ((ldd - C) >> 2); it += GS_THREADS) {  // padding columns of d_after
+        const int PV = (ldd - C) >> 2, j = it / PV;
+        io<TO>::st4(d_after + (tok0 + j) * ldd + C + ((it - j * PV) << 2), f4zero());
     }
     const float tg = block_sum(pg, red);
     const float ts = block_sum(ps, red);
@@ -311,39 +317,51 @@ inline int check_geometry(const char *who, int B, int H, int W, int C, int w) {
     return DSW_OK;
 }
 
+// row stride of a window-token matrix: a multiple of 4 elements, at least C
+inline int check_ld(const char *who, int ld, int C) {
+    if (ld < C || ld % 4) return fail(DSW_EINVAL, "%s: row stride %d must be a multiple of 4 and >= %d", who, ld, C);
+    return DSW_OK;
+}
+
 }  // namespace dsw
 
 using namespace dsw;
 
 extern "C" int dsw_gather_fwd(const void *x, int x_dtype, const int *win_b, const int *win_h1,
                               const int *win_w1, int n_win, int B, int H, int W, int C, int w,
-                              void *out, int out_dtype, void *stream) {
+                              void *out, int out_dtype, int ld_out, void *stream) {
     int rc = check_geometry("dsw_gather_fwd", B, H, W, C, w);
+    if (rc) return rc;
+    if (!ld_out) ld_out = C;
+    rc = check_ld("dsw_gather_fwd", ld_out, C);
     if (rc) return rc;
     DSW_REQUIRE(n_win >= 0, "dsw_gather_fwd: n_win < 0");
     if (n_win == 0) return DSW_OK;
     DSW_REQUIRE(x && win_b && win_h1 && win_w1 && out, "dsw_gather_fwd: null pointer");
     DSW_DISPATCH_DTYPE(x_dtype, TI, DSW_DISPATCH_DTYPE(out_dtype, TO, {
         hipLaunchKernelGGL((gather_fwd_kernel<TI, TO>), dim3(n_win * w), dim3(GS_THREADS), 0, as_stream(stream),
-                           (const TI *)x, win_b, win_h1, win_w1, H, W, C, w, (TO *)out);
+                           (const TI *)x, win_b, win_h1, win_w1, H, W, C, w, ld_out, (TO *)out);
     }));
     return check_launch("gather_fwd_kernel");
 }
 
 extern "C" int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellmap, const int *win_h1,
                               const int *win_w1, int n_win, int B, int H, int W, int C, int w,
-                              void *dx, int dx_dtype, int accumulate, void *stream) {
+                              int ld_dout, void *dx, int dx_dtype, int accumulate, void *stream) {
     int rc = check_geometry("dsw_gather_bwd", B, H, W, C, w);
+    if (rc) return rc;
+    if (!ld_dout) ld_dout = C;
+    rc = check_ld("dsw_gather_bwd", ld_dout, C);
     if (rc) return rc;
     DSW_REQUIRE(cellmap && dx && (n_win == 0 || (dout && win_h1 && win_w1)), "dsw_gather_bwd: null pointer");
     const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
     DSW_DISPATCH_DTYPE(dout_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
         if (accumulate)
             hipLaunchKernelGGL((gather_bwd_kernel<TG, TO, true>), dim3(B * H * tiles), dim3(GS_THREADS), 0, as_stream(stream),
-                               (const TG *)dout, cellmap, win_h1, win_w1, H, W, C, w, tiles, (TO *)dx);
+                               (const TG *)dout, cellmap, win_h1, win_w1, H, W, C, w, ld_dout, tiles, (TO *)dx);
         else
             hipLaunchKernelGGL((gather_bwd_kernel<TG, TO, false>), dim3(B * H * tiles), dim3(GS_THREADS), 0, as_stream(stream),
-                               (const TG *)dout, cellmap, win_h1, win_w1, H, W, C, w, tiles, (TO *)dx);
+                               (const TG *)dout, cellmap, win_h1, win_w1, H, W, C, w, ld_dout, tiles, (TO *)dx);
     }));
     return check_launch("gather_bwd_kernel");
 }
@@ -351,8 +369,12 @@ extern "C" int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellm
 extern "C" int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int after_dtype,
                                     const float *gates_delta, const float *scores_delta,
                                     const int *cellmap, const int *win_h1, const int *win_w1, int n_win,
-                                    int B, int H, int W, int C, int w, void *y, int y_dtype, void *stream) {
+                                    int B, int H, int W, int C, int w, int ld_after, void *y, int y_dtype,
+                                    void *stream) {
     int rc = check_geometry("dsw_scatter_mean_fwd", B, H, W, C, w);
+    if (rc) return rc;
+    if (!ld_after) ld_after = C;
+    rc = check_ld("dsw_scatter_mean_fwd", ld_after, C);
     if (rc) return rc;
     DSW_REQUIRE(x && y && cellmap && (n_win == 0 || (after && gates_delta && scores_delta && win_h1 && win_w1)),
                 "dsw_scatter_mean_fwd: null pointer");
@@ -360,7 +382,7 @@ extern "C" int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *afte
     DSW_DISPATCH_DTYPE(x_dtype, TX, DSW_DISPATCH_DTYPE(after_dtype, TA, DSW_DISPATCH_DTYPE(y_dtype, TY, {
         hipLaunchKernelGGL((scatter_fwd_kernel<TX, TA, TY>), dim3(B * H * tiles), dim3(GS_THREADS), 0,
                            as_stream(stream), (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
-                           win_h1, win_w1, H, W, C, w, tiles, (TY *)y);
+                           win_h1, win_w1, H, W, C, w, ld_after, tiles, (TY *)y);
     })));
     return check_launch("scatter_fwd_kernel");
 }
@@ -369,10 +391,16 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
                                     const void *after, int after_dtype, const float *gates_delta,
                                     const float *scores_delta, const int *cellmap, const int *win_b,
                                     const int *win_h1, const int *win_w1, int n_win, int B, int H, int W,
-                                    int C, int w, void *dx, int dx_dtype, int accumulate_dx, void *d_after,
-                                    int d_after_dtype, float *d_gates_delta, float *d_scores_delta,
-                                    float *partial, void *stream) {
+                                    int C, int w, int ld_after, void *dx, int dx_dtype, int accumulate_dx,
+                                    void *d_after, int d_after_dtype, int ld_d_after, float *d_gates_delta,
+                                    float *d_scores_delta, float *partial, void *stream) {
     int rc = check_geometry("dsw_scatter_mean_bwd", B, H, W, C, w);
+    if (rc) return rc;
+    if (!ld_after) ld_after = C;
+    if (!ld_d_after) ld_d_after = C;
+    rc = check_ld("dsw_scatter_mean_bwd", ld_after, C);
+    if (rc) return rc;
+    rc = check_ld("dsw_scatter_mean_bwd", ld_d_after, C);
     if (rc) return rc;
     DSW_REQUIRE(dy && dx && cellmap, "dsw_scatter_mean_bwd: null pointer");
     DSW_REQUIRE(n_win == 0 || (x && after && gates_delta && scores_delta && win_b && win_h1 && win_w1 && d_after &&
@@ -399,11 +427,11 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
         if (d_after_dtype == DSW_F32) {
             hipLaunchKernelGGL((scatter_bwd_win_kernel<TG, TX, TA, float>), dim3(n_win * w), dim3(GS_THREADS), 0, st,
                                (const TG *)dy, (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
-                               win_b, win_h1, win_w1, H, W, C, w, (float *)d_after, partial);
+                               win_b, win_h1, win_w1, H, W, C, w, ld_after, ld_d_after, (float *)d_after, partial);
         } else if (d_after_dtype == DSW_BF16) {
             hipLaunchKernelGGL((scatter_bwd_win_kernel<TG, TX, TA, bf16_t>), dim3(n_win * w), dim3(GS_THREADS), 0, st,
                                (const TG *)dy, (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
-                               win_b, win_h1, win_w1, H, W, C, w, (bf16_t *)d_after, partial);
+                               win_b, win_h1, win_w1, H, W, C, w, ld_after, ld_d_after, (bf16_t *)d_after, partial);
         } else {
             return fail(DSW_EUNSUPPORTED, "dsw_scatter_mean_bwd: d_after dtype %d", d_after_dtype);
         }

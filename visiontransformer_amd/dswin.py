@@ -192,10 +192,12 @@ class DeformableSparseWindowAttention(WindowedAttention):
             if sink is not None:
                 sink.expected = 1  # only the sparse discriminator saw x
             return x
-        before = K.gather_windows(x, sel, w, out_dtype=act, sink=sink)   # [n, L, C]
-        qkv = K.linear(before, self.in_proj)
-        z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED)
-        after = K.linear(z, self.out_proj)
+        # rows of the window matrices stay padded to multiples of 64 elements between the kernels and
+        # the projections (views of the first C / 3C columns)
+        before = K.gather_windows(x, sel, w, out_dtype=act, sink=sink, pad_out=True)   # [n, L, C]
+        qkv = K.linear(before, self.in_proj, pad_out=True)
+        z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
+        after = K.linear(z, self.out_proj, pad_out=True)
         y = K.scatter_mean_residual(x, after, sel, w, sink=sink)          # [B,H,W,C]
         if self.use_torch_convs:
             return self.out_conv(y.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()

@@ -146,35 +146,38 @@ def _dx_deliver(sink, buf):
 
 class _GatherFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, win_b, win_h1, win_w1, cellmap, w, out_dtype, sink):
+    def forward(ctx, x, win_b, win_h1, win_w1, cellmap, w, out_dtype, sink, pad_out):
         _lib.require_cuda(x)
         x = x.contiguous()
         B, H, W, C = x.shape
         n = win_b.numel()
-        out = torch.empty(n, w * w, C, dtype=out_dtype, device=x.device)
+        ldo = _ceil_pad(C) if pad_out else C
+        out = _mark_padded(torch.empty(n, w * w, ldo, dtype=out_dtype, device=x.device))
         call("dsw_gather_fwd", ptr(x), dtype_code(x.dtype), ptr(win_b), ptr(win_h1), ptr(win_w1), n,
-             B, H, W, C, w, ptr(out), dtype_code(out_dtype), stream(x.device))
+             B, H, W, C, w, ptr(out), dtype_code(out_dtype), ldo, stream(x.device))
         ctx.save_for_backward(cellmap, win_h1, win_w1)
         ctx.meta = (B, H, W, C, w, n, x.dtype, sink)
-        return out
+        return out[..., :C]
 
     @staticmethod
     def backward(ctx, dout):
         cellmap, win_h1, win_w1 = ctx.saved_tensors
         B, H, W, C, w, n, xdt, sink = ctx.meta
         if not ctx.needs_input_grad[0]:
-            return (None,) * 8
-        dout = dout.contiguous()
+            return (None,) * 9
+        dout2, ldg = _row_view4(dout, C)
         dx, acc = _dx_target(sink, (B, H, W, C), xdt, dout.device)
-        call("dsw_gather_bwd", ptr(dout), dtype_code(dout.dtype), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
-             B, H, W, C, w, ptr(dx), dtype_code(xdt), acc, stream(dout.device))
-        return (_dx_deliver(sink, dx),) + (None,) * 7
+        call("dsw_gather_bwd", _dptr(dout2), dtype_code(dout2.dtype), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
+             B, H, W, C, w, ldg, ptr(dx), dtype_code(xdt), acc, stream(dout.device))
+        return (_dx_deliver(sink, dx),) + (None,) * 8
 
 
-def gather_windows(x, sel, w, out_dtype=None, sink=None):
+def gather_windows(x, sel, w, out_dtype=None, sink=None, pad_out=False):
     """roi_align of the selected windows straight from NHWC to [n, w*w, C]
-    (DSwinT_arch.py:259, :297, :303).  `sink`: see GradSink."""
-    return _GatherFn.apply(x, sel.win_b, sel.win_h1, sel.win_w1, sel.cellmap, int(w), out_dtype or x.dtype, sink)
+    (DSwinT_arch.py:259, :297, :303).  `sink`: see GradSink.  pad_out: the result is a view of the
+    first C columns of rows padded (with zeros) to a multiple of 64 elements."""
+    return _GatherFn.apply(x, sel.win_b, sel.win_h1, sel.win_w1, sel.cellmap, int(w), out_dtype or x.dtype, sink,
+                           bool(pad_out))
 
 
 class _ScatterMeanFn(torch.autograd.Function):
@@ -182,18 +185,20 @@ class _ScatterMeanFn(torch.autograd.Function):
     def forward(ctx, x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, w, sink):
         _lib.require_cuda(x, after)
         x = x.contiguous()
-        after = after.contiguous()
+        B, H, W, C = x.shape
+        after_shape = after.shape
+        after, lda = _row_view4(after, C)
         gates_delta = gates_delta.to(torch.float32).contiguous()
         scores_delta = scores_delta.to(torch.float32).contiguous()
-        B, H, W, C = x.shape
         n = win_b.numel()
         y = torch.empty_like(x)
-        call("dsw_scatter_mean_fwd", ptr(x), dtype_code(x.dtype), ptr(after), dtype_code(after.dtype),
+        call("dsw_scatter_mean_fwd", ptr(x), dtype_code(x.dtype), _dptr(after), dtype_code(after.dtype),
              ptr(gates_delta), ptr(scores_delta), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
-             B, H, W, C, w, ptr(y), dtype_code(y.dtype), stream(x.device))
+             B, H, W, C, w, lda, ptr(y), dtype_code(y.dtype), stream(x.device))
         ctx.save_for_backward(x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1)
         ctx.w = w
         ctx.sink = sink
+        ctx.after_meta = (after_shape, lda)
         return y
 
     @staticmethod
@@ -206,14 +211,16 @@ class _ScatterMeanFn(torch.autograd.Function):
         dev = dy.device
         sink = ctx.sink if ctx.needs_input_grad[0] else None
         dx, acc = _dx_target(sink, x.shape, x.dtype, x.device)
-        d_after = torch.empty_like(after)
+        after_shape, lda = ctx.after_meta
+        # d_after keeps the row stride of `after` (padded rows stay padded for the projection's backward)
+        d_after = _mark_padded(torch.empty(after.shape[0], lda, dtype=after.dtype, device=dev))
         dg = torch.empty(2, n, dtype=torch.float32, device=dev)
         partial = torch.empty(2 * n * w, dtype=torch.float32, device=dev)
         call("dsw_scatter_mean_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype),
-             ptr(after), dtype_code(after.dtype), ptr(gates_delta), ptr(scores_delta), ptr(cellmap),
-             ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, ptr(dx), dtype_code(dx.dtype), acc,
-             ptr(d_after), dtype_code(d_after.dtype), ptr(dg[0]), ptr(dg[1]), ptr(partial), stream(dev))
-        return _dx_deliver(sink, dx), d_after, dg[0], dg[1], None, None, None, None, None, None
+             _dptr(after), dtype_code(after.dtype), ptr(gates_delta), ptr(scores_delta), ptr(cellmap),
+             ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, lda, ptr(dx), dtype_code(dx.dtype), acc,
+             ptr(d_after), dtype_code(d_after.dtype), lda, ptr(dg[0]), ptr(dg[1]), ptr(partial), stream(dev))
+        return _dx_deliver(sink, dx), d_after[:, :C].view(after_shape), dg[0], dg[1], None, None, None, None, None, None
 
 
 def scatter_mean_residual(x, after, sel, w, sink=None):
@@ -231,6 +238,18 @@ def _row_view(t, n):
     rows = t2.shape[0]
     ok = t2.stride(1) == 1 and (rows == 1 or t2.stride(0) == n or (t2.stride(0) > n and t2.stride(0) % 2 == 0)) and \
         (t2.stride(0) == n or t2.data_ptr() % 4 == 0)
+    if not ok:
+        t2 = t2.contiguous()
+    return t2, (t2.stride(0) if rows > 1 else n)
+
+
+def _row_view4(t, n):
+    """as _row_view, for the kernels that move 4 elements per lane (row stride a multiple of 4,
+    rows 16-byte aligned for fp32 / 8-byte for bf16)"""
+    t2 = t.reshape(-1, n)
+    rows = t2.shape[0]
+    ok = t2.stride(1) == 1 and (rows == 1 or (t2.stride(0) >= n and t2.stride(0) % 4 == 0)) and \
+        t2.data_ptr() % (4 * t2.element_size()) == 0
     if not ok:
         t2 = t2.contiguous()
     return t2, (t2.stride(0) if rows > 1 else n)
@@ -257,7 +276,7 @@ class _WinAttnFn(torch.autograd.Function):
         lw = None if lepe_w is None else lepe_w.detach().to(torch.float32).reshape(C, 9).contiguous()
         lb = None if lepe_b is None else lepe_b.detach().to(torch.float32).contiguous()
         ldo = _ceil_pad(C) if pad_out else C
-        out = torch.empty(rows, ldo, dtype=qkv.dtype, device=dev)
+        out = _mark_padded(torch.empty(rows, ldo, dtype=qkv.dtype, device=dev))
         lse = torch.empty(n_win, heads, L, dtype=torch.float32, device=dev)
         call("dsw_win_attn_fwd", _dptr(qkv2), dtype_code(qkv.dtype), layout, n_img, H, W, w, C, heads, ldq, ldo,
              ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(out), ptr(lse), stream(dev))
@@ -278,7 +297,7 @@ class _WinAttnFn(torch.autograd.Function):
         rows = qkv2.shape[0]
         # dqkv keeps the row stride of qkv: a padded qkv (from a projection that left its result in
         # padded rows) gets a padded gradient, padding columns zeroed by the kernel
-        dqkv = torch.empty(rows, ldq, dtype=qkv2.dtype, device=dev)
+        dqkv = _mark_padded(torch.empty(rows, ldq, dtype=qkv2.dtype, device=dev))
         d_tab = None if tab is None else torch.empty_like(tab)
         d_lw = None if lw is None else torch.empty_like(lw)
         d_lb = None if lb is None else torch.empty_like(lb)
@@ -517,13 +536,27 @@ def _ceil_pad(n):
     return (n + _PAD - 1) // _PAD * _PAD
 
 
+# how often a projection took an operand with its padding as it stood / had to re-pad it by a copy
+PAD_STATS = {"taken": 0, "copied": 0}
+
+
+def _mark_padded(buf):
+    """Tag a buffer whose padding columns this module keeps at zero (see _padded_rows)."""
+    buf._dsw_zero_padded = True
+    return buf
+
+
 def _padded_rows(t2, act):
-    """If the 2-D view t2 [T, n] has its rows spaced ceil64(n) > n elements apart inside its storage,
-    return the [T, ceil64(n)] view that includes the padding columns, else None.  The GEMMs below
-    multiply padding columns by zero weights, so all that is asked of them is to be finite; the
-    buffers this module creates keep them at zero."""
+    """If the 2-D view t2 [T, n] is the first n columns of a [T, ceil64(n)] buffer that this module
+    created with zero padding columns, return that buffer as a view, else None.  The GEMMs below
+    multiply the padding columns by zero weights, which only works if they hold finite numbers:
+    rows that merely look padded (a gradient laid out by autograd, a slice of a foreign tensor)
+    may hold anything there and are copied into a fresh padded buffer instead."""
     T, n = t2.shape
     ld = _ceil_pad(n)
+    base = t2._base if t2._base is not None else t2
+    if not getattr(base, "_dsw_zero_padded", False):
+        return None
     if ld == n or t2.dtype != act or t2.stride(1) != 1 or (T > 1 and t2.stride(0) != ld):
         return None
     if (t2.storage_offset() + T * ld) * t2.element_size() > t2.untyped_storage().nbytes():
@@ -546,7 +579,23 @@ def cast_rows(t2, dtype, ld=None):
     out = torch.empty(T, ld, dtype=dtype, device=t2.device)
     src_ld = t2.stride(0) if T > 1 else n
     _lib.call("dsw_cast_rows", ctypes.c_void_p(t2.data_ptr()), _lib.dtype_code(t2.dtype), src_ld, _lib.ptr(out),
-              _lib.dtype_code(dtype), ld, T, n, 1 if ld > n else 0, _lib.stream(t2.device))
+              _lib.dtype_code(dtype), ld, T, T, n, 1 if ld > n else 0, _lib.stream(t2.device))
+    return out
+
+
+def _padded_matrix(m, dtype, rows_p, cols_p):
+    """[r, c] parameter -> fresh [rows_p, cols_p] tensor of `dtype`, zero outside the first r x c"""
+    r, c = m.shape
+    m = m.detach()
+    ok = (m.is_cuda and m.is_contiguous() and c % 4 == 0 and cols_p % 4 == 0 and m.dtype in (torch.float32, torch.bfloat16)
+          and dtype in (torch.float32, torch.bfloat16) and m.data_ptr() % 16 == 0)
+    if not ok:
+        out = torch.zeros(rows_p, cols_p, dtype=dtype, device=m.device)
+        out[:r, :c].copy_(m)
+        return out
+    out = torch.empty(rows_p, cols_p, dtype=dtype, device=m.device)
+    _lib.call("dsw_cast_rows", _lib.ptr(m), _lib.dtype_code(m.dtype), c, _lib.ptr(out), _lib.dtype_code(dtype), cols_p,
+              rows_p, r, c, 1 if cols_p > c else 0, _lib.stream(m.device))
     return out
 
 
@@ -575,18 +624,18 @@ class _LinearFn(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             x2 = x.reshape(-1, Kd)
             xk = _padded_rows(x2, act_dtype)
+            PAD_STATS["taken" if xk is not None else "copied"] += 1
             if xk is None:
                 xk = _cast_padded(x2, act_dtype) if x2.dtype != act_dtype else x2.contiguous()
             Kx, Np, Kp = xk.shape[1], _ceil_pad(N), _ceil_pad(Kd)
-            w_p = torch.zeros(Np, Kp, dtype=act_dtype, device=x.device)
-            w_p[:N, :Kd].copy_(weight)
+            w_p = _padded_matrix(weight, act_dtype, Np, Kp)
             Nout = Np if pad_out else N
             if bias is not None:
-                b_p = torch.zeros(Nout, dtype=act_dtype, device=x.device)
-                b_p[:N].copy_(bias)
+                b_p = _padded_matrix(bias.view(1, N), act_dtype, 1, Nout).view(Nout)
                 y_p = torch.addmm(b_p, xk, w_p[:Nout, :Kx].t())
             else:
                 y_p = xk @ w_p[:Nout, :Kx].t()
+            _mark_padded(y_p)  # padding columns = zero weight rows x finite inputs + zero bias
         ctx.save_for_backward(xk, w_p)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, N, Kd)
         return y_p[:, :N].view(x.shape[:-1] + (N,))
@@ -599,12 +648,13 @@ class _LinearFn(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             dy2 = dy.reshape(-1, N)
             dyk = _padded_rows(dy2, act)
+            PAD_STATS["taken" if dyk is not None else "copied"] += 1
             if dyk is None:
                 dyk = _cast_padded(dy2, act) if dy2.dtype != act else dy2.contiguous()
             Ndy, Kx, T = dyk.shape[1], xk.shape[1], xk.shape[0]
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = (dyk @ w_p[:Ndy]).as_strided((T, Kd), (w_p.shape[1], 1))
+                dx = _mark_padded(dyk @ w_p[:Ndy]).as_strided((T, Kd), (w_p.shape[1], 1))
                 if xdt != act:
                     dx = cast_rows(dx, xdt)
                 dx = dx.view(xshape)
