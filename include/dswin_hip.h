@@ -79,6 +79,15 @@ int dsw_select_bwd(const float *probs, const float *d_scores_delta, const float 
                    const int *win_b, const int *win_cell, int n_win, float tau,
                    int B, int Hw, int Ww, float *d_scores, float *d_gate, void *stream);
 
+/* dsw_select_fwd accepts sig = NULL: the three sigmoids of sd[:, 1:] (DSwinT_arch.py:269-270, :280)
+ * are then taken inside the kernels, rounded to the activation dtype like the tensor op.
+ * dsw_select_bwd_sd is the backward for that case, continued through the sigmoid: it writes the
+ * gradient of sd itself, d_sd [B,4,Hw,Ww] in sd's dtype (channel 0: logits, channel 1: gate,
+ * channels 2,3: zero - the offsets get no gradient, DSwinT_arch.py:232-233). */
+int dsw_select_bwd_sd(const float *probs, const float *d_scores_delta, const float *d_gates_delta,
+                      const int *win_b, const int *win_cell, int n_win, float tau, int B, int Hw,
+                      int Ww, const void *sd, int sd_dtype, void *d_sd, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * (2) Bilinear window gather.  Replaces the NHWC->NCHW copy (DSwinT_arch.py:259),
  *     torchvision.ops.roi_align(x, rois, (w,w)) (:297) and the NCHW->NHWC copy (:303):

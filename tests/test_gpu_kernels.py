@@ -327,3 +327,29 @@ def test_colsum(cuda0, rows, cols, dtype):
     assert got.dtype == torch.float32 and got.shape == (cols,)
     assert rel_err(got, ref.float()) < 1e-5
     assert torch.equal(got, K.colsum(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_select_in_kernel_sigmoid(cuda0, dtype):
+    """sig = None (sigmoids and their backward inside the kernels) against the explicit
+    sd[:, 1:].sigmoid() tensor: same windows bit for bit, same gradient of sd."""
+    from visiontransformer_amd import functional as K
+    g = torch.Generator(device=cuda0).manual_seed(11)
+    B, Hw, Ww, w, k = 5, 6, 4, 8, 7
+    sd0 = (torch.randn(B, 4, Hw, Ww, device=cuda0, generator=g) * 2).to(dtype)
+    noise = -torch.empty(B, Hw * Ww, device=cuda0).exponential_(generator=g).log()
+    outs = []
+    for fused in (False, True):
+        sd = sd0.clone().requires_grad_()
+        sig = None if fused else sd[:, 1:].sigmoid()
+        sel = K.select_windows(sd, sig, noise, 0.7, k, w, Hw * w, Ww * w)
+        assert sel.n > 0
+        wg = torch.linspace(0.5, 1.5, sel.n, device=cuda0)
+        ((sel.scores_delta * wg).sum() + (sel.gates_delta * wg.flip(0)).sum()).backward()
+        outs.append((sel, sd.grad))
+    (a, ga), (b, gb) = outs
+    for f in ("win_b", "win_cell", "win_h1", "win_w1", "cellmap", "cand_idx", "cand_pass"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    assert torch.equal(a.scores_delta, b.scores_delta) and torch.equal(a.gates_delta, b.gates_delta)
+    assert rel_err(gb.float(), ga.float()) < (1e-5 if dtype == torch.float32 else 2e-2)

@@ -28,6 +28,7 @@ SIGNATURES = {
     "dswin_last_error_string": (ctypes.c_char_p, []),
     "dsw_select_fwd": (_I, [_P, _P, _I, _P, _F] + [_I] * 7 + [_P] * 12 + [_P]),
     "dsw_select_bwd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
+    "dsw_select_bwd_sd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _I, _P, _P]),
     "dsw_gather_fwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _I, _P]),
     "dsw_gather_bwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 7 + [_P, _I, _I, _P]),
     "dsw_scatter_mean_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 7 + [_P, _I, _P]),

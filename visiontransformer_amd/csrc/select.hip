@@ -17,6 +17,15 @@ template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return 
 // derives the softmax statistics itself; each thread then ranks one window by counting the
 // windows that beat it (higher logit, or equal logit and lower index).  rank < k <=> selected,
 // and the rank is the position in the descending top-k list.
+// sigmoid of channel 1 + j of sd at a grid cell, rounded to the activation dtype: what
+// `sd[:, 1:].sigmoid()` holds (DSwinT_arch.py:269-270, :280); read from `sig` when the caller made it
+template <typename T>
+__device__ __forceinline__ float gate_value(const T *__restrict__ sd, const T *__restrict__ sig, int b, int j, int n, int cell) {
+    if (sig != nullptr) return io<T>::ld(sig + ((size_t)b * 3 + j) * n + cell);
+    const float v = io<T>::ld(sd + ((size_t)b * 4 + 1 + j) * n + cell);
+    return round_to<T>(1.0f / (1.0f + expf(-v)));
+}
+
 template <typename T>
 __global__ __launch_bounds__(SEL_THREADS) void select_rank_kernel(
     const T *__restrict__ sd, const T *__restrict__ sig, const float *__restrict__ noise, float tau,
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rank_kernel(
         const size_t o = (size_t)b * k + rank;
         cand_idx[o] = i;
         cand_p[o] = p;
-        const float g = io<T>::ld(sig + ((size_t)b * 3 + 0) * n + i);
+        const float g = gate_value<T>(sd, sig, b, 0, n, i);
         cand_pass[o] = g > 0.5f ? 1 : 0;
     }
 }
@@ -62,8 +71,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rank_kernel(
 // compacts its own k candidates in rank order and finishes the per-window arithmetic.
 template <typename T>
 __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(
-    const T *__restrict__ sig, const int *__restrict__ cand_idx, const float *__restrict__ cand_p,
-    const int *__restrict__ cand_pass, int B, int Hw, int Ww, int k, int w, int H, int W,
+    const T *__restrict__ sd, const T *__restrict__ sig, const int *__restrict__ cand_idx,
+    const float *__restrict__ cand_p, const int *__restrict__ cand_pass, int B, int Hw, int Ww, int k, int w, int H, int W,
     int *__restrict__ n_pass, int *__restrict__ win_b, int *__restrict__ win_cell,
     int *__restrict__ win_h1, int *__restrict__ win_w1, float *__restrict__ scores_delta,
     float *__restrict__ gates_delta, int *__restrict__ cellmap) {
@@ -104,8 +113,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(
             const int cell = cand_idx[(size_t)b * k + r];
             const int hc = cell / Ww, wc = cell - hc * Ww;
             const float fw = (float)w, half = (float)w * 0.5f;
-            const float oh = io<T>::ld(sig + ((size_t)b * 3 + 1) * n + cell);
-            const float ow = io<T>::ld(sig + ((size_t)b * 3 + 2) * n + cell);
+            const float oh = gate_value<T>(sd, sig, b, 1, n, cell);
+            const float ow = gate_value<T>(sd, sig, b, 2, n, cell);
             // offsets*w - w/2: two ops, each rounded in the activation dtype; .long() truncates
             const float th = round_to<T>(__fsub_rn(round_to<T>(__fmul_rn(oh, fw)), half));
             const float tw = round_to<T>(__fsub_rn(round_to<T>(__fmul_rn(ow, fw)), half));
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(
             win_cell[id] = cell;
             win_h1[id] = h1;
             win_w1[id] = w1;
-            const float g = io<T>::ld(sig + ((size_t)b * 3 + 0) * n + cell);
+            const float g = gate_value<T>(sd, sig, b, 0, n, cell);
             const float p = cand_p[(size_t)b * k + r];
             gates_delta[id] = __fadd_rn(__fsub_rn(1.0f, g), g);   // (hard - g).detach() + g, hard = 1
             scores_delta[id] = __fadd_rn(__fsub_rn(1.0f, p), p);  // (1 - p).detach() + p
@@ -156,6 +165,44 @@ __global__ __launch_bounds__(SEL_THREADS) void select_bwd_kernel(
         d_scores[(size_t)b * n + j] = probs[(size_t)b * n + j] * (dp[j] - dot) / tau;
 }
 
+// The same backward, continued through `sd[:, 1:].sigmoid()` and written as the gradient of sd
+// itself, [B, 4, n] in the activation dtype: channel 0 = d(logits), channel 1 = d(gate) * s (1 - s),
+// channels 2, 3 (offsets) = 0 (they reach the output through .long() only, DSwinT_arch.py:232-233).
+template <typename T>
+__global__ __launch_bounds__(SEL_THREADS) void select_bwd_sd_kernel(
+    const float *__restrict__ probs, const float *__restrict__ d_scores_delta,
+    const float *__restrict__ d_gates_delta, const int *__restrict__ win_b,
+    const int *__restrict__ win_cell, int n_win, float tau, int n, const T *__restrict__ sd, T *__restrict__ d_sd) {
+    extern __shared__ __attribute__((aligned(16))) float dp[];  // [n] d(p), [n] d(gate), reduction scratch
+    float *dg = dp + n, *red = dg + n;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < n; j += SEL_THREADS) {
+        dp[j] = 0.f;
+        dg[j] = 0.f;
+    }
+    __syncthreads();
+    for (int t = tid; t < n_win; t += SEL_THREADS) {
+        if (win_b[t] == b) {
+            const int cell = win_cell[t];
+            dp[cell] = d_scores_delta[t];
+            dg[cell] = d_gates_delta[t];
+        }
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int j = tid; j < n; j += SEL_THREADS) part += probs[(size_t)b * n + j] * dp[j];
+    const float dot = block_sum(part, red);
+    const T *sdb = sd + (size_t)b * 4 * n;
+    T *out = d_sd + (size_t)b * 4 * n;
+    for (int j = tid; j < n; j += SEL_THREADS) {
+        io<T>::st(out + j, probs[(size_t)b * n + j] * (dp[j] - dot) / tau);
+        const float sg = round_to<T>(1.0f / (1.0f + expf(-io<T>::ld(sdb + n + j))));
+        io<T>::st(out + n + j, round_to<T>(dg[j]) * sg * (1.0f - sg));
+        io<T>::st(out + 2 * n + j, 0.f);
+        io<T>::st(out + 3 * n + j, 0.f);
+    }
+}
+
 }  // namespace dsw
 
 using namespace dsw;
@@ -166,7 +213,7 @@ extern "C" int dsw_select_fwd(const void *sd, const void *sig, int sd_dtype, con
                               int *n_pass, int *win_b, int *win_cell, int *win_h1, int *win_w1,
                               float *scores_delta, float *gates_delta, int *cellmap,
                               void *stream) {
-    DSW_REQUIRE(sd && sig && probs && cand_idx && cand_p && cand_pass && n_pass && win_b && win_cell &&
+    DSW_REQUIRE(sd && probs && cand_idx && cand_p && cand_pass && n_pass && win_b && win_cell &&
                     win_h1 && win_w1 && scores_delta && gates_delta && cellmap,
                 "dsw_select_fwd: null pointer");
     DSW_REQUIRE(B > 0 && Hw > 0 && Ww > 0 && w > 0, "dsw_select_fwd: bad sizes B=%d Hw=%d Ww=%d w=%d", B, Hw, Ww, w);
@@ -187,7 +234,7 @@ extern "C" int dsw_select_fwd(const void *sd, const void *sig, int sd_dtype, con
                            noise, tau, n, k, probs, cand_idx, cand_p, cand_pass);
         int rc = check_launch("select_rank_kernel");
         if (rc) return rc;
-        hipLaunchKernelGGL(select_compact_kernel<T>, dim3(B), dim3(SEL_THREADS), 0, st, (const T *)sig, cand_idx,
+        hipLaunchKernelGGL(select_compact_kernel<T>, dim3(B), dim3(SEL_THREADS), 0, st, (const T *)sd, (const T *)sig, cand_idx,
                            cand_p, cand_pass, B, Hw, Ww, k, w, H, W, n_pass, win_b, win_cell, win_h1, win_w1,
                            scores_delta, gates_delta, cellmap);
         return check_launch("select_compact_kernel");
@@ -212,4 +259,25 @@ extern "C" int dsw_select_bwd(const float *probs, const float *d_scores_delta,
     hipLaunchKernelGGL(select_bwd_kernel, dim3(B), dim3(SEL_THREADS), lds, as_stream(stream), probs, d_scores_delta,
                        d_gates_delta, win_b, win_cell, n_win, tau, n, d_scores, d_gate);
     return check_launch("select_bwd_kernel");
+}
+
+extern "C" int dsw_select_bwd_sd(const float *probs, const float *d_scores_delta, const float *d_gates_delta,
+                                 const int *win_b, const int *win_cell, int n_win, float tau, int B, int Hw, int Ww,
+                                 const void *sd, int sd_dtype, void *d_sd, void *stream) {
+    DSW_REQUIRE(probs && sd && d_sd, "dsw_select_bwd_sd: null pointer");
+    DSW_REQUIRE(n_win == 0 || (d_scores_delta && d_gates_delta && win_b && win_cell), "dsw_select_bwd_sd: null window arrays");
+    DSW_REQUIRE(B > 0 && Hw > 0 && Ww > 0 && n_win >= 0 && tau > 0.f, "dsw_select_bwd_sd: bad sizes");
+    const int n = Hw * Ww;
+    if (n > SEL_MAX_WINDOWS) return fail(DSW_EUNSUPPORTED, "dsw_select_bwd_sd: %d windows per image exceeds %d", n, SEL_MAX_WINDOWS);
+    const size_t lds = (size_t)(2 * n + 8) * sizeof(float);
+    DSW_DISPATCH_DTYPE(sd_dtype, T, {
+        auto kern = select_bwd_sd_kernel<T>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(DSW_ELAUNCH, "select_bwd_sd: LDS attribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(kern, dim3(B), dim3(SEL_THREADS), lds, as_stream(stream), probs, d_scores_delta, d_gates_delta,
+                           win_b, win_cell, n_win, tau, n, (const T *)sd, (T *)d_sd);
+    });
+    return check_launch("select_bwd_sd_kernel");
 }

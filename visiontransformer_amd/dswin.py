@@ -184,9 +184,8 @@ class DeformableSparseWindowAttention(WindowedAttention):
         self.last_selection = None
         if k == 0:  # DSwinT_arch.py:273-274
             return x
-        sig = sd[:, 1:].sigmoid()
         noise = self._noise(sd[:, 0].reshape(B, -1))
-        sel = K.select_windows(sd, sig, noise, self.temperature, k, w, H, W)
+        sel = K.select_windows(sd, None, noise, self.temperature, k, w, H, W)  # sigmoids taken in the kernels
         self.last_selection = sel
         if sel.n == 0:  # DSwinT_arch.py:291-292
             if sink is not None:

@@ -45,9 +45,9 @@ class _SelectFn(torch.autograd.Function):
     def forward(ctx, sd, sig, noise, tau, k, w, H, W):
         _lib.require_cuda(sd, sig, noise)
         B, four, Hw, Ww = sd.shape
-        assert four == 4 and sig.shape == (B, 3, Hw, Ww) and sig.dtype == sd.dtype
+        assert four == 4 and (sig is None or (sig.shape == (B, 3, Hw, Ww) and sig.dtype == sd.dtype))
         sd = sd.contiguous()
-        sig = sig.contiguous()
+        sig = None if sig is None else sig.contiguous()
         n = Hw * Ww
         dev = sd.device
         if noise is not None:
@@ -71,21 +71,27 @@ class _SelectFn(torch.autograd.Function):
         win_b, win_cell, win_h1, win_w1 = (win[i, :npass].contiguous() for i in range(4))
         scores_delta = deltas[0, :npass].contiguous()
         gates_delta = deltas[1, :npass].contiguous()
-        ctx.save_for_backward(probs, win_b, win_cell)
+        ctx.save_for_backward(probs, win_b, win_cell, sd if sig is None else None)
         ctx.meta = (tau, B, Hw, Ww, npass, sd.dtype)
         ctx.mark_non_differentiable(win_b, win_cell, win_h1, win_w1, cellmap, cand_idx, cand_pass, probs)
-        ctx.set_materialize_grads(True)
+        ctx.set_materialize_grads(False)
         return scores_delta, gates_delta, win_b, win_cell, win_h1, win_w1, cellmap, cand_idx, cand_pass, probs
 
     @staticmethod
     def backward(ctx, d_scores_delta, d_gates_delta, *unused):
-        probs, win_b, win_cell = ctx.saved_tensors
+        probs, win_b, win_cell, sd = ctx.saved_tensors
         tau, B, Hw, Ww, npass, dt = ctx.meta
         dev = probs.device
         n = Hw * Ww
+        zero = lambda: torch.zeros(npass, dtype=torch.float32, device=dev)
+        dsd = zero() if d_scores_delta is None else d_scores_delta.to(torch.float32).contiguous()
+        dgd = zero() if d_gates_delta is None else d_gates_delta.to(torch.float32).contiguous()
+        if sd is not None:  # the sigmoids were taken inside the forward kernels: one kernel, gradient of sd itself
+            d_sd = torch.empty(B, 4, Hw, Ww, dtype=dt, device=dev)
+            call("dsw_select_bwd_sd", ptr(probs), ptr(dsd), ptr(dgd), ptr(win_b), ptr(win_cell), npass, _c_float(tau),
+                 B, Hw, Ww, ptr(sd), dtype_code(dt), ptr(d_sd), stream(dev))
+            return d_sd, None, None, None, None, None, None, None
         grads = torch.empty(2, B, n, dtype=torch.float32, device=dev)
-        dsd = d_scores_delta.to(torch.float32).contiguous()
-        dgd = d_gates_delta.to(torch.float32).contiguous()
         call("dsw_select_bwd", ptr(probs), ptr(dsd), ptr(dgd), ptr(win_b), ptr(win_cell), npass, _c_float(tau),
              B, Hw, Ww, ptr(grads[0]), ptr(grads[1]), stream(dev))
         d_sd = torch.zeros(B, 4, Hw, Ww, dtype=dt, device=dev)
@@ -96,7 +102,8 @@ class _SelectFn(torch.autograd.Function):
 
 
 def select_windows(sd, sig, noise, tau, k, w, H, W):
-    """Top-k + hard gate + compaction + corners (DSwinT_arch.py:201-237, :280-295)."""
+    """Top-k + hard gate + compaction + corners (DSwinT_arch.py:201-237, :280-295).  sig =
+    sd[:, 1:].sigmoid(), or None to have the kernels take the sigmoids themselves."""
     out = _SelectFn.apply(sd, sig, noise, float(tau), int(k), int(w), int(H), int(W))
     sdl, gdl, win_b, win_cell, win_h1, win_w1, cellmap, cand_idx, cand_pass, probs = out
     return Selection(n=win_b.numel(), win_b=win_b, win_cell=win_cell, win_h1=win_h1, win_w1=win_w1,
