@@ -77,14 +77,26 @@ def time_calls(fn, iters, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per call
 
 
-def kernel_rooflines(device, iters=20, warm=3):
+def kernel_rooflines(device, iters=20, warm=3, k=4, attention=True):
     """Per-kernel achieved rate at config B shapes, measured with events on the launch stream."""
-    from visiontransformer_amd import functional as K
-    from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
     torch.manual_seed(1)
+    out = {}
+    if attention:
+        _attention_rooflines(device, iters, warm, out)
+    # DS-MSA side: k windows per image (config B: 4), all passing, random corners
+    x = torch.randn(B_PER_GPU, HW, HW, C, device=device)
+    _window_rooflines(device, iters, warm, k, x, out)
+    for v in out.values():
+        if "achieved" in v:
+            v["frac"] = v["achieved"] / v["peak"]
+    return out
+
+
+def _attention_rooflines(device, iters, warm, out):
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd._lib import QKV_INTERLEAVED
     L = WIN * WIN
     T = B_PER_GPU * HW * HW
-    out = {}
     bf = torch.bfloat16
     table = torch.randn((2 * WIN - 1) ** 2, HEADS, device=device) * 0.02
     # windowed MSA shape: all 512 windows, image grid addressing
@@ -100,41 +112,60 @@ def kernel_rooflines(device, iters=20, warm=3):
                                unit="TFLOP/s", us=t_f * 1e6, algorithmic=flops_f)
     out["win_attn_bwd"] = dict(bound="mfma", achieved=flops_b / t_b / 1e12, peak=MFMA_BF16_PEAK_TFLOPS,
                                unit="TFLOP/s", us=t_b * 1e6, algorithmic=flops_b)
-    # DS-MSA side: 128 windows (k = 4 per image, all passing), random corners
-    x = torch.randn(B_PER_GPU, HW, HW, C, device=device)
-    sd = torch.randn(B_PER_GPU, 4, HW // WIN, HW // WIN, device=device)
+
+
+def _window_rooflines(device, iters, warm, k, x, out):
+    """Selection, gather and scatter kernels, called through the C ABI with preallocated buffers
+    (the autograd wrappers cost more host time per call than these kernels run)."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd._lib import call, dtype_code, ptr, stream
+    L = WIN * WIN
+    bf = torch.bfloat16
+    B, H, W = B_PER_GPU, HW, HW
+    sd = torch.randn(B, 4, H // WIN, W // WIN, device=device)
     sd[:, 1] = 4.0
     sig = sd[:, 1:].sigmoid()
-    sel = K.select_windows(sd, sig, None, 1.0, 4, WIN, HW, HW)
+    sel = K.select_windows(sd, sig, None, 1.0, k, WIN, H, W)
     n = sel.n
-    t_s = time_calls(lambda: K.select_windows(sd, sig, None, 1.0, 4, WIN, HW, HW), iters, warm)
-    out["select"] = dict(bound="latency", us=t_s * 1e6)
-    xs = x.clone().requires_grad_()
-    g = K.gather_windows(xs, sel, WIN, out_dtype=bf)
-    t_g = time_calls(lambda: K.gather_windows(x, sel, WIN, out_dtype=bf), iters, warm)
-    dg = torch.randn_like(g)
-    t_gb = time_calls(lambda: torch.autograd.grad(g, xs, dg, retain_graph=True), iters, warm)
+    t_s = time_calls(lambda: K.select_windows(sd, sig, None, 1.0, k, WIN, H, W), iters, warm)
+    out["select"] = dict(bound="latency", us=t_s * 1e6, note="two kernels + the host read of the window count")
+    st = stream(device)
+    f32c, bfc = dtype_code(torch.float32), dtype_code(bf)
+    g = torch.empty(n, L, C, device=device, dtype=bf)
+    gather_f = lambda: call("dsw_gather_fwd", ptr(x), f32c, ptr(sel.win_b), ptr(sel.win_h1), ptr(sel.win_w1), n, B, H, W, C,
+                            WIN, ptr(g), bfc, C, st)
+    t_g = time_calls(gather_f, iters, warm)
+    dg = torch.randn(n, L, C, device=device).to(bf)
+    dx = torch.empty_like(x)
+    gather_b = lambda: call("dsw_gather_bwd", ptr(dg), bfc, ptr(sel.cellmap), ptr(sel.win_h1), ptr(sel.win_w1), n, B, H, W, C,
+                            WIN, C, ptr(dx), f32c, 0, st)
+    t_gb = time_calls(gather_b, iters, warm)
     by_g = n * C * ((WIN + 1) ** 2 * 4 + L * 2)
-    by_gb = n * C * L * 2 + B_PER_GPU * HW * HW * C * 4
+    by_gb = n * C * L * 2 + B * H * W * C * 4
     out["gather_fwd"] = dict(bound="hbm", achieved=by_g / t_g / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t_g * 1e6,
                              algorithmic=by_g)
     out["gather_bwd"] = dict(bound="hbm", achieved=by_gb / t_gb / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t_gb * 1e6,
                              algorithmic=by_gb)
-    after = torch.randn(n, L, C, device=device).to(bf).requires_grad_()
-    y = K.scatter_mean_residual(xs, after, sel, WIN)
-    t_sc = time_calls(lambda: K.scatter_mean_residual(x, after.detach(), sel, WIN), iters, warm)
-    dy = torch.randn_like(y)
-    t_scb = time_calls(lambda: torch.autograd.grad(y, (xs, after), dy, retain_graph=True), iters, warm)
-    by_sc = n * C * L * 2 + 2 * B_PER_GPU * HW * HW * C * 4
-    by_scb = 2 * B_PER_GPU * HW * HW * C * 4 + n * C * L * (2 + 2) + n * C * (WIN + 1) ** 2 * 4
+    after = torch.randn(n, L, C, device=device).to(bf)
+    y = torch.empty_like(x)
+    gd, sdl = sel.gates_delta.float().contiguous(), sel.scores_delta.float().contiguous()
+    scatter_f = lambda: call("dsw_scatter_mean_fwd", ptr(x), f32c, ptr(after), bfc, ptr(gd), ptr(sdl), ptr(sel.cellmap),
+                             ptr(sel.win_h1), ptr(sel.win_w1), n, B, H, W, C, WIN, C, ptr(y), f32c, st)
+    t_sc = time_calls(scatter_f, iters, warm)
+    dy = torch.randn_like(x)
+    d_after = torch.empty_like(after)
+    dgs = torch.empty(2, n, device=device)
+    partial = torch.empty(2 * n * WIN, device=device)
+    scatter_b = lambda: call("dsw_scatter_mean_bwd", ptr(dy), f32c, ptr(x), f32c, ptr(after), bfc, ptr(gd), ptr(sdl),
+                             ptr(sel.cellmap), ptr(sel.win_b), ptr(sel.win_h1), ptr(sel.win_w1), n, B, H, W, C, WIN, C,
+                             ptr(dx), f32c, 0, ptr(d_after), bfc, C, ptr(dgs[0]), ptr(dgs[1]), ptr(partial), st)
+    t_scb = time_calls(scatter_b, iters, warm)
+    by_sc = n * C * L * 2 + 2 * B * H * W * C * 4
+    by_scb = 2 * B * H * W * C * 4 + n * C * L * (2 + 2) + n * C * (WIN + 1) ** 2 * 4
     out["scatter_mean_fwd"] = dict(bound="hbm", achieved=by_sc / t_sc / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                    us=t_sc * 1e6, algorithmic=by_sc)
     out["scatter_mean_bwd"] = dict(bound="hbm", achieved=by_scb / t_scb / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                   us=t_scb * 1e6, algorithmic=by_scb)
-    for v in out.values():
-        if "achieved" in v:
-            v["frac"] = v["achieved"] / v["peak"]
-    return out
+                                   us=t_scb * 1e6, algorithmic=by_scb, note="three kernels: dx, window side, reduce")
 
 
 def pmc_traffic(kernel):

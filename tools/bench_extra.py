@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Measurements beyond the driver's bench line (one MI355X, synthetic data):
+
+  D  DSWT default model, x4 SR of one 960x540 LR image (-> 3840x2160), tiles of 256x256 LR + 32 px
+     halo, eval mode, bf16 autocast: output megapixels / s.
+  E  config B with num_win_selected 0.5 / 1.0 (256 / 512 windows of 16x16, gates open, random
+     offsets): gather / scatter kernels against the HBM roofline.
+  C  MSFT (dim 192, levels 2, w 8), x4 training step (fwd + bwd, bf16 autocast) on 64x64 patches,
+     batch 8: patches / s.
+
+  python tools/bench_extra.py [D] [E] [C]   -> one JSON line per workload
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def sync_time(fn, iters, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def workload_d(dev):
+    from visiontransformer_amd.models import DSWT_DEFAULT, dswt_from_config
+    from visiontransformer_amd.parallel import plan_tiles, tiled_super_resolve
+    torch.manual_seed(0)
+    model = dswt_from_config(DSWT_DEFAULT).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    lr = (torch.randn(1, 3, 540, 960, device=dev, generator=g) * 0.5).clamp_(-1, 1)
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return tiled_super_resolve(model, lr, 4, tile=256, halo=32)
+
+    out = run()
+    assert out.shape == (1, 3, 2160, 3840) and torch.isfinite(out).all()
+    dt = sync_time(run, 3)
+    return {"metric": "x4 SR output megapixels/sec (fwd)", "value": out.shape[2] * out.shape[3] / 1e6 / dt, "unit": "MP/s",
+            "n_gpus": 1, "s_per_image": dt, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "D: DSWT default (14.6 M params), 960x540 LR -> 3840x2160, %d tiles of 256x256 LR + 32 px halo"
+                                   % len(plan_tiles(540, 960, 256, 32))}}
+
+
+def workload_e(dev):
+    out = {}
+    for frac, k in ((0.5, 8), (1.0, 16)):
+        ks = bench.kernel_rooflines(dev, iters=20, warm=3, k=k, attention=False)
+        out["num_win_selected=%.1f (%d windows)" % (frac, bench.B_PER_GPU * k)] = {
+            n: {"us": round(v["us"], 1), "GB/s": round(v.get("achieved", 0.0), 1), "frac_of_8TB/s": round(v.get("frac", 0.0), 3)}
+            for n, v in ks.items()}
+    return {"metric": "gather / scatter kernels vs HBM roofline", "config": {"workload": "E: B=32, 64x64, C=180, w=16, gates open"},
+            "kernels": out}
+
+
+def workload_c(dev):
+    from visiontransformer_amd.models import MSFT_CONFIG_C, MSFTransformer
+    torch.manual_seed(0)
+    cfg = dict(MSFT_CONFIG_C)
+    model = MSFTransformer(**cfg).to(dev).train()
+    for m in model.modules():
+        if hasattr(m, "attn_drop"):
+            m.attn_drop = 0.0
+    B = 8
+    x = torch.randn(B, 3, 64, 64, device=dev)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(x)
+        y.float().mean().backward()
+        model.zero_grad(set_to_none=True)
+
+    dt = sync_time(step, 5, warm=2)
+    return {"metric": "training patches/sec (MSFT x4, fwd+bwd)", "value": B / dt, "unit": "patches/s", "n_gpus": 1,
+            "ms_per_step": dt * 1e3, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C: MSFT dim 192, levels 2, w 8, 8 blocks x 3, batch %d of 64x64 LR" % B}}
+
+
+def main():
+    dev = torch.device("cuda:0")
+    from visiontransformer_amd import _lib
+    _lib.load()
+    which = [a.upper() for a in sys.argv[1:]] or ["D", "E", "C"]
+    for w in which:
+        print(json.dumps({"D": workload_d, "E": workload_e, "C": workload_c}[w](dev)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -45,8 +45,9 @@ template <typename T, int WS, int DP> struct BwdCfg {
     static constexpr int N_EPI = BF ? NW * 32 * QS : 0;  // the bf16 epilogue's per-wave row slices reuse the dS region
     static constexpr int N_DS = N_DS0 > N_EPI ? N_DS0 : N_EPI;
     static constexpr int N_QB = 32 * QS;
+    static constexpr bool DBUF = BF;  // two staging buffers for the Q / dO block: one barrier less per block
     static constexpr size_t lds_bytes(bool bias) {
-        return (size_t)(N_K + N_DS + 2 * N_QB) * sizeof(T) + (size_t)2 * L * sizeof(float) +
+        return (size_t)(N_K + N_DS + (DBUF ? 4 : 2) * N_QB) * sizeof(T) + (size_t)2 * L * sizeof(float) +
                (KSPLIT > 1 ? (size_t)QTILES * 64 * 4 * sizeof(float) : 0) +
                (bias ? (size_t)(bias_lds<WS>::FLOATS + (WS == 16 ? NW * BGW_ROWS * BGW_STRIDE : 0)) * sizeof(float) : 0);
     }
@@ -125,9 +126,11 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *Kl = reinterpret_cast<T *>(smem);   // bf16: K^T [DP][KTS];  f32: K [L][QS]
     T *dSs = Kl + Cfg::N_K;                // bf16: dS^T [L][DSS], 8-byte chunks swizzled;  f32: dS [32][SS]
-    T *Qb = dSs + Cfg::N_DS;               // [32][QS]
+    T *Qb = dSs + Cfg::N_DS;               // [32][QS]  (DBUF: second pair of buffers 2*N_QB further on)
     T *dOb = Qb + Cfg::N_QB;               // [32][QS]
-    float *ndelta_s = reinterpret_cast<float *>(dOb + Cfg::N_QB);  // [L]  -delta
+    constexpr bool DBUF = Cfg::DBUF;
+    constexpr int BUF = 2 * Cfg::N_QB;     // elements from one (Qb, dOb) pair to the other
+    float *ndelta_s = reinterpret_cast<float *>(Qb + (DBUF ? 4 : 2) * Cfg::N_QB);  // [L]  -delta
     float *nlse_s = ndelta_s + L;                                   // [L]  -lse * log2(e)
     float *qpart = nlse_s + L;                                      // KSPLIT = 2: [QTILES][64] float4
     float *tb = qpart + (KSPLIT > 1 ? QTILES * 64 * 4 : 0);         // BIAS: [TBF]
@@ -284,8 +287,9 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     };
     // Q is stored times scale*log2(e): S comes out of the MFMA in the base-2 domain, and dK picks
     // up the inverse factor once, in the epilogue.
-    auto store_block = [&]() {
+    auto store_block = [&](int buf) {
         if (!stager) return;
+        T *Qb = dSs + Cfg::N_DS + buf * BUF, *dOb = Qb + Cfg::N_QB;  // shadow: the pair being filled
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = i * RS + r0;
@@ -341,14 +345,20 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
 
     float bg_carry_a = 0.f, bg_carry_w = 0.f;  // w = 16 bias gradient: (G = 1, kip = 0) sums of the previous block
     load_block(0);
+    if constexpr (DBUF) store_block(0);
     for (int qb = 0; qb < NT; ++qb) {
-        lds_barrier();  // previous block's LDS reads are done (first pass: prologue writes land)
+        // previous block's LDS reads are done (first pass: prologue writes land); with two staging
+        // buffers this block's Q / dO rows were stored during the previous block and are now visible
+        lds_barrier();
         if constexpr (KSPLIT > 1) {
             if (qb > 0 && khalf == 0) finish_dq(qb - 1, qkeep, true);  // the upper key half's partial has landed
         }
-        store_block();
-        lds_barrier();
+        if constexpr (!DBUF) {
+            store_block(0);
+            lds_barrier();
+        }
         if (qb + 1 < NT) load_block(qb + 1);
+        const int cur = DBUF ? (qb & 1) * BUF : 0;  // staging pair of this block
 
         // table entry of (q, key): (qi-ki+w-1)*TS + (qj-kj+w-1); q = qb*32 + rho(r) + 4hh
         const int lane_base = (WS - 1) * (TS + 1) - ki * TS - kj + 4 * hh + (qb * 32 / WS) * TS;
@@ -366,16 +376,16 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         if constexpr (BF) {
 #pragma unroll
             for (int s = 0; s < DP / 16; ++s) {
-                const uint4 qa = *reinterpret_cast<const uint4 *>(Qb + l31 * QS + 16 * s + 8 * hh);
-                const uint4 ga = *reinterpret_cast<const uint4 *>(dOb + l31 * QS + 16 * s + 8 * hh);
+                const uint4 qa = *reinterpret_cast<const uint4 *>(Qb + cur + l31 * QS + 16 * s + 8 * hh);
+                const uint4 ga = *reinterpret_cast<const uint4 *>(dOb + cur + l31 * QS + 16 * s + 8 * hh);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(qa), as_bf16x8(kfb[s]), sacc, 0, 0, 0);
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ga), as_bf16x8(vfb[s]), pacc, 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int s4 = 0; s4 < DP / 8; ++s4) {
-                const float4 qa = *reinterpret_cast<const float4 *>(Qb + l31 * QS + hh * (DP / 2) + 4 * s4);
-                const float4 ga = *reinterpret_cast<const float4 *>(dOb + l31 * QS + hh * (DP / 2) + 4 * s4);
+                const float4 qa = *reinterpret_cast<const float4 *>(Qb + cur + l31 * QS + hh * (DP / 2) + 4 * s4);
+                const float4 ga = *reinterpret_cast<const float4 *>(dOb + cur + l31 * QS + hh * (DP / 2) + 4 * s4);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kff[4 * s4 + 0], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kff[4 * s4 + 1], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kff[4 * s4 + 2], sacc, 0, 0, 0);
@@ -447,8 +457,8 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
                 for (int u = 0; u < DP / 32; ++u) {
                     // A operands dO^T, Q^T (row = head dim 32u + l31): element j is query
                     // 16s + 8(j>>2) + 4hh + (j&3), fetched as two transposing reads of the row-major block
-                    const uint2 g0 = lds_read_tr16(gtr + (16 * s) * QS + 32 * u), g1 = lds_read_tr16(gtr + (16 * s + 8) * QS + 32 * u);
-                    const uint2 q0 = lds_read_tr16(qtr + (16 * s) * QS + 32 * u), q1 = lds_read_tr16(qtr + (16 * s + 8) * QS + 32 * u);
+                    const uint2 g0 = lds_read_tr16(gtr + cur + (16 * s) * QS + 32 * u), g1 = lds_read_tr16(gtr + cur + (16 * s + 8) * QS + 32 * u);
+                    const uint2 q0 = lds_read_tr16(qtr + cur + (16 * s) * QS + 32 * u), q1 = lds_read_tr16(qtr + cur + (16 * s + 8) * QS + 32 * u);
                     dVacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(g0.x, g0.y, g1.x, g1.y)), as_bf16x8(pb), dVacc[u], 0, 0, 0);
                     dKacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(q0.x, q0.y, q1.x, q1.y)), as_bf16x8(db), dKacc[u], 0, 0, 0);
                 }
@@ -460,14 +470,17 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
             for (int r = 0; r < 16; ++r) {
 #pragma unroll
                 for (int u = 0; u < DP / 32; ++u) {
-                    const float ga = dOb[(rho(r) + 4 * hh) * QS + 32 * u + l31];
-                    const float qa = Qb[(rho(r) + 4 * hh) * QS + 32 * u + l31];
+                    const float ga = dOb[cur + (rho(r) + 4 * hh) * QS + 32 * u + l31];
+                    const float qa = Qb[cur + (rho(r) + 4 * hh) * QS + 32 * u + l31];
                     dVacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, sacc[r], dVacc[u], 0, 0, 0);
                     dKacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, pacc[r], dKacc[u], 0, 0, 0);
                 }
             }
         }
-        lds_barrier();  // the whole dS block is in LDS
+        if constexpr (DBUF) {
+            if (qb + 1 < NT) store_block((qb + 1) & 1);  // nobody reads that pair any more
+        }
+        lds_barrier();  // the whole dS block (and the next block's rows) is in LDS
 
         // element (query q of the block, key k) of the dS image
         auto ds_at = [&](int q, int k) -> float {

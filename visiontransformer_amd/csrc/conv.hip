@@ -17,11 +17,18 @@ __device__ __forceinline__ float silu_grad(float v) {
     const float s = 1.f / (1.f + __expf(-v));
     return s * (1.f + v * (1.f - s));
 }
+// four fused multiply-adds as two packed ones (v_pk_fma_f32 does two lanes' worth per issue slot)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
-    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+    const f32x2_t lo = __builtin_elementwise_fma(f32x2_t{a.x, a.y}, f32x2_t{b.x, b.y}, f32x2_t{c.x, c.y});
+    const f32x2_t hi = __builtin_elementwise_fma(f32x2_t{a.z, a.w}, f32x2_t{b.z, b.w}, f32x2_t{c.z, c.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 __device__ __forceinline__ float4 fma4s(float4 a, float s, float4 c) {
-    return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+    const f32x2_t ss = {s, s};
+    const f32x2_t lo = __builtin_elementwise_fma(f32x2_t{a.x, a.y}, ss, f32x2_t{c.x, c.y});
+    const f32x2_t hi = __builtin_elementwise_fma(f32x2_t{a.z, a.w}, ss, f32x2_t{c.z, c.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,6 +481,8 @@ __global__ __launch_bounds__(256) void sd_bwd_w2_kernel(const float *__restrict_
 // dx[b,y,x,ci] = sum_{o,taps} w0[o][ci][tap] * dt0[b, y-(a-1), x-(bb-1), o].  Same row-segment / walk-down
 // mapping as the depthwise kernel; the channel quad's 36 weight vectors live in registers and the
 // dt0 window (16 B per pixel, shared by all channel quads of the pixel) comes from the vector cache.
+// (staging the 36 weight vectors costs a block about as much as 16 rows of work: long walks)
+constexpr int DX_ROWS = 32;
 template <typename TO, bool ACC>
 __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__restrict__ dt0, const float *__restrict__ w0,
                                                                int H, int W, int C, int segs, TO *__restrict__ dx) {
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__re
         for (int t = 0; t < 9; ++t) w0s[(t * 4 + o) * C + ci] = w0[(size_t)i * 9 + t];
     }
     __syncthreads();
-    const int CV = C >> 2, rowq = W * CV, hblocks = (H + CW_ROWS - 1) / CW_ROWS;
+    const int CV = C >> 2, rowq = W * CV, hblocks = (H + DX_ROWS - 1) / DX_ROWS;
     const int seg = blockIdx.x % segs, hb = (blockIdx.x / segs) % hblocks, b = blockIdx.x / (segs * hblocks);
     const int i = seg * CV_THREADS + threadIdx.x;
     if (i >= rowq) return;
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__re
     TO *dst = dx + (size_t)b * H * W * C + (size_t)i * 4;
     const size_t rs = (size_t)W * C;
     const bool has_l = xx > 0, has_r = xx < W - 1;
-    const int h0 = hb * CW_ROWS, h1 = min(h0 + CW_ROWS, H);
+    const int h0 = hb * DX_ROWS, h1 = min(h0 + DX_ROWS, H);
     // g[k]: dt0 at columns xx-1, xx, xx+1; rows y-1 (r0), y (r1), y+1 (r2).  Tap (a, bb) pairs with row y+1-a, column xx+1-bb.
     float4 r0[3], r1[3], r2[3];
     auto load_row = [&](int yy, float4(&r)[3]) {
@@ -516,6 +525,7 @@ __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__re
     for (int h = h0; h < h1; ++h) {
         load_row(h + 1, r2);
         float4 acc = f4zero();
+        if constexpr (ACC) acc = io<TO>::ld4(dst + (size_t)h * rs);  // add into an existing dx
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb) {
             const float4 g2 = r2[2 - bb], g1 = r1[2 - bb], g0 = r0[2 - bb];  // a = 0, 1, 2
@@ -526,7 +536,6 @@ __global__ __launch_bounds__(CV_THREADS) void sd_bwd_dx_kernel(const float *__re
             acc = fma4s(wq[6 + bb][0], g0.x, acc), acc = fma4s(wq[6 + bb][1], g0.y, acc);
             acc = fma4s(wq[6 + bb][2], g0.z, acc), acc = fma4s(wq[6 + bb][3], g0.w, acc);
         }
-        if constexpr (ACC) acc = acc + io<TO>::ld4(dst + (size_t)h * rs);  // add into an existing dx
         io<TO>::st4(dst + (size_t)h * rs, acc);
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb) r0[bb] = r1[bb], r1[bb] = r2[bb];
@@ -763,7 +772,8 @@ extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x
         rc = set_lds_attr(kern, lds, "dsw_sparse_disc_bwd");
         if (rc) return rc;
         const int segs = walk_segs(W, C);
-        hipLaunchKernelGGL(kern, dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds, st, dt0, w0, H, W, C, segs, (TO *)dx);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B * ((H + DX_ROWS - 1) / DX_ROWS) * segs), dim3(CV_THREADS), lds, st, dt0, w0, H, W, C,
+                           segs, (TO *)dx);
     });
     DSW_DISPATCH_DTYPE(x_dtype, TX, {
         auto kern0 = sd_bwd_w0_kernel<TX>;
