@@ -257,6 +257,29 @@ int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, i
                   long long dst_ld, long long rows, long long src_rows, int cols, int zero_pad,
                   void *stream);
 
+/* The projections of the attention modules (the nn.Linear calls at DSwinT_arch.py:303, :308, :334,
+ * :337 and msft_arch.py:128, :141) and their input gradients as one bf16 MFMA kernel:
+ *
+ *   c[m][n] = sum_{k < K} a[m][k] * w_p[n][k]  (+ bias[n] for n < N),   m < M, n < ncols
+ *
+ * dsw_weight_prep turns an nn.Linear weight [N][K] (fp32 or bf16) into the operands: w_p
+ * [ceil64(N)][ceil64(K)] and its transpose w_pt [ceil64(K)][ceil64(N)], bf16, zero outside N x K
+ * (either pointer may be NULL).  The forward projection multiplies by w_p, the input gradient
+ * dx = dy . W multiplies by w_pt.
+ *   a:      [M][lda] fp32 or bf16; fp32 values are rounded to bf16 on load.  K % 4 == 0 (fp32) or
+ *           K % 8 == 0 (bf16); lda a multiple of 4 / 8 elements; 16-byte aligned.
+ *   w_p:    bf16 [wrows][ldw], ldw >= ceil64(K); rows >= wrows read as zero.
+ *   bias:   fp32 [N] or NULL.
+ *   c:      [M][ldc] fp32 or bf16, columns 0..ncols-1 written (ncols % 4 == 0): with ncols =
+ *           ceil64(N) and a zero-padded w_p the padding columns come out as zeros.
+ *   a_copy: NULL, or bf16 [M][lda_copy]: receives a rounded to bf16 with the columns K..ceil64(K)-1
+ *           zeroed (the operand the weight-gradient GEMM wants), saving a separate cast pass.
+ * K <= 192 takes any ncols; K > 192 is run in slabs of 64/128/192 columns of a. */
+int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w_p, void *w_pt, void *stream);
+int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
+               int ldw, const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols,
+               void *a_copy, long long lda_copy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

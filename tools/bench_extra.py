@@ -75,11 +75,14 @@ def workload_c(dev):
             m.attn_drop = 0.0
     B = 8
     x = torch.randn(B, 3, 64, 64, device=dev)
+    target = torch.randn(B, 3, 256, 256, device=dev)
 
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = model(x)
-        y.float().mean().backward()
+        # an L1 loss as in training: a dense gradient (the gradient of a plain mean() is a stride-0
+        # expansion, which sends MIOpen to its naive kernels)
+        torch.nn.functional.l1_loss(y.float(), target).backward()
         model.zero_grad(set_to_none=True)
 
     dt = sync_time(step, 5, warm=2)

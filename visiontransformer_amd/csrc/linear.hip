@@ -1,0 +1,369 @@
+// The Linear projections of the attention modules (DSwinT_arch.py:303, :308, :334, :337) as one
+// MFMA kernel for their shape: millions of rows, a few hundred columns on either side.
+//
+//   C[M, ncols] = A[M, K] . Wp[ncols, Kp]^T (+ bias)
+//
+// A is streamed from HBM exactly once per block column, in whatever dtype / row stride the producer
+// left it (fp32 activations are rounded to bf16 on the way into LDS; an optional bf16 copy of A in
+// padded rows is written on the side for the weight-gradient GEMM), the weight is a small padded
+// bf16 matrix that stays in L2, and the bias add and the output cast happen in the accumulators.
+//
+// Work split: a workgroup owns 128 rows of A (32 per wave).  The rows' k-slab (up to 192 wide) goes
+// through LDS once and is then held as MFMA operands in registers, while the weight is walked in
+// chunks of 64 output columns through LDS: one 16-byte LDS read per MFMA.
+//   * K <= 192 (forward projections): one slab, any number of column chunks, each stored as soon as
+//     it is complete.
+//   * K > 192 (input gradients, K = 3C): several slabs; the accumulators of up to three chunks
+//     (192 columns) persist across slabs, wider outputs are split over blockIdx.y.
+#include "attn_common.hpp"
+
+namespace dsw {
+namespace {
+
+constexpr int LN_BM = 128;       // rows of A per workgroup
+constexpr int LN_CN = 64;        // output columns per chunk
+constexpr int LN_THREADS = 256;  // 4 waves, 32 rows each
+constexpr int LN_MAXACC = 3;     // chunks whose accumulators persist across k slabs
+
+template <int KS> struct LnCfg {
+    static constexpr int LS = KS + 8;  // LDS row stride in elements: 16-byte reads of 32 rows fall on distinct banks
+    static constexpr int NKS = KS / 16;
+    static constexpr int A_PIECES = 4 * (KS / 64);  // 8-element pieces per thread: A slab, weight chunk
+    static constexpr int B_PIECES = 2 * (KS / 64);
+    static constexpr size_t LDS = (size_t)(LN_BM + LN_CN) * LS * sizeof(bf16_t);
+};
+
+// Buffer descriptors: loads past the end of the described range return zero, which takes care of the rows beyond M, of weight rows beyond the matrix and of an
+// absent bias without a branch.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// 8 consecutive elements of a row of A as they come from memory (k .. k+7 of a row with K valid
+// columns: the part at or beyond K reads as zero)
+template <typename T> struct a_piece;
+template <> struct a_piece<float> {
+    uint4 lo, hi;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        lo = buf_load16(r, voff, soff);
+        hi = buf_load16(r, voff + 16, soff);
+    }
+    __device__ __forceinline__ uint4 pack(int k, int K) const {
+        const bool l = k + 4 <= K, h = k + 8 <= K;
+        uint4 v;
+        v.x = l ? pack_bf16(__uint_as_float(lo.x), __uint_as_float(lo.y)) : 0u;
+        v.y = l ? pack_bf16(__uint_as_float(lo.z), __uint_as_float(lo.w)) : 0u;
+        v.z = h ? pack_bf16(__uint_as_float(hi.x), __uint_as_float(hi.y)) : 0u;
+        v.w = h ? pack_bf16(__uint_as_float(hi.z), __uint_as_float(hi.w)) : 0u;
+        return v;
+    }
+};
+template <> struct a_piece<bf16_t> {  // K % 8 == 0
+    uint4 v;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { v = buf_load16(r, voff, soff); }
+    __device__ __forceinline__ uint4 pack(int k, int K) const { return k + 8 <= K ? v : make_uint4(0u, 0u, 0u, 0u); }
+};
+
+// One chunk of 64 output columns against the wave's 32 rows: 2 MFMAs per k step, their weight
+// operands read from LDS one group of two k steps ahead (the scheduling fences keep the compiler
+// from hoisting every read of the chunk to the top, which costs 100 registers).
+template <int NKS, int LS>
+__device__ __forceinline__ void chunk_mfma(const bf16_t *brow, const bf16x8 (&afr)[NKS], f32x16 (&acc)[2]) {
+    constexpr int NG = NKS / 2;
+    bf16x8 w[2][4];
+    auto read_group = [&](int g, bf16x8(&dst)[4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                dst[2 * j + t] = as_bf16x8(*reinterpret_cast<const uint4 *>(brow + t * 32 * LS + (2 * g + j) * 16));
+    };
+    read_group(0, w[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) read_group(g + 1, w[(g + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#ifdef LN_ABL_NOMFMA
+                acc[t][0] += __builtin_bit_cast(f32x4, w[g & 1][2 * j + t])[0];
+#else
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][2 * j + t], afr[2 * g + j], acc[t], 0, 0, 0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename TA, typename TC, int KS, bool PERSIST>
+__global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
+    const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
+    const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
+    long long lda_copy, int chunks_per_block) {
+    using cfg = LnCfg<KS>;
+    constexpr int LS = cfg::LS, NKS = cfg::NKS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    bf16_t *As = reinterpret_cast<bf16_t *>(smem);
+    bf16_t *Bs = As + LN_BM * LS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * LN_BM;
+    const int rows = min(M - m0, LN_BM);
+    const int total_chunks = (ncols + LN_CN - 1) / LN_CN;
+    const int nc0 = blockIdx.y * chunks_per_block;
+    const int nch = min(chunks_per_block, total_chunks - nc0);  // >= 1 by the grid's construction
+
+    // staging: 8 threads per row, 8 elements each = 64 columns; a slab is KS / 64 such column groups
+    // (immediate offsets) over 4 (A: 128 rows) or 2 (weight chunk: 64 rows) row groups
+    const int srow = tid >> 3, scol = (tid & 7) * 8;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + (size_t)m0 * lda, ((size_t)(rows - 1) * lda + K) * sizeof(TA));
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(Wp, (size_t)wrows * ldw * sizeof(bf16_t));
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(bias, bias != nullptr ? (size_t)N * sizeof(float) : 0);
+    // bf16 copy of A: plain stores from the first block column
+    bf16_t *const copy_row = a_copy != nullptr && blockIdx.y == 0 ? a_copy + (size_t)(m0 + srow) * lda_copy + scol : nullptr;
+    unsigned a_off[4], w_off[2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) a_off[p] = (unsigned)(((size_t)(p * 32 + srow) * lda + scol) * sizeof(TA));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) w_off[q] = (unsigned)(((q * 32 + srow) * ldw + scol) * sizeof(bf16_t));
+
+    f32x16 acc[PERSIST ? LN_MAXACC : 1][2];
+#pragma unroll
+    for (int c = 0; c < (PERSIST ? LN_MAXACC : 1); ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+
+    // Results leave through LDS: a lane holds 4 consecutive columns of one row per register group, which
+    // stored directly would touch 32 rows with 16 bytes each per instruction.  Each wave lays its tile
+    // out in its own 32 rows of As (spent once the operands are in registers; no other wave reads
+    // them) and stores whole 128-byte row segments, 8 rows per instruction.
+    auto store_tiles = [&](const f32x16(&a)[2], int chunk) {
+        constexpr int SW = 128 / sizeof(TC);  // columns per pass
+        constexpr int TPP = SW / 32;          // 32-column tiles per pass: 2 (bf16), 1 (fp32)
+        constexpr int PC = 16 / sizeof(TC);   // columns per 16-byte piece
+        constexpr int SROW = 144;             // staging row stride in bytes
+        unsigned char *stg = reinterpret_cast<unsigned char *>(As + wave * 32 * LS);
+        const int nb = (nc0 + chunk) * LN_CN;
+        uint4 bv[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[t][g] = buf_load16(rs_b, (unsigned)(nb + 4 * hh + t * 32 + 8 * g) * 4u, 0u);
+#pragma unroll
+        for (int ps = 0; ps < 2 / TPP; ++ps) {
+#pragma unroll
+            for (int tt = 0; tt < TPP; ++tt) {
+                const int t = ps * TPP + tt;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = make_float4(a[t][4 * g] + __uint_as_float(bv[t][g].x), a[t][4 * g + 1] + __uint_as_float(bv[t][g].y),
+                                                 a[t][4 * g + 2] + __uint_as_float(bv[t][g].z), a[t][4 * g + 3] + __uint_as_float(bv[t][g].w));
+                    io<TC>::st4(reinterpret_cast<TC *>(stg + l31 * SROW) + tt * 32 + 8 * g + 4 * hh, v);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + (lane >> 3), m = m0 + wave * 32 + row;
+                const int col = nb + ps * SW + (lane & 7) * PC;
+                const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * SROW + (lane & 7) * 16);
+                TC *dst = C + (size_t)m * ldc + col;
+#ifdef LN_ABL_NOSTORE
+                if (m < M && v.x == 0x12345u) {
+#else
+                if (m < M) {
+#endif
+                    if (col + PC <= ncols) *reinterpret_cast<uint4 *>(dst) = v;
+                    else if (sizeof(TC) == 2 && col + 4 <= ncols) *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    };
+
+    uint4 breg[cfg::B_PIECES];
+    auto load_b = [&](int slab, int chunk) {
+        const unsigned soff = (unsigned)(((size_t)(nc0 + chunk) * LN_CN * ldw + slab * KS) * sizeof(bf16_t));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+#ifdef LN_ABL_NOWLOAD
+            for (int j = 0; j < KS / 64; ++j) breg[q * (KS / 64) + j] = make_uint4(soff, q, j, 1u);
+#else
+            for (int j = 0; j < KS / 64; ++j) breg[q * (KS / 64) + j] = buf_load16(rs_w, w_off[q] + j * 128, soff);
+#endif
+    };
+    auto write_b = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < KS / 64; ++j)
+                *reinterpret_cast<uint4 *>(Bs + (q * 32 + srow) * LS + j * 64 + scol) = breg[q * (KS / 64) + j];
+    };
+
+    for (int slab = 0; slab < nslab; ++slab) {
+        {
+            a_piece<TA> ap[cfg::A_PIECES];
+            const unsigned soff = (unsigned)(slab * KS * sizeof(TA));
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int j = 0; j < KS / 64; ++j) ap[p * (KS / 64) + j].load(rs_a, a_off[p] + j * 64 * (unsigned)sizeof(TA), soff);
+            if (slab == 0) load_b(0, 0);
+            lds_barrier();  // the previous slab's reads of As / Bs are over
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int j = 0; j < KS / 64; ++j) {
+                    const uint4 v = ap[p * (KS / 64) + j].pack(slab * KS + j * 64 + scol, K);
+                    *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * LS + j * 64 + scol) = v;
+                    if (copy_row != nullptr && p * 32 + srow < rows)
+                        *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + slab * KS + j * 64) = v;
+                }
+            write_b();
+        }
+        lds_barrier();
+        // this wave's 32 rows of the slab as MFMA operands
+        bf16x8 afr[NKS];
+        {
+            const bf16_t *arow = As + (wave * 32 + l31) * LS + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) afr[ks] = as_bf16x8(*reinterpret_cast<const uint4 *>(arow + ks * 16));
+        }
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            if (chunk > 0) {
+                lds_barrier();
+                write_b();
+                lds_barrier();
+            }
+            if (chunk + 1 < nch) load_b(slab, chunk + 1);
+            else if (slab + 1 < nslab) load_b(slab + 1, 0);
+            const bf16_t *brow = Bs + l31 * LS + 8 * hh;
+            if constexpr (PERSIST) {
+                // chunk is uniform; a switch keeps the accumulators in registers
+#pragma unroll
+                for (int cc = 0; cc < LN_MAXACC; ++cc)
+                    if (cc == chunk) chunk_mfma<NKS, LS>(brow, afr, acc[cc]);
+            } else {
+                chunk_mfma<NKS, LS>(brow, afr, acc[0]);
+                store_tiles(acc[0], chunk);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][t][r] = 0.f;
+            }
+        }
+    }
+    if constexpr (PERSIST) {
+#pragma unroll
+        for (int cc = 0; cc < LN_MAXACC; ++cc)
+            if (cc < nch) store_tiles(acc[cc], cc);
+    }
+}
+
+// w [N, K] (fp32 or bf16) -> zero-padded bf16 copies: wp [Np, Kp] and its transpose wpt [Kp, Np]
+template <typename TW>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const TW *__restrict__ w, int N, int K, int Np, int Kp,
+                                                          bf16_t *__restrict__ wp, bf16_t *__restrict__ wpt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np * Kp) return;
+    const int n = i / Kp, k = i - n * Kp;
+    const bf16_t v = (n < N && k < K) ? f32_to_bf16(io<TW>::ld(w + (size_t)n * K + k)) : (bf16_t)0;
+    if (wp != nullptr) wp[i] = v;
+    if (wpt != nullptr) wpt[(size_t)k * Np + n] = v;
+}
+
+int set_lds(const void *kern, size_t lds, const char *who) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DSW_ELAUNCH, "%s: LDS attribute: %s", who, hipGetErrorString(e));
+    }
+    return DSW_OK;
+}
+
+template <typename TA, typename TC, int KS>
+int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
+                  void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, hipStream_t st) {
+    using cfg = LnCfg<KS>;
+    const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
+    int cpb;
+    if (nslab > 1) {
+        cpb = total < LN_MAXACC ? total : LN_MAXACC;
+    } else {
+        // enough workgroups for two per CU; every extra block column re-reads A (from L2 at best)
+        int gy = (512 + mt - 1) / mt;
+        gy = gy < 1 ? 1 : (gy > total ? total : gy);
+        cpb = (total + gy - 1) / gy;
+    }
+    const dim3 grid(mt, (total + cpb - 1) / cpb);
+    int rc;
+    if (nslab > 1) {
+        auto kern = linear_nt_kernel<TA, TC, KS, true>;
+        if ((rc = set_lds((const void *)kern, cfg::LDS, "dsw_linear"))) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), cfg::LDS, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb);
+    } else {
+        auto kern = linear_nt_kernel<TA, TC, KS, false>;
+        if ((rc = set_lds((const void *)kern, cfg::LDS, "dsw_linear"))) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), cfg::LDS, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb);
+    }
+    return check_launch("linear_nt_kernel");
+}
+
+}  // namespace
+}  // namespace dsw
+
+using namespace dsw;
+
+extern "C" int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w_p, void *w_pt, void *stream) {
+    if (N <= 0 || K <= 0) return fail(DSW_EINVAL, "dsw_weight_prep: bad sizes N=%d K=%d", N, K);
+    DSW_REQUIRE(w && (w_p || w_pt), "dsw_weight_prep: null pointer");
+    const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64;
+    DSW_DISPATCH_DTYPE(w_dtype, TW, {
+        hipLaunchKernelGGL(weight_prep_kernel<TW>, dim3((Np * Kp + 255) / 256), dim3(256), 0, as_stream(stream), (const TW *)w, N, K, Np,
+                           Kp, (bf16_t *)w_p, (bf16_t *)w_pt);
+    });
+    return check_launch("weight_prep_kernel");
+}
+
+extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                          const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, void *a_copy, long long lda_copy,
+                          void *stream) {
+    if (M <= 0 || M > 0x7fffff00LL || K <= 0 || ncols <= 0 || wrows <= 0)
+        return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
+    DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
+    const int Kp = (K + 63) / 64 * 64;
+    const int a_align = a_dtype == DSW_F32 ? 4 : 8;
+    if (K % a_align || lda < K || lda % a_align || ((uintptr_t)a & 15))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear: A needs K and its row stride to be multiples of %d elements, the stride >= K, and a "
+                                      "16-byte aligned base (K=%d lda=%lld)", a_align, K, lda);
+    if (ldw < Kp || ldw % 8 || ((uintptr_t)w_p & 15))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear: the weight needs rows of >= %d elements (K rounded up to 64), a multiple of 8 (ldw=%d)", Kp, ldw);
+    if (ncols % 4 || ldc < ncols || ldc % 4 || ((uintptr_t)c & 15))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear: C needs ncols %% 4 == 0, ldc %% 4 == 0, ldc >= ncols, a 16-byte aligned base (ncols=%d ldc=%lld)",
+                    ncols, ldc);
+    if (bias != nullptr && (N <= 0 || N % 4 || N > ncols || ((uintptr_t)bias & 15)))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear: bias needs N %% 4 == 0, N <= ncols, a 16-byte aligned base (N=%d ncols=%d)", N, ncols);
+    if (a_copy != nullptr && (lda_copy < Kp || lda_copy % 8 || ((uintptr_t)a_copy & 15)))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear: the bf16 copy of A needs rows of >= %d elements, a multiple of 8 (lda_copy=%lld)", Kp, lda_copy);
+    const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 ? 128 : 64);
+    const int nslab = Kp / KS;
+    hipStream_t st = as_stream(stream);
+    int rc = DSW_OK;
+#define DSW_LINEAR_KS(KSV)                                                                                                     \
+    DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, st); \
+    }))
+    if (KS == 192) DSW_LINEAR_KS(192);
+    else if (KS == 128) DSW_LINEAR_KS(128);
+    else DSW_LINEAR_KS(64);
+#undef DSW_LINEAR_KS
+    return rc;
+}

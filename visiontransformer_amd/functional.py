@@ -611,69 +611,162 @@ def _cast_padded(t2, act):
     return cast_rows(t2, act, _ceil_pad(t2.shape[1]))
 
 
-class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b through the stock GEMM library, shaped for it in two ways.
+def _weight_operands(weight):
+    """nn.Linear weight [N, K] -> zero-padded bf16 [ceil64(N), ceil64(K)] and its transpose (one launch)"""
+    N, Kd = weight.shape
+    Np, Kp = _ceil_pad(N), _ceil_pad(Kd)
+    w = weight.detach()
+    w_p = torch.empty(Np, Kp, dtype=torch.bfloat16, device=w.device)
+    w_pt = torch.empty(Kp, Np, dtype=torch.bfloat16, device=w.device)
+    call("dsw_weight_prep", ptr(w), dtype_code(w.dtype), N, Kd, ptr(w_p), ptr(w_pt), stream(w.device))
+    return w_p, w_pt
 
-    * The library's kernels for this path's widths (180, 540: rows that are not multiples of 64
-      elements) run 2-4x slower than for 192 / 576.  Operands are therefore used at widths rounded
-      up to 64 wherever that costs no extra pass: an input that has to be cast anyway is cast into a
-      zero-padded buffer, an input or gradient that already sits in padded rows (a view produced
-      here or by the attention kernels) is taken with its padding, the weight is zero-padded in
-      both dimensions, and outputs keep their padded width (the caller sees a view of the first n
-      columns).
-    * The weight gradient dY^T X has a tiny output and a huge reduction dimension (all tokens),
-      which the library runs on a handful of CUs; it is issued as a batched GEMM over token chunks
-      and the chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
+
+def _mfma_operand(t2):
+    """Can dsw_linear read the rows of the 2-D tensor t2 where they lie?  -> row stride or None"""
+    T, n = t2.shape
+    unit = 4 if t2.dtype == torch.float32 else 8
+    ld = t2.stride(0) if T > 1 else n
+    if (t2.dtype in (torch.float32, torch.bfloat16) and t2.stride(1) == 1 and n % unit == 0 and ld % unit == 0 and ld >= n
+            and t2.data_ptr() % 16 == 0):
+        return ld
+    return None
+
+
+def _mfma_linear(a2, K, w_op, bias, N, out, ncols, a_copy):
+    """out[:, :ncols] = a2[:, :K] @ w_op[:ncols, :]^T (+ bias); a_copy (optional) receives a2 in padded bf16 rows"""
+    call("dsw_linear", ctypes.c_void_p(a2.data_ptr()), dtype_code(a2.dtype), a2.stride(0) if a2.shape[0] > 1 else a2.shape[1],
+         a2.shape[0], K, ptr(w_op), w_op.shape[0], w_op.shape[1], None if bias is None else ptr(bias), N, ptr(out),
+         dtype_code(out.dtype), out.shape[1], ncols, None if a_copy is None else ptr(a_copy),
+         0 if a_copy is None else a_copy.shape[1], stream(out.device))
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b for the projections of the attention modules.
+
+    Under bf16 autocast on the GPU the product and the input gradient run in the library's own
+    MFMA kernel (dsw_linear), which reads the activations where they lie - the fp32 residual stream,
+    a gradient laid out by autograd, padded bf16 rows from the attention kernels - rounds them to bf16
+    on the way in, writes the bf16 copy the weight gradient needs on the side, and adds the bias / casts
+    the result in its accumulators: no separate cast or padding passes.  fp32 runs and shapes it does
+    not take go through the stock GEMM library.  Either way:
+
+    * operands and results live in rows padded to multiples of 64 elements wherever that costs no
+      extra pass (the library's kernels for 180 / 540 wide rows run 2-4x slower than for 192 / 576):
+      padded inputs are taken with their padding, outputs keep their padded width (the caller sees a
+      view of the first n columns);
+    * the weight gradient dY^T X has a tiny output and a huge reduction dimension (all tokens), which
+      the library runs on a handful of CUs; it is issued as a batched GEMM over token chunks and the
+      chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act_dtype, pad_out):
         N, Kd = weight.shape
         with torch.autocast("cuda", enabled=False):
             x2 = x.reshape(-1, Kd)
+            T = x2.shape[0]
             xk = _padded_rows(x2, act_dtype)
             PAD_STATS["taken" if xk is not None else "copied"] += 1
-            if xk is None:
-                xk = _cast_padded(x2, act_dtype) if x2.dtype != act_dtype else x2.contiguous()
-            Kx, Np, Kp = xk.shape[1], _ceil_pad(N), _ceil_pad(Kd)
-            w_p = _padded_matrix(weight, act_dtype, Np, Kp)
+            Np, Kp = _ceil_pad(N), _ceil_pad(Kd)
             Nout = Np if pad_out else N
-            if bias is not None:
-                b_p = _padded_matrix(bias.view(1, N), act_dtype, 1, Nout).view(Nout)
-                y_p = torch.addmm(b_p, xk, w_p[:Nout, :Kx].t())
+            mfma = (act_dtype == torch.bfloat16 and x2.is_cuda and T > 0 and N % 4 == 0 and weight.is_contiguous()
+                    and weight.dtype in (torch.float32, torch.bfloat16) and weight.data_ptr() % 16 == 0)
+            if mfma:
+                b32 = None if bias is None else bias.detach().float().contiguous()
+                w_p, w_pt = _weight_operands(weight)
+                a_copy = None
+                if xk is not None:
+                    a2, K = xk, Kp
+                elif x2.dtype == act_dtype and Kd == Kp and x2.is_contiguous() and x2.data_ptr() % 16 == 0:
+                    a2, K, xk = x2, Kd, x2
+                elif _mfma_operand(x2) is not None:
+                    a2, K = x2, Kd
+                    if ctx.needs_input_grad[1]:
+                        a_copy = xk = _mark_padded(torch.empty(T, Kp, dtype=act_dtype, device=x2.device))
+                else:
+                    a2 = xk = _cast_padded(x2, act_dtype)
+                    K = Kp
+                y_p = torch.empty(T, Nout, dtype=act_dtype, device=x2.device)
+                _mfma_linear(a2, K, w_p, b32, N, y_p, Nout, a_copy)
+                if xk is None:
+                    xk = x2  # no weight gradient wanted: only the shape is read
+                w_saved = w_pt
             else:
-                y_p = xk @ w_p[:Nout, :Kx].t()
+                if xk is None:
+                    xk = _cast_padded(x2, act_dtype) if x2.dtype != act_dtype else x2.contiguous()
+                Kx = xk.shape[1]
+                w_p = _padded_matrix(weight, act_dtype, Np, Kp)
+                if bias is not None:
+                    b_p = _padded_matrix(bias.view(1, N), act_dtype, 1, Nout).view(Nout)
+                    y_p = torch.addmm(b_p, xk, w_p[:Nout, :Kx].t())
+                else:
+                    y_p = xk @ w_p[:Nout, :Kx].t()
+                w_saved = w_p
             _mark_padded(y_p)  # padding columns = zero weight rows x finite inputs + zero bias
-        ctx.save_for_backward(xk, w_p)
-        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, N, Kd)
+        ctx.save_for_backward(xk, w_saved)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, N, Kd, mfma)
         return y_p[:, :N].view(x.shape[:-1] + (N,))
 
     @staticmethod
     def backward(ctx, dy):
-        xk, w_p = ctx.saved_tensors
-        xshape, xdt, wdt, bdt, N, Kd = ctx.meta
-        act = w_p.dtype
+        xk, w_s = ctx.saved_tensors
+        xshape, xdt, wdt, bdt, N, Kd, mfma = ctx.meta
+        act = w_s.dtype
+        Np, Kp = _ceil_pad(N), _ceil_pad(Kd)
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = ctx.needs_input_grad[1] or (bdt is not None and ctx.needs_input_grad[2])
         with torch.autocast("cuda", enabled=False):
             dy2 = dy.reshape(-1, N)
+            T = dy2.shape[0]
             dyk = _padded_rows(dy2, act)
             PAD_STATS["taken" if dyk is not None else "copied"] += 1
-            if dyk is None:
-                dyk = _cast_padded(dy2, act) if dy2.dtype != act else dy2.contiguous()
-            Ndy, Kx, T = dyk.shape[1], xk.shape[1], xk.shape[0]
             dx = None
-            if ctx.needs_input_grad[0]:
-                dx = _mark_padded(dyk @ w_p[:Ndy]).as_strided((T, Kd), (w_p.shape[1], 1))
+            if mfma and need_dx and xdt in (torch.float32, torch.bfloat16):
+                # dx = dy W: the same kernel on the transposed weight [Kp, Np]
+                a_copy = None
+                if dyk is not None:
+                    a2, K = dyk, Np
+                elif dy2.dtype == act and N == Np and dy2.is_contiguous() and dy2.data_ptr() % 16 == 0:
+                    a2, K, dyk = dy2, N, dy2
+                else:
+                    if dy2.stride(1) != 1:
+                        dy2 = dy2.contiguous()
+                    if _mfma_operand(dy2) is not None:
+                        a2, K = dy2, N
+                        if need_dw:
+                            a_copy = dyk = _mark_padded(torch.empty(T, Np, dtype=act, device=dy2.device))
+                    else:
+                        a2 = dyk = _cast_padded(dy2, act)
+                        K = Np
+                if xdt == act:
+                    dx_p = _mark_padded(torch.empty(T, Kp, dtype=act, device=dy2.device))
+                    _mfma_linear(a2, K, w_s, None, 0, dx_p, Kp, a_copy)
+                    dx = dx_p[:, :Kd].view(xshape) if Kp != Kd else dx_p.view(xshape)
+                else:
+                    dx = torch.empty(T, Kd, dtype=xdt, device=dy2.device)
+                    _mfma_linear(a2, K, w_s, None, 0, dx, Kd, a_copy)
+                    dx = dx.view(xshape)
+            if dyk is None and (need_dw or (need_dx and dx is None)):
+                dyk = _cast_padded(dy2, act) if dy2.dtype != act else dy2.contiguous()
+            if need_dx and dx is None:
+                w_p = w_s.t() if mfma else w_s       # [Np, Kp] either way
+                dx = _mark_padded(dyk @ w_p[:dyk.shape[1]]).as_strided((T, Kd), (w_p.shape[1], 1))
                 if xdt != act:
                     dx = cast_rows(dx, xdt)
                 dx = dx.view(xshape)
-            if T >= 8 * _WGRAD_CHUNK and T % _WGRAD_CHUNK == 0:
-                S = T // _WGRAD_CHUNK
-                part = torch.bmm(dyk.view(S, _WGRAD_CHUNK, Ndy).transpose(1, 2), xk.view(S, _WGRAD_CHUNK, Kx))
-                dw = part.sum(0, dtype=torch.float32)
-            else:
-                dw = (dyk.t() @ xk).float()
-            dw = dw[:N, :Kd]
-            db = None if bdt is None else colsum(dyk)[:N].to(bdt)
-        return dx, dw.to(wdt), db, None, None
+            dw = db = None
+            if ctx.needs_input_grad[1]:
+                Ndy, Kx = dyk.shape[1], xk.shape[1]
+                if T >= 8 * _WGRAD_CHUNK and T % _WGRAD_CHUNK == 0:
+                    S = T // _WGRAD_CHUNK
+                    part = torch.bmm(dyk.view(S, _WGRAD_CHUNK, Ndy).transpose(1, 2), xk.view(S, _WGRAD_CHUNK, Kx))
+                    dw = part.sum(0, dtype=torch.float32)
+                else:
+                    dw = (dyk.t() @ xk).float()
+                dw = dw[:N, :Kd].to(wdt)
+            if bdt is not None and ctx.needs_input_grad[2]:
+                db = colsum(dyk)[:N].to(bdt)
+        return dx, dw, db, None, None
 
 
 def linear(x, lin, pad_out=False):
