@@ -353,3 +353,119 @@ def test_select_in_kernel_sigmoid(cuda0, dtype):
         assert torch.equal(getattr(a, f), getattr(b, f)), f
     assert torch.equal(a.scores_delta, b.scores_delta) and torch.equal(a.gates_delta, b.gates_delta)
     assert rel_err(gb.float(), ga.float()) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+def _ceil64(n):
+    return (n + 63) // 64 * 64
+
+
+def _weight_ops(w, dev):
+    from visiontransformer_amd import _lib
+    N, K = w.shape
+    wp = torch.empty(_ceil64(N), _ceil64(K), device=dev, dtype=torch.bfloat16)
+    wpt = torch.empty(_ceil64(K), _ceil64(N), device=dev, dtype=torch.bfloat16)
+    _lib.call("dsw_weight_prep", _lib.ptr(w), _lib.dtype_code(w.dtype), N, K, _lib.ptr(wp), _lib.ptr(wpt), _lib.stream(dev))
+    return wp, wpt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,a_dtype,c_dtype,pad_a,pad_c,copy", [
+    (300, 180, 540, torch.float32, torch.bfloat16, False, True, True),    # qkv from the fp32 stream
+    (300, 96, 288, torch.bfloat16, torch.bfloat16, True, True, False),    # padded bf16 rows in, K slab of 128
+    (257, 64, 64, torch.float32, torch.float32, False, False, True),      # ragged last row block, K slab of 64
+    (1000, 544, 180, torch.bfloat16, torch.float32, True, False, False),  # 3 slabs: accumulators persist
+    (1000, 256, 320, torch.bfloat16, torch.bfloat16, True, True, False),  # 2 slabs, two block columns
+    (515, 320, 100, torch.float32, torch.bfloat16, False, False, True),   # 5 slabs of 64, dense ragged output
+    (128 * 40 + 1, 180, 180, torch.bfloat16, torch.bfloat16, True, True, False),
+    (128 * 300, 180, 540, torch.float32, torch.bfloat16, False, True, True),
+])
+def test_linear_kernel(cuda0, M, K, N, a_dtype, c_dtype, pad_a, pad_c, copy):
+    """dsw_linear / dsw_weight_prep through the C ABI against a torch fp32 product of the same
+    bf16-rounded operands: 1e-2 of the largest value for bf16 results (their own rounding), 1e-5 * K
+    for fp32 results; padding columns of the result and of the bf16 copy of A exactly zero, the copy
+    bit-exact."""
+    from visiontransformer_amd import _lib
+    bf = torch.bfloat16
+    g = torch.Generator(device=cuda0).manual_seed(M + K + N)
+    w = torch.randn(N, K, device=cuda0, generator=g) * 0.1
+    bias = torch.randn(N, device=cuda0, generator=g)
+    wp, wpt = _weight_ops(w, cuda0)
+    assert torch.equal(wp[:N, :K], w.to(bf)) and torch.equal(wpt, wp.t())
+    assert wp[N:].abs().max().item() == 0 if wp.shape[0] > N else True
+    lda = _ceil64(K) if pad_a else K
+    a = torch.zeros(M, lda, device=cuda0, dtype=a_dtype)
+    a[:, :K] = torch.randn(M, K, device=cuda0, generator=g).to(a_dtype)
+    ncols = _ceil64(N) if pad_c else N
+    c = torch.full((M, ncols), float("nan"), device=cuda0, dtype=c_dtype)
+    a_copy = torch.full((M, _ceil64(K)), float("nan"), device=cuda0, dtype=bf) if copy else None
+    Kk = lda if a_dtype == bf else K
+    _lib.call("dsw_linear", _lib.ptr(a), _lib.dtype_code(a_dtype), lda, M, Kk, _lib.ptr(wp), wp.shape[0], wp.shape[1], _lib.ptr(bias), N,
+              _lib.ptr(c), _lib.dtype_code(c_dtype), ncols, ncols, _lib.ptr(a_copy) if copy else None, a_copy.shape[1] if copy else 0,
+              _lib.stream(cuda0))
+    ref = a[:, :K].to(bf).float() @ w.to(bf).float().t() + bias
+    tol = 1e-2 if c_dtype == bf else 1e-5 * K
+    assert ((c[:, :N].float() - ref).abs().max() / ref.abs().max()).item() < tol
+    if ncols > N:
+        assert c[:, N:].abs().max().item() == 0
+    if copy:
+        assert torch.equal(a_copy[:, :K], a[:, :K].to(bf))
+        if a_copy.shape[1] > K:
+            assert a_copy[:, K:].abs().max().item() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(300, 180, 540), (1000, 96, 100), (4096 + 24, 192, 64), (128 * 300 + 5, 180, 180)])
+def test_linear_wgrad_kernel(cuda0, M, K, N):
+    """dsw_linear_wgrad (weight and bias gradient of a projection) against a float64 product of
+    the same bf16 operands, and bitwise reproducible."""
+    from visiontransformer_amd import _lib
+    bf = torch.bfloat16
+    g = torch.Generator(device=cuda0).manual_seed(M + K + N)
+    Kp, Np = _ceil64(K), _ceil64(N)
+    x = torch.zeros(M, Kp, device=cuda0, dtype=bf)
+    x[:, :K] = torch.randn(M, K, device=cuda0, generator=g).to(bf)
+    dy = torch.zeros(M, Np, device=cuda0, dtype=bf)
+    dy[:, :N] = torch.randn(M, N, device=cuda0, generator=g).to(bf)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((N, K), float("nan"), device=cuda0)
+        db = torch.full((N,), float("nan"), device=cuda0) if K < Kp else None
+        ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, N), device=cuda0)
+        _lib.call("dsw_linear_wgrad", _lib.ptr(dy), Np, _lib.ptr(x), Kp, M, N, K, _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
+                  _lib.ptr(ws), _lib.stream(cuda0))
+        outs.append((dw, db))
+    dw, db = outs[0]
+    ref = dy[:, :N].double().t() @ x[:, :K].double()
+    assert rel_err(dw, ref.float()) < 1e-5
+    assert torch.equal(dw, outs[1][0])
+    if db is not None:
+        assert rel_err(db, dy[:, :N].double().sum(0).float()) < 1e-5
+        assert torch.equal(db, outs[1][1])
+    else:
+        with pytest.raises(RuntimeError, match="padding column"):
+            _lib.call("dsw_linear_wgrad", _lib.ptr(dy), Np, _lib.ptr(x), Kp, M, N, K, _lib.ptr(dw), _lib.ptr(dw), _lib.ptr(ws),
+                      _lib.stream(cuda0))
+
+
+@pytest.mark.gpu
+def test_linear_function_against_torch(cuda0):
+    """The projection Function under bf16 autocast (own MFMA kernels) against F.linear under the
+    same autocast: values and all three gradients within 2e-2, for an fp32 input (cast fused),
+    a padded bf16 input, and an input whose width leaves no padding column (bias gradient by column sums)."""
+    import torch.nn.functional as F
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(5)
+    for Kd, N, T in ((180, 540, 128 * 9 + 3), (192, 64, 2048 * 8), (96, 100, 777)):
+        lin = torch.nn.Linear(Kd, N).to(cuda0)
+        x = torch.randn(T, Kd, device=cuda0, requires_grad=True)
+        dy = torch.randn(T, N, device=cuda0)
+        res = []
+        for own in (False, True):
+            lin.zero_grad(set_to_none=True)
+            x.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = K.linear(x, lin, pad_out=True) if own else F.linear(x, lin.weight, lin.bias)
+            (y.float() * dy).sum().backward()
+            res.append((y.float(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
+        for got, ref in zip(res[1], res[0]):
+            assert rel_err(got, ref) < 2e-2

@@ -63,7 +63,44 @@ def case(M, K, N, a_dt, c_dt, pad_a, pad_c, copy, dgrad=False):
     return ok
 
 
+def wcase(M, K, N):
+    torch.manual_seed(1)
+    Kp, Np = ceil64(K), ceil64(N)
+    x = torch.zeros(M, Kp, device=dev, dtype=bf); x[:, :K] = torch.randn(M, K, device=dev).to(bf)
+    dy = torch.zeros(M, Np, device=dev, dtype=bf); dy[:, :N] = torch.randn(M, N, device=dev).to(bf)
+    dw = torch.full((N, K), float("nan"), device=dev); db = torch.full((N,), float("nan"), device=dev) if K < Kp else None
+    ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, N), device=dev)
+    f = lambda: _lib.call("dsw_linear_wgrad", _lib.ptr(dy), Np, _lib.ptr(x), Kp, M, N, K, _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
+                          _lib.ptr(ws), _lib.stream(dev))
+    f()
+    ref = dy[:, :N].double().t() @ x[:, :K].double()
+    err = ((dw.double() - ref).abs().max() / ref.abs().max()).item()
+    ok = err < 1e-5
+    if db is not None:
+        rb = dy[:, :N].double().sum(0)
+        eb = ((db.double() - rb).abs().max() / rb.abs().max()).item()
+        ok = ok and eb < 1e-5
+    else:
+        eb = float("nan")
+    S = M // 2048 if M % 2048 == 0 and M >= 16384 else 1
+    lib = (lambda: torch.bmm(dy.view(S, M // S, Np).transpose(1, 2), x.view(S, M // S, Kp)).sum(0, dtype=torch.float32))
+    t_lib = bench.time_calls(lib, 20); t_me = bench.time_calls(f, 20)
+    print("wgrad M=%6d K=%3d N=%3d : err %.1e / %.1e %s  lib(bmm+sum) %6.1f us  this %6.1f us (%.0f GB/s)" % (
+        M, K, N, err, eb, "ok" if ok else "WRONG", t_lib * 1e6, t_me * 1e6, M * (Kp + Np) * 2 / t_me / 1e9), flush=True)
+    return ok
+
+
 ok = True
+if os.environ.get('WONLY'):
+    for M in (131072, 32768):
+        wcase(M, 180, 540); wcase(M, 180, 180)
+    sys.exit(0)
+ok &= wcase(300, 180, 540)
+ok &= wcase(1000, 96, 100)
+ok &= wcase(4099 if False else 4096 + 24, 192, 64)
+for M in (131072, 32768):
+    ok &= wcase(M, 180, 540)
+    ok &= wcase(M, 180, 180)
 # small odd cases first
 ok &= case(300, 180, 540, f32, bf, 0, 1, 1)
 ok &= case(300, 96, 288, bf, bf, 1, 1, 0)

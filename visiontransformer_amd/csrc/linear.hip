@@ -16,6 +16,7 @@
 //   * K > 192 (input gradients, K = 3C): several slabs; the accumulators of up to three chunks
 //     (192 columns) persist across slabs, wider outputs are split over blockIdx.y.
 #include "attn_common.hpp"
+#include <stdlib.h>
 
 namespace dsw {
 namespace {
@@ -279,6 +280,148 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const TW *__restrict__
     if (wpt != nullptr) wpt[(size_t)k * Np + n] = v;
 }
 
+// ---- weight gradient ---------------------------------------------------------------------------
+// dW[n][k] = sum_m dY[m][n] X[m][k]: a tiny output and a reduction over every token.  A workgroup
+// (6 waves) owns a 192 x 192 output block in its accumulators and walks its share of the rows in
+// stages of 64, both operands staged row-major in LDS and read as MFMA operands with transposing
+// reads (the reduction index m is the row of both tiles).  With K < ceil64(K) the first padding
+// column of X is replaced by ones on the way into LDS, which makes column K of the result the bias
+// gradient sum_m dY[m][n].  Partial blocks go to a workspace and are summed in a fixed order.
+constexpr int WG_TN = 192;       // output rows (columns of dY) per workgroup
+constexpr int WG_TK = 192;       // output columns (columns of X): the whole padded K
+constexpr int WG_BM = 64;        // rows per stage
+constexpr int WG_THREADS = 384;  // 6 waves: 3 (n) x 2 (k), 64 x 96 each
+constexpr int WG_LS = 224;       // LDS row stride in elements: 112 dwords = 48 mod 64 keeps the transposing reads conflict-free
+constexpr int WG_PIECES = WG_BM * (WG_TN / 8) / WG_THREADS;  // 16-byte pieces per thread and operand: 4
+constexpr size_t WG_LDS = (size_t)2 * WG_BM * WG_LS * sizeof(bf16_t);
+
+__global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_t *__restrict__ dY, long long ldy,
+                                                                      const bf16_t *__restrict__ X, long long ldx, int M, int K, int Kp,
+                                                                      int Np, int rows_per_block, float *__restrict__ partial) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    bf16_t *Ys = reinterpret_cast<bf16_t *>(smem);
+    bf16_t *Xs = Ys + WG_BM * WG_LS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wn = wave % 3, wk = wave / 3;
+    const int n0 = blockIdx.x * WG_TN;
+    const int m_begin = blockIdx.y * rows_per_block;
+    const int rows = min(M - m_begin, rows_per_block);  // >= 1 by the grid's construction
+    const int nst = (rows + WG_BM - 1) / WG_BM;
+    const bool ones = K < Kp;
+
+    // staging: piece = 8 consecutive columns; 24 pieces per row, 16 rows per pass of the block
+    const int prow = tid / 24, pc = tid - prow * 24;
+    const bool y_ok = n0 + pc * 8 < Np, x_ok = pc * 8 < Kp;
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(dY + (size_t)m_begin * ldy + n0, ((size_t)(rows - 1) * ldy + (Np - n0)) * sizeof(bf16_t));
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(X + (size_t)m_begin * ldx, ((size_t)(rows - 1) * ldx + Kp) * sizeof(bf16_t));
+    const unsigned y_off = (unsigned)(((size_t)prow * ldy + pc * 8) * sizeof(bf16_t));
+    const unsigned x_off = (unsigned)(((size_t)prow * ldx + pc * 8) * sizeof(bf16_t));
+    const unsigned y_step = (unsigned)(16 * ldy * sizeof(bf16_t)), x_step = (unsigned)(16 * ldx * sizeof(bf16_t));
+
+    uint4 yr[WG_PIECES], xr[WG_PIECES];
+    auto load_stage = [&](int st) {
+        const unsigned ys = (unsigned)((size_t)st * WG_BM * ldy * sizeof(bf16_t)), xs = (unsigned)((size_t)st * WG_BM * ldx * sizeof(bf16_t));
+#pragma unroll
+        for (int i = 0; i < WG_PIECES; ++i) {
+            yr[i] = buf_load16(rs_y, y_off + i * y_step, ys);
+            xr[i] = buf_load16(rs_x, x_off + i * x_step, xs);
+        }
+    };
+    auto write_stage = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < WG_PIECES; ++i) {
+            const int r = prow + 16 * i;
+            uint4 y = yr[i], x = xr[i];
+            if (!y_ok) y = make_uint4(0u, 0u, 0u, 0u);
+            if (!x_ok) x = make_uint4(0u, 0u, 0u, 0u);
+            if (ones && pc == (K >> 3) && st * WG_BM + r < rows) {
+                // element K & 7 of this piece := 1.0 (K % 4 == 0: element 0 or 4)
+                if (K & 4) x.z = (x.z & 0xffff0000u) | 0x3f80u;
+                else x.x = (x.x & 0xffff0000u) | 0x3f80u;
+            }
+            *reinterpret_cast<uint4 *>(Ys + r * WG_LS + pc * 8) = y;
+            *reinterpret_cast<uint4 *>(Xs + r * WG_LS + pc * 8) = x;
+        }
+    };
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transposing reads: slot j of a lane's 8 reduction indices is row 8 (j >> 2) + 4 hh + (j & 3) of the
+    // 16-row step, the same for both operands
+    const int trq = (lane >> 2) & 3, trp = lane & 3, trg = (lane >> 4) & 1;
+    const bf16_t *ytr = Ys + (4 * hh + trq) * WG_LS + wn * 64 + 16 * trg + 4 * trp;
+    const bf16_t *xtr = Xs + (4 * hh + trq) * WG_LS + wk * 96 + 16 * trg + 4 * trp;
+
+    load_stage(0);
+    for (int st = 0; st < nst; ++st) {
+        if (st > 0) lds_barrier();  // the previous stage's reads are over
+        write_stage(st);
+        lds_barrier();
+        if (st + 1 < nst) load_stage(st + 1);
+#pragma unroll
+        for (int ks = 0; ks < WG_BM / 16; ++ks) {
+            bf16x8 a[2], b[3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint2 r0 = lds_read_tr16(ytr + (16 * ks) * WG_LS + 32 * t), r1 = lds_read_tr16(ytr + (16 * ks + 8) * WG_LS + 32 * t);
+                a[t] = as_bf16x8(make_uint4(r0.x, r0.y, r1.x, r1.y));
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const uint2 r0 = lds_read_tr16(xtr + (16 * ks) * WG_LS + 32 * t), r1 = lds_read_tr16(xtr + (16 * ks + 8) * WG_LS + 32 * t);
+                b[t] = as_bf16x8(make_uint4(r0.x, r0.y, r1.x, r1.y));
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 3; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+    }
+    // lane = output column k, registers = rows n: 128-byte runs per row
+    float *pb = partial + (size_t)blockIdx.y * Np * WG_TK;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + ta * 32 + rho(r) + 4 * hh;
+                if (n < Np) pb[(size_t)n * WG_TK + wk * 96 + tb * 32 + l31] = acc[ta][tb][r];
+            }
+}
+
+// dw[n][k] = sum_s partial[s][n][k] (n < N, k < K); db[n] = sum_s partial[s][n][K].  A workgroup sums 16
+// groups of 4 columns, its 16 thread slices taking every 16th partial block; the slices meet in LDS and
+// are added in slice order (a fixed tree: bitwise reproducible).
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *__restrict__ partial, int S, int Np, int N, int K,
+                                                                  float *__restrict__ dw, float *__restrict__ db) {
+    __shared__ float4 red[16][16];
+    const int it = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + it;  // (n, group of 4 columns)
+    const int n = i / (WG_TK / 4), k4 = (i - n * (WG_TK / 4)) * 4;
+    const bool live = n < N && (k4 < K || (k4 == K && db != nullptr));
+    float4 a = f4zero();
+    if (live) {
+        const float4 *p = reinterpret_cast<const float4 *>(partial + (size_t)n * WG_TK + k4);
+        const size_t stride = (size_t)Np * WG_TK / 4;
+        for (int s0 = sl; s0 < S; s0 += 16) a = a + p[(size_t)s0 * stride];
+    }
+    red[sl][it] = a;
+    __syncthreads();
+    if (sl == 0 && live) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) a = a + red[j][it];
+        if (k4 < K) *reinterpret_cast<float4 *>(dw + (size_t)n * K + k4) = a;
+        else db[n] = a.x;
+    }
+}
+
 int set_lds(const void *kern, size_t lds, const char *who) {
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -366,4 +509,50 @@ extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M
     else DSW_LINEAR_KS(64);
 #undef DSW_LINEAR_KS
     return rc;
+}
+
+static void wgrad_split(long long M, int Np, int *rows_per_block, int *S) {
+    const int nb = (Np + WG_TN - 1) / WG_TN;
+    long long want = 256 / nb;  // about one workgroup per CU: every extra one adds a partial block to write and re-read
+    if (const char *e = getenv("DSW_WGRAD_SPLIT")) want = atoi(e) / nb;
+    if (want < 1) want = 1;
+    long long rpb = (M + want - 1) / want;
+    rpb = (rpb + WG_BM - 1) / WG_BM * WG_BM;
+    *rows_per_block = (int)rpb;
+    *S = (int)((M + rpb - 1) / rpb);
+}
+
+extern "C" size_t dsw_linear_wgrad_workspace(long long M, int N) {
+    if (M <= 0 || N <= 0 || M > 0x7fffff00LL) return 0;
+    const int Np = (N + 63) / 64 * 64;
+    int rpb, S;
+    wgrad_split(M, Np, &rpb, &S);
+    return (size_t)S * Np * WG_TK;
+}
+
+extern "C" int dsw_linear_wgrad(const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K, float *dw,
+                                float *db, float *workspace, void *stream) {
+    if (M <= 0 || M > 0x7fffff00LL || N <= 0 || K <= 0) return fail(DSW_EINVAL, "dsw_linear_wgrad: bad sizes M=%lld N=%d K=%d", M, N, K);
+    DSW_REQUIRE(dy && x && dw && workspace, "dsw_linear_wgrad: null pointer");
+    const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64;
+    if (Kp > WG_TK) return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: K=%d (at most %d)", K, WG_TK);
+    if (K % 4) return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: K=%d must be a multiple of 4", K);
+    if (db != nullptr && K == Kp)
+        return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: the bias gradient rides in a padding column of x, K=%d leaves none", K);
+    if (ldy < Np || ldx < Kp || ldy % 8 || ldx % 8 || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: dy / x need rows of >= %d / %d bf16 elements (zero padded), multiples of 8, "
+                                      "16-byte aligned (ldy=%lld ldx=%lld)", Np, Kp, ldy, ldx);
+    if (((uintptr_t)dw & 15) || ((uintptr_t)workspace & 15)) return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: dw / workspace must be 16-byte aligned");
+    int rpb, S;
+    wgrad_split(M, Np, &rpb, &S);
+    hipStream_t st = as_stream(stream);
+    int rc = set_lds((const void *)linear_wgrad_kernel, WG_LDS, "dsw_linear_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((Np + WG_TN - 1) / WG_TN, S), dim3(WG_THREADS), WG_LDS, st, (const bf16_t *)dy, ldy,
+                       (const bf16_t *)x, ldx, (int)M, K, Kp, Np, rpb, workspace);
+    rc = check_launch("linear_wgrad_kernel");
+    if (rc) return rc;
+    const int items = N * (WG_TK / 4);
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((items + 15) / 16), dim3(256), 0, st, workspace, S, Np, N, K, dw, db);
+    return check_launch("linear_wgrad_reduce_kernel");
 }

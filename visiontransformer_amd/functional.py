@@ -755,16 +755,28 @@ class _LinearFn(torch.autograd.Function):
                     dx = cast_rows(dx, xdt)
                 dx = dx.view(xshape)
             dw = db = None
+            want_db = bdt is not None and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
                 Ndy, Kx = dyk.shape[1], xk.shape[1]
-                if T >= 8 * _WGRAD_CHUNK and T % _WGRAD_CHUNK == 0:
+                if (mfma and Kp <= 192 and Kd % 4 == 0 and Ndy == Np and Kx == Kp and xk.dtype == act and dyk.is_contiguous()
+                        and xk.is_contiguous() and dyk.data_ptr() % 16 == 0 and xk.data_ptr() % 16 == 0):
+                    # own split-K kernel; the bias gradient rides in x's first padding column when there is one
+                    dw = torch.empty(N, Kd, dtype=torch.float32, device=dyk.device)
+                    fused_db = want_db and Kd < Kp
+                    dbf = torch.empty(N, dtype=torch.float32, device=dyk.device) if fused_db else None
+                    ws = torch.empty(int(_lib.load().dsw_linear_wgrad_workspace(T, N)), dtype=torch.float32, device=dyk.device)
+                    call("dsw_linear_wgrad", ptr(dyk), Np, ptr(xk), Kp, T, N, Kd, ptr(dw), None if dbf is None else ptr(dbf), ptr(ws),
+                         stream(dyk.device))
+                    dw = dw.to(wdt)
+                    if fused_db:
+                        db = dbf.to(bdt)
+                elif T >= 8 * _WGRAD_CHUNK and T % _WGRAD_CHUNK == 0:
                     S = T // _WGRAD_CHUNK
                     part = torch.bmm(dyk.view(S, _WGRAD_CHUNK, Ndy).transpose(1, 2), xk.view(S, _WGRAD_CHUNK, Kx))
-                    dw = part.sum(0, dtype=torch.float32)
+                    dw = part.sum(0, dtype=torch.float32)[:N, :Kd].to(wdt)
                 else:
-                    dw = (dyk.t() @ xk).float()
-                dw = dw[:N, :Kd].to(wdt)
-            if bdt is not None and ctx.needs_input_grad[2]:
+                    dw = (dyk.t() @ xk).float()[:N, :Kd].to(wdt)
+            if want_db and db is None:
                 db = colsum(dyk)[:N].to(bdt)
         return dx, dw, db, None, None
 
