@@ -266,8 +266,9 @@ int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, i
  * [ceil64(N)][ceil64(K)] and its transpose w_pt [ceil64(K)][ceil64(N)], bf16, zero outside N x K
  * (either pointer may be NULL).  The forward projection multiplies by w_p, the input gradient
  * dx = dy . W multiplies by w_pt.
- *   a:      [M][lda] fp32 or bf16; fp32 values are rounded to bf16 on load.  K % 4 == 0 (fp32) or
- *           K % 8 == 0 (bf16); lda a multiple of 4 / 8 elements; 16-byte aligned.
+ *   a:      [M][lda] fp32 or bf16; fp32 values are rounded to bf16 on load.  K and lda multiples
+ *           of 4 elements, base aligned to 4 elements (bf16 rows that are 16-byte aligned, K and lda
+ *           multiples of 8, load in half as many instructions).
  *   w_p:    bf16 [wrows][ldw], ldw >= ceil64(K); rows >= wrows read as zero.
  *   bias:   fp32 [N] or NULL.
  *   c:      [M][ldc] fp32 or bf16, columns 0..ncols-1 written (ncols % 4 == 0): with ncols =

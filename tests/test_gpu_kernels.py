@@ -377,6 +377,7 @@ def _weight_ops(w, dev):
     (1000, 256, 320, torch.bfloat16, torch.bfloat16, True, True, False),  # 2 slabs, two block columns
     (515, 320, 100, torch.float32, torch.bfloat16, False, False, True),   # 5 slabs of 64, dense ragged output
     (128 * 40 + 1, 180, 180, torch.bfloat16, torch.bfloat16, True, True, False),
+    (128 * 9 + 77, 180, 180, torch.bfloat16, torch.float32, False, False, True),     # dense bf16 rows of 360 bytes: 8-byte loads
     (128 * 300, 180, 540, torch.float32, torch.bfloat16, False, True, True),
 ])
 def test_linear_kernel(cuda0, M, K, N, a_dtype, c_dtype, pad_a, pad_c, copy):
@@ -398,7 +399,7 @@ def test_linear_kernel(cuda0, M, K, N, a_dtype, c_dtype, pad_a, pad_c, copy):
     ncols = _ceil64(N) if pad_c else N
     c = torch.full((M, ncols), float("nan"), device=cuda0, dtype=c_dtype)
     a_copy = torch.full((M, _ceil64(K)), float("nan"), device=cuda0, dtype=bf) if copy else None
-    Kk = lda if a_dtype == bf else K
+    Kk = lda if (a_dtype == bf and pad_a) else K
     _lib.call("dsw_linear", _lib.ptr(a), _lib.dtype_code(a_dtype), lda, M, Kk, _lib.ptr(wp), wp.shape[0], wp.shape[1], _lib.ptr(bias), N,
               _lib.ptr(c), _lib.dtype_code(c_dtype), ncols, ncols, _lib.ptr(a_copy) if copy else None, a_copy.shape[1] if copy else 0,
               _lib.stream(cuda0))

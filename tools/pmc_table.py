@@ -15,7 +15,7 @@ def main():
     for d in sys.argv[1:]:
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f)):
-                m = re.search(r"dsw::(\w+)", row["Kernel_Name"])
+                m = re.search(r"dsw::(?:\(anonymous namespace\)::)?(\w+)", row["Kernel_Name"])
                 if not m:
                     continue
                 a = re.search(r"<([^>]*)>", row["Kernel_Name"])

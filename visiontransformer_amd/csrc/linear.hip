@@ -16,7 +16,6 @@
 //   * K > 192 (input gradients, K = 3C): several slabs; the accumulators of up to three chunks
 //     (192 columns) persist across slabs, wider outputs are split over blockIdx.y.
 #include "attn_common.hpp"
-#include <stdlib.h>
 
 namespace dsw {
 namespace {
@@ -37,6 +36,7 @@ template <int KS> struct LnCfg {
 // Buffer descriptors: loads past the end of the described range return zero, which takes care of the rows beyond M, of weight rows beyond the matrix and of an
 // absent bias without a branch.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
 }
@@ -49,7 +49,7 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 template <typename T> struct a_piece;
 template <> struct a_piece<float> {
     uint4 lo, hi;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool) {
         lo = buf_load16(r, voff, soff);
         hi = buf_load16(r, voff + 16, soff);
     }
@@ -63,10 +63,22 @@ template <> struct a_piece<float> {
         return v;
     }
 };
-template <> struct a_piece<bf16_t> {  // K % 8 == 0
+template <> struct a_piece<bf16_t> {
     uint4 v;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { v = buf_load16(r, voff, soff); }
-    __device__ __forceinline__ uint4 pack(int k, int K) const { return k + 8 <= K ? v : make_uint4(0u, 0u, 0u, 0u); }
+    // half16: rows are only 8-byte aligned (a dense [M][K] matrix with K % 8 == 4): two 8-byte loads
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool half16) {
+        if (half16) {
+            const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+            const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff + 8, (int)soff, 0);
+            v = make_uint4(a.x, a.y, b.x, b.y);
+        } else {
+            v = buf_load16(r, voff, soff);
+        }
+    }
+    __device__ __forceinline__ uint4 pack(int k, int K) const {
+        const bool l = k + 4 <= K, h = k + 8 <= K;
+        return make_uint4(l ? v.x : 0u, l ? v.y : 0u, h ? v.z : 0u, h ? v.w : 0u);
+    }
 };
 
 // One chunk of 64 output columns against the wave's 32 rows: 2 MFMAs per k step, their weight
@@ -91,11 +103,7 @@ __device__ __forceinline__ void chunk_mfma(const bf16_t *brow, const bf16x8 (&af
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-#ifdef LN_ABL_NOMFMA
-                acc[t][0] += __builtin_bit_cast(f32x4, w[g & 1][2 * j + t])[0];
-#else
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][2 * j + t], afr[2 * g + j], acc[t], 0, 0, 0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -110,10 +118,12 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t *As = reinterpret_cast<bf16_t *>(smem);
     bf16_t *Bs = As + LN_BM * LS;
+    float *biasl = reinterpret_cast<float *>(Bs + LN_CN * LS);  // bias of this block's columns, zero where there is none
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int m0 = blockIdx.x * LN_BM;
     const int rows = min(M - m0, LN_BM);
+    const bool half16 = sizeof(TA) == 2 && (((lda | K) & 7) != 0 || (reinterpret_cast<uintptr_t>(A) & 15) != 0);
     const int total_chunks = (ncols + LN_CN - 1) / LN_CN;
     const int nc0 = blockIdx.y * chunks_per_block;
     const int nch = min(chunks_per_block, total_chunks - nc0);  // >= 1 by the grid's construction
@@ -126,6 +136,8 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(bias, bias != nullptr ? (size_t)N * sizeof(float) : 0);
     // bf16 copy of A: plain stores from the first block column
     bf16_t *const copy_row = a_copy != nullptr && blockIdx.y == 0 ? a_copy + (size_t)(m0 + srow) * lda_copy + scol : nullptr;
+    for (int i = tid; i < nch * LN_CN; i += LN_THREADS)
+        biasl[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, (unsigned)(nc0 * LN_CN + i) * 4u, 0, 0));
     unsigned a_off[4], w_off[2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) a_off[p] = (unsigned)(((size_t)(p * 32 + srow) * lda + scol) * sizeof(TA));
@@ -151,11 +163,12 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
         constexpr int SROW = 144;             // staging row stride in bytes
         unsigned char *stg = reinterpret_cast<unsigned char *>(As + wave * 32 * LS);
         const int nb = (nc0 + chunk) * LN_CN;
-        uint4 bv[2][4];
+        // the bias comes from LDS (staged once per block)
+        float4 bv[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bv[t][g] = buf_load16(rs_b, (unsigned)(nb + 4 * hh + t * 32 + 8 * g) * 4u, 0u);
+            for (int g = 0; g < 4; ++g) bv[t][g] = *reinterpret_cast<const float4 *>(biasl + chunk * LN_CN + 4 * hh + t * 32 + 8 * g);
 #pragma unroll
         for (int ps = 0; ps < 2 / TPP; ++ps) {
 #pragma unroll
@@ -163,8 +176,8 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 const int t = ps * TPP + tt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 v = make_float4(a[t][4 * g] + __uint_as_float(bv[t][g].x), a[t][4 * g + 1] + __uint_as_float(bv[t][g].y),
-                                                 a[t][4 * g + 2] + __uint_as_float(bv[t][g].z), a[t][4 * g + 3] + __uint_as_float(bv[t][g].w));
+                    const float4 v = make_float4(a[t][4 * g] + bv[t][g].x, a[t][4 * g + 1] + bv[t][g].y, a[t][4 * g + 2] + bv[t][g].z,
+                                                 a[t][4 * g + 3] + bv[t][g].w);
                     io<TC>::st4(reinterpret_cast<TC *>(stg + l31 * SROW) + tt * 32 + 8 * g + 4 * hh, v);
                 }
             }
@@ -175,11 +188,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 const int col = nb + ps * SW + (lane & 7) * PC;
                 const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * SROW + (lane & 7) * 16);
                 TC *dst = C + (size_t)m * ldc + col;
-#ifdef LN_ABL_NOSTORE
-                if (m < M && v.x == 0x12345u) {
-#else
                 if (m < M) {
-#endif
                     if (col + PC <= ncols) *reinterpret_cast<uint4 *>(dst) = v;
                     else if (sizeof(TC) == 2 && col + 4 <= ncols) *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
                 }
@@ -194,11 +203,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-#ifdef LN_ABL_NOWLOAD
-            for (int j = 0; j < KS / 64; ++j) breg[q * (KS / 64) + j] = make_uint4(soff, q, j, 1u);
-#else
             for (int j = 0; j < KS / 64; ++j) breg[q * (KS / 64) + j] = buf_load16(rs_w, w_off[q] + j * 128, soff);
-#endif
     };
     auto write_b = [&]() {
 #pragma unroll
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int j = 0; j < KS / 64; ++j) ap[p * (KS / 64) + j].load(rs_a, a_off[p] + j * 64 * (unsigned)sizeof(TA), soff);
+                for (int j = 0; j < KS / 64; ++j) ap[p * (KS / 64) + j].load(rs_a, a_off[p] + j * 64 * (unsigned)sizeof(TA), soff, half16);
             if (slab == 0) load_b(0, 0);
             lds_barrier();  // the previous slab's reads of As / Bs are over
 #pragma unroll
@@ -445,16 +450,18 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
         cpb = (total + gy - 1) / gy;
     }
     const dim3 grid(mt, (total + cpb - 1) / cpb);
+    const size_t lds = cfg::LDS + (size_t)cpb * LN_CN * sizeof(float);
+    if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "dsw_linear: %d output columns per block need %zu bytes of LDS", cpb * LN_CN, lds);
     int rc;
     if (nslab > 1) {
         auto kern = linear_nt_kernel<TA, TC, KS, true>;
-        if ((rc = set_lds((const void *)kern, cfg::LDS, "dsw_linear"))) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), cfg::LDS, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
+        if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
                            bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb);
     } else {
         auto kern = linear_nt_kernel<TA, TC, KS, false>;
-        if ((rc = set_lds((const void *)kern, cfg::LDS, "dsw_linear"))) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), cfg::LDS, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
+        if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
                            bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb);
     }
     return check_launch("linear_nt_kernel");
@@ -483,10 +490,9 @@ extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M
         return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
     DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
     const int Kp = (K + 63) / 64 * 64;
-    const int a_align = a_dtype == DSW_F32 ? 4 : 8;
-    if (K % a_align || lda < K || lda % a_align || ((uintptr_t)a & 15))
-        return fail(DSW_EUNSUPPORTED, "dsw_linear: A needs K and its row stride to be multiples of %d elements, the stride >= K, and a "
-                                      "16-byte aligned base (K=%d lda=%lld)", a_align, K, lda);
+    if (K % 4 || lda < K || lda % 4 || ((uintptr_t)a & (a_dtype == DSW_F32 ? 15 : 7)))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear: A needs K and its row stride to be multiples of 4 elements, the stride >= K, and a "
+                                      "base aligned to 4 elements (K=%d lda=%lld)", K, lda);
     if (ldw < Kp || ldw % 8 || ((uintptr_t)w_p & 15))
         return fail(DSW_EUNSUPPORTED, "dsw_linear: the weight needs rows of >= %d elements (K rounded up to 64), a multiple of 8 (ldw=%d)", Kp, ldw);
     if (ncols % 4 || ldc < ncols || ldc % 4 || ((uintptr_t)c & 15))
@@ -514,7 +520,6 @@ extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M
 static void wgrad_split(long long M, int Np, int *rows_per_block, int *S) {
     const int nb = (Np + WG_TN - 1) / WG_TN;
     long long want = 256 / nb;  // about one workgroup per CU: every extra one adds a partial block to write and re-read
-    if (const char *e = getenv("DSW_WGRAD_SPLIT")) want = atoi(e) / nb;
     if (want < 1) want = 1;
     long long rpb = (M + want - 1) / want;
     rpb = (rpb + WG_BM - 1) / WG_BM * WG_BM;

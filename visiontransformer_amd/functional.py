@@ -625,10 +625,9 @@ def _weight_operands(weight):
 def _mfma_operand(t2):
     """Can dsw_linear read the rows of the 2-D tensor t2 where they lie?  -> row stride or None"""
     T, n = t2.shape
-    unit = 4 if t2.dtype == torch.float32 else 8
     ld = t2.stride(0) if T > 1 else n
-    if (t2.dtype in (torch.float32, torch.bfloat16) and t2.stride(1) == 1 and n % unit == 0 and ld % unit == 0 and ld >= n
-            and t2.data_ptr() % 16 == 0):
+    if (t2.dtype in (torch.float32, torch.bfloat16) and t2.stride(1) == 1 and n % 4 == 0 and ld % 4 == 0 and ld >= n
+            and t2.data_ptr() % (4 * t2.element_size()) == 0):
         return ld
     return None
 
