@@ -272,14 +272,15 @@ int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, i
  *   w_p:    bf16 [wrows][ldw], ldw >= ceil64(K); rows >= wrows read as zero.
  *   bias:   fp32 [N] or NULL.
  *   c:      [M][ldc] fp32 or bf16, columns 0..ncols-1 written (ncols % 4 == 0): with ncols =
- *           ceil64(N) and a zero-padded w_p the padding columns come out as zeros.
+ *           ceil64(N) and a zero-padded w_p the padding columns come out as zeros.  accumulate != 0
+ *           (fp32 c only): the product is added to what c holds.
  *   a_copy: NULL, or bf16 [M][lda_copy]: receives a rounded to bf16 with the columns K..ceil64(K)-1
  *           zeroed (the operand the weight-gradient GEMM wants), saving a separate cast pass.
  * K <= 192 takes any ncols; K > 192 is run in slabs of 64/128/192 columns of a. */
 int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w_p, void *w_pt, void *stream);
 int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
                int ldw, const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols,
-               void *a_copy, long long lda_copy, void *stream);
+               int accumulate, void *a_copy, long long lda_copy, void *stream);
 
 /* Weight and bias gradient of those projections (torch.nn.Linear backward behind the same call
  * sites): dw[n][k] = sum_m dy[m][n] x[m][k], db[n] = sum_m dy[m][n], fp32, summed in a fixed order.
@@ -290,6 +291,25 @@ int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, co
 size_t dsw_linear_wgrad_workspace(long long M, int N);
 int dsw_linear_wgrad(const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K,
                      float *dw, float *db, float *workspace, void *stream);
+
+/* The first convolution of the DS-MSA sparse discriminator (nn.Conv2d(dim, 4, 3, 1, 1),
+ * DSwinT_arch.py:181) as a GEMM on the matrix cores, for bf16 runs: with Wf[4 t + o][c] = w0[o][c][t]
+ * (t = 3 ky + kx), P = x . Wf^T by dsw_linear gives the 36 products of every pixel,
+ * dsw_sd_stencil_fwd gathers them, t0[px][o] = b0[o] + sum_t P[px + off(t)][4 t + o] (zero padding), and
+ * dsw_sparse_disc_tail_fwd runs the rest of the discriminator (:182-185) on t0.  Backward:
+ * dsw_sparse_disc_tail_bwd returns dt0 and the gradients of the two small convolutions,
+ * dsw_sd_gather_bwd lays out G[px][4 t + o] = dt0[px - off(t)][o] (bf16 [pixels][64], columns 36.. zero),
+ * and then dx = G . Wf (dsw_linear on Wf^T), dWf = G^T . x and db0[o] = column 16 + o of G summed
+ * (dsw_linear_wgrad).
+ *   P: fp32 [B*H*W][ldp], ldp >= 36, ldp % 4 == 0.  t0, dt0: fp32 [B][H][W][4].  u: fp32 [B][4][H/w][W/w].
+ *   du: scratch of B*4*(H/w)*(W/w) floats. */
+int dsw_sd_stencil_fwd(const float *P, int ldp, const float *b0, int B, int H, int W, float *t0, void *stream);
+int dsw_sd_gather_bwd(const float *dt0, int B, int H, int W, void *G, void *stream);
+int dsw_sparse_disc_tail_fwd(const float *t0, const float *w2, const float *b2, const float *w4, const float *b4,
+                             int B, int H, int W, int w, float *u, void *sd, int sd_dtype, void *stream);
+int dsw_sparse_disc_tail_bwd(const void *dsd, int dsd_dtype, const float *w2, const float *w4, const float *t0,
+                             const float *u, int B, int H, int W, int w, float *du, float *dt0, float *dw2,
+                             float *db2, float *dw4, float *db4, void *stream);
 
 #ifdef __cplusplus
 }

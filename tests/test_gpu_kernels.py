@@ -401,7 +401,7 @@ def test_linear_kernel(cuda0, M, K, N, a_dtype, c_dtype, pad_a, pad_c, copy):
     a_copy = torch.full((M, _ceil64(K)), float("nan"), device=cuda0, dtype=bf) if copy else None
     Kk = lda if (a_dtype == bf and pad_a) else K
     _lib.call("dsw_linear", _lib.ptr(a), _lib.dtype_code(a_dtype), lda, M, Kk, _lib.ptr(wp), wp.shape[0], wp.shape[1], _lib.ptr(bias), N,
-              _lib.ptr(c), _lib.dtype_code(c_dtype), ncols, ncols, _lib.ptr(a_copy) if copy else None, a_copy.shape[1] if copy else 0,
+              _lib.ptr(c), _lib.dtype_code(c_dtype), ncols, ncols, 0, _lib.ptr(a_copy) if copy else None, a_copy.shape[1] if copy else 0,
               _lib.stream(cuda0))
     ref = a[:, :K].to(bf).float() @ w.to(bf).float().t() + bias
     tol = 1e-2 if c_dtype == bf else 1e-5 * K

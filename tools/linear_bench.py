@@ -25,7 +25,7 @@ def prep(w):
 
 def run(a, K, wp, bias, N, c, ncols, a_copy=None):
     _lib.call("dsw_linear", _lib.ptr(a), _lib.dtype_code(a.dtype), a.stride(0), a.shape[0], K, _lib.ptr(wp), wp.shape[0], wp.stride(0),
-              _lib.ptr(bias) if bias is not None else None, N, _lib.ptr(c), _lib.dtype_code(c.dtype), c.stride(0), ncols,
+              _lib.ptr(bias) if bias is not None else None, N, _lib.ptr(c), _lib.dtype_code(c.dtype), c.stride(0), ncols, 0,
               _lib.ptr(a_copy) if a_copy is not None else None, a_copy.stride(0) if a_copy is not None else 0, _lib.stream(dev))
 
 

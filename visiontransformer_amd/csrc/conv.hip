@@ -644,6 +644,48 @@ template <typename K> static int set_lds_attr(K kern, size_t lds, const char *wh
     return DSW_OK;
 }
 
+// ---- first conv of the sparse discriminator as a GEMM (bf16 runs) -------------------------------
+// conv C -> 4, 3x3 = for every pixel the 36 products P[px][4 t + o] = sum_c x[px][c] w0[o][c][t] (one
+// [pixels, C] x [C, 36] GEMM on the matrix cores, dsw_linear) followed by a 9-point gather of them:
+//   t0[px][o] = b0[o] + sum_t P[px + off(t)][4 t + o],   off(t) = (t / 3 - 1, t % 3 - 1), zero outside.
+__global__ __launch_bounds__(256) void sd_stencil_fwd_kernel(const float *__restrict__ P, int ldp, const float *__restrict__ b0, int B,
+                                                              int H, int W, float *__restrict__ t0) {
+    const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (px >= (long long)B * H * W) return;
+    const int xw = (int)(px % W), yh = (int)((px / W) % H);
+    float4 acc = *reinterpret_cast<const float4 *>(b0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        if (yh + dy >= 0 && yh + dy < H && xw + dx >= 0 && xw + dx < W)
+            acc = acc + *reinterpret_cast<const float4 *>(P + (size_t)(px + dy * W + dx) * ldp + 4 * t);
+    }
+    *reinterpret_cast<float4 *>(t0 + (size_t)px * 4) = acc;
+}
+
+// The transposed gather for the backward pass: G[px][4 t + o] = dt0[px - off(t)][o] (zero outside the
+// image), bf16 rows of 64 with columns 36.. zero.  Then dx = G . Wf and dWf = G^T . x are plain GEMMs
+// (Wf[4 t + o][c] = w0[o][c][t]), and column 16 + o of G summed over pixels is db0[o].
+__global__ __launch_bounds__(256) void sd_gather_bwd_kernel(const float *__restrict__ dt0, int B, int H, int W, bf16_t *__restrict__ G) {
+    const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (px >= (long long)B * H * W) return;
+    const int xw = (int)(px % W), yh = (int)((px / W) % H);
+    uint32_t out[32];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        float4 v = f4zero();
+        if (yh - dy >= 0 && yh - dy < H && xw - dx >= 0 && xw - dx < W) v = *reinterpret_cast<const float4 *>(dt0 + (size_t)(px - dy * W - dx) * 4);
+        out[2 * t] = pack_bf16(v.x, v.y);
+        out[2 * t + 1] = pack_bf16(v.z, v.w);
+    }
+#pragma unroll
+    for (int i = 18; i < 32; ++i) out[i] = 0u;
+    uint4 *dst = reinterpret_cast<uint4 *>(G + (size_t)px * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+}
+
 }  // namespace dsw
 
 using namespace dsw;
@@ -704,6 +746,40 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
     return check_launch("split10_kernel");
 }
 
+extern "C" int dsw_sd_stencil_fwd(const float *P, int ldp, const float *b0, int B, int H, int W, float *t0, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || ldp < 36 || ldp % 4) return fail(DSW_EINVAL, "dsw_sd_stencil_fwd: bad sizes B=%d H=%d W=%d ldp=%d", B, H, W, ldp);
+    DSW_REQUIRE(P && b0 && t0, "dsw_sd_stencil_fwd: null pointer");
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(sd_stencil_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), P, ldp, b0, B, H, W, t0);
+    return check_launch("sd_stencil_fwd_kernel");
+}
+
+extern "C" int dsw_sd_gather_bwd(const float *dt0, int B, int H, int W, void *G, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return fail(DSW_EINVAL, "dsw_sd_gather_bwd: bad sizes B=%d H=%d W=%d", B, H, W);
+    DSW_REQUIRE(dt0 && G, "dsw_sd_gather_bwd: null pointer");
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(sd_gather_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), dt0, B, H, W, (bf16_t *)G);
+    return check_launch("sd_gather_bwd_kernel");
+}
+
+extern "C" int dsw_sparse_disc_tail_fwd(const float *t0, const float *w2, const float *b2, const float *w4, const float *b4, int B,
+                                        int H, int W, int w, float *u, void *sd, int sd_dtype, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return fail(DSW_EINVAL, "dsw_sparse_disc_tail_fwd: bad sizes B=%d H=%d W=%d", B, H, W);
+    DSW_REQUIRE(w > 0 && H % w == 0 && W % w == 0, "dsw_sparse_disc_tail_fwd: H,W (%d,%d) must be multiples of %d", H, W, w);
+    if (w % 4) return fail(DSW_EUNSUPPORTED, "dsw_sparse_disc_tail_fwd: window size %d must be a multiple of 4", w);
+    DSW_REQUIRE(t0 && w2 && b2 && w4 && b4 && u && sd, "dsw_sparse_disc_tail_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int Hw = H / w, Ww = W / w;
+    hipLaunchKernelGGL(sd_stage_u_kernel, dim3(B * Hw * Ww), dim3(256), 0, st, t0, w2, b2, H, W, w, u);
+    int rc = check_launch("sd_stage_u_kernel");
+    if (rc) return rc;
+    const int n = B * 4 * Hw * Ww;
+    DSW_DISPATCH_DTYPE(sd_dtype, TO, {
+        hipLaunchKernelGGL((sd_stage_b_kernel<TO>), dim3((n + 255) / 256), dim3(256), 0, st, u, w4, b4, B, Hw, Ww, (TO *)sd);
+    });
+    return check_launch("sd_stage_b_kernel");
+}
+
 extern "C" int dsw_sparse_disc_fwd(const void *x, int x_dtype, const float *w0, const float *b0, const float *w2,
                                    const float *b2, const float *w4, const float *b4, int B, int H, int W, int C, int w,
                                    float *t0, float *u, void *sd, int sd_dtype, void *stream) {
@@ -713,7 +789,6 @@ extern "C" int dsw_sparse_disc_fwd(const void *x, int x_dtype, const float *w0, 
     if (w % 4) return fail(DSW_EUNSUPPORTED, "dsw_sparse_disc_fwd: window size %d must be a multiple of 4", w);
     DSW_REQUIRE(x && w0 && b0 && w2 && b2 && w4 && b4 && t0 && u && sd, "dsw_sparse_disc_fwd: null pointer");
     hipStream_t st = as_stream(stream);
-    const int Hw = H / w, Ww = W / w;
     const size_t lds = (size_t)(9 * C * 4) * sizeof(float);
     const long long nstrips = (long long)B * H * (W / 4);
     DSW_DISPATCH_DTYPE(x_dtype, TX, {
@@ -726,14 +801,26 @@ extern "C" int dsw_sparse_disc_fwd(const void *x, int x_dtype, const float *w0, 
     });
     rc = check_launch("sd_stage_a_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(sd_stage_u_kernel, dim3(B * Hw * Ww), dim3(256), 0, st, t0, w2, b2, H, W, w, u);
-    rc = check_launch("sd_stage_u_kernel");
-    if (rc) return rc;
-    const int n = B * 4 * Hw * Ww;
-    DSW_DISPATCH_DTYPE(sd_dtype, TO, {
-        hipLaunchKernelGGL((sd_stage_b_kernel<TO>), dim3((n + 255) / 256), dim3(256), 0, st, u, w4, b4, B, Hw, Ww, (TO *)sd);
+    return dsw_sparse_disc_tail_fwd(t0, w2, b2, w4, b4, B, H, W, w, u, sd, sd_dtype, stream);
+}
+
+extern "C" int dsw_sparse_disc_tail_bwd(const void *dsd, int dsd_dtype, const float *w2, const float *w4, const float *t0,
+                                        const float *u, int B, int H, int W, int w, float *du, float *dt0, float *dw2, float *db2,
+                                        float *dw4, float *db4, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return fail(DSW_EINVAL, "dsw_sparse_disc_tail_bwd: bad sizes B=%d H=%d W=%d", B, H, W);
+    DSW_REQUIRE(w > 0 && H % w == 0 && W % w == 0, "dsw_sparse_disc_tail_bwd: H,W (%d,%d) must be multiples of %d", H, W, w);
+    DSW_REQUIRE(dsd && w2 && w4 && t0 && u && du && dt0 && dw2 && db2 && dw4 && db4, "dsw_sparse_disc_tail_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int Hw = H / w, Ww = W / w, L = w * w, n = B * 4 * Hw * Ww;
+    DSW_DISPATCH_DTYPE(dsd_dtype, TG, {
+        hipLaunchKernelGGL((sd_bwd_b_kernel<TG>), dim3((n + 255) / 256), dim3(256), 0, st, (const TG *)dsd, u, w4, B, Hw, Ww, du);
+        hipLaunchKernelGGL((sd_bwd_w4_kernel<TG>), dim3(148), dim3(256), 0, st, (const TG *)dsd, u, B, Hw, Ww, dw4, db4);
     });
-    return check_launch("sd_stage_b_kernel");
+    int rc = check_launch("sd_bwd_b/w4 kernels");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sd_bwd_a_pix_kernel, dim3((B * H * W + 255) / 256), dim3(256), 0, st, du, t0, w2, B, H, W, w, dt0);
+    hipLaunchKernelGGL(sd_bwd_w2_kernel, dim3((4 * L + 1 + 15) / 16), dim3(256), 0, st, du, t0, B, H, W, w, dw2, db2);
+    return check_launch("sd_bwd_a/w2 kernels");
 }
 
 extern "C" int dsw_sparse_disc_bwd_blocks(int B, int H) { return B > 0 && H > 0 ? B * ((H + SD_ROWS - 1) / SD_ROWS) : 0; }
@@ -748,7 +835,7 @@ extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x
     DSW_REQUIRE(dsd && x && w0 && w2 && w4 && t0 && u && dx && dw0 && db0 && dw2 && db2 && dw4 && db4 && scratch,
                 "dsw_sparse_disc_bwd: null pointer");
     hipStream_t st = as_stream(stream);
-    const int Hw = H / w, Ww = W / w, L = w * w, n = B * 4 * Hw * Ww;
+    const int Hw = H / w, Ww = W / w, n = B * 4 * Hw * Ww;
     // scratch layout: du [n] | dt0 [B*H*W*4] | w0 partials [nblk][4*C*9+4] | packed [4*C*9+4]
     float *du = scratch;
     float *dt0 = du + ((n + 3) & ~3);
@@ -756,15 +843,7 @@ extern "C" int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x
     const int nblk = dsw_sparse_disc_bwd_blocks(B, H);
     const int np = 4 * C * 9 + 4;
     float *packed = part + (size_t)nblk * np;
-    DSW_DISPATCH_DTYPE(dsd_dtype, TG, {
-        hipLaunchKernelGGL((sd_bwd_b_kernel<TG>), dim3((n + 255) / 256), dim3(256), 0, st, (const TG *)dsd, u, w4, B, Hw, Ww, du);
-        hipLaunchKernelGGL((sd_bwd_w4_kernel<TG>), dim3(148), dim3(256), 0, st, (const TG *)dsd, u, B, Hw, Ww, dw4, db4);
-    });
-    rc = check_launch("sd_bwd_b/w4 kernels");
-    if (rc) return rc;
-    hipLaunchKernelGGL(sd_bwd_a_pix_kernel, dim3((B * H * W + 255) / 256), dim3(256), 0, st, du, t0, w2, B, H, W, w, dt0);
-    hipLaunchKernelGGL(sd_bwd_w2_kernel, dim3((4 * L + 1 + 15) / 16), dim3(256), 0, st, du, t0, B, H, W, w, dw2, db2);
-    rc = check_launch("sd_bwd_a/w2 kernels");
+    rc = dsw_sparse_disc_tail_bwd(dsd, dsd_dtype, w2, w4, t0, u, B, H, W, w, du, dt0, dw2, db2, dw4, db4, stream);
     if (rc) return rc;
     const size_t lds = (size_t)36 * C * sizeof(float);
     DSW_DISPATCH_DTYPE(dx_dtype, TO, {

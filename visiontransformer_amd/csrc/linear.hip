@@ -112,7 +112,7 @@ template <typename TA, typename TC, int KS, bool PERSIST>
 __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
-    long long lda_copy, int chunks_per_block) {
+    long long lda_copy, int chunks_per_block, int accumulate) {
     using cfg = LnCfg<KS>;
     constexpr int LS = cfg::LS, NKS = cfg::NKS;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -186,9 +186,16 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
             for (int i = 0; i < 4; ++i) {
                 const int row = i * 8 + (lane >> 3), m = m0 + wave * 32 + row;
                 const int col = nb + ps * SW + (lane & 7) * PC;
-                const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * SROW + (lane & 7) * 16);
+                uint4 v = *reinterpret_cast<const uint4 *>(stg + row * SROW + (lane & 7) * 16);
                 TC *dst = C + (size_t)m * ldc + col;
                 if (m < M) {
+                    if constexpr (sizeof(TC) == 4) {
+                        if (accumulate && col + PC <= ncols) {
+                            const float4 o = *reinterpret_cast<const float4 *>(dst);
+                            v = make_uint4(__float_as_uint(__uint_as_float(v.x) + o.x), __float_as_uint(__uint_as_float(v.y) + o.y),
+                                           __float_as_uint(__uint_as_float(v.z) + o.z), __float_as_uint(__uint_as_float(v.w) + o.w));
+                        }
+                    }
                     if (col + PC <= ncols) *reinterpret_cast<uint4 *>(dst) = v;
                     else if (sizeof(TC) == 2 && col + 4 <= ncols) *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
                 }
@@ -437,7 +444,7 @@ int set_lds(const void *kern, size_t lds, const char *who) {
 
 template <typename TA, typename TC, int KS>
 int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
-                  void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, hipStream_t st) {
+                  void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, int accumulate, hipStream_t st) {
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
@@ -457,12 +464,12 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
         auto kern = linear_nt_kernel<TA, TC, KS, true>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, accumulate);
     } else {
         auto kern = linear_nt_kernel<TA, TC, KS, false>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, accumulate);
     }
     return check_launch("linear_nt_kernel");
 }
@@ -484,8 +491,8 @@ extern "C" int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w
 }
 
 extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
-                          const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, void *a_copy, long long lda_copy,
-                          void *stream) {
+                          const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
+                          long long lda_copy, void *stream) {
     if (M <= 0 || M > 0x7fffff00LL || K <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
     DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
@@ -502,13 +509,14 @@ extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M
         return fail(DSW_EUNSUPPORTED, "dsw_linear: bias needs N %% 4 == 0, N <= ncols, a 16-byte aligned base (N=%d ncols=%d)", N, ncols);
     if (a_copy != nullptr && (lda_copy < Kp || lda_copy % 8 || ((uintptr_t)a_copy & 15)))
         return fail(DSW_EUNSUPPORTED, "dsw_linear: the bf16 copy of A needs rows of >= %d elements, a multiple of 8 (lda_copy=%lld)", Kp, lda_copy);
+    if (accumulate && c_dtype != DSW_F32) return fail(DSW_EUNSUPPORTED, "dsw_linear: accumulation needs an fp32 result");
     const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 ? 128 : 64);
     const int nslab = Kp / KS;
     hipStream_t st = as_stream(stream);
     int rc = DSW_OK;
 #define DSW_LINEAR_KS(KSV)                                                                                                     \
     DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
-        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, st); \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, accumulate, st); \
     }))
     if (KS == 192) DSW_LINEAR_KS(192);
     else if (KS == 128) DSW_LINEAR_KS(128);

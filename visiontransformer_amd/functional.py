@@ -470,6 +470,11 @@ def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None):
 
 
 class _SparseDiscFn(torch.autograd.Function):
+    """The sparse discriminator.  fp32 runs: NHWC fp32 kernels for all three convolutions.  bf16 runs:
+    the first convolution (C -> 4, 3x3: nearly all of the arithmetic and traffic) goes to the matrix
+    cores as a [pixels, C] x [C, 36] product followed by a 9-point gather, and its input / weight
+    gradients are the transposed products (see dsw_sd_stencil_fwd in the header)."""
+
     @staticmethod
     def forward(ctx, x, w0, b0, w2, b2, w4, b4, w, out_dtype, sink):
         _lib.require_cuda(x)
@@ -480,31 +485,73 @@ class _SparseDiscFn(torch.autograd.Function):
         t0 = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
         u = torch.empty(B, 4, H // w, W // w, dtype=torch.float32, device=dev)
         sd = torch.empty(B, 4, H // w, W // w, dtype=out_dtype, device=dev)
-        call("dsw_sparse_disc_fwd", ptr(x), dtype_code(x.dtype), *[ptr(p) for p in ps], B, H, W, C, w, ptr(t0), ptr(u),
-             ptr(sd), dtype_code(out_dtype), stream(dev))
-        ctx.save_for_backward(x, ps[0], ps[2], ps[4], t0, u)
-        ctx.meta = (w, [(p.shape, p.dtype) for p in (w0, b0, w2, b2, w4, b4)], sink)
+        Kp = _ceil_pad(C)
+        mfma = (out_dtype == torch.bfloat16 and C % 4 == 0 and Kp <= 192 and x.dtype in (torch.float32, torch.bfloat16)
+                and _mfma_operand(x.view(-1, C)) is not None)
+        if mfma:
+            M = B * H * W
+            wf = ps[0].permute(2, 3, 0, 1).reshape(36, C).contiguous()   # Wf[4 t + o][c] = w0[o][c][t]
+            w_p, w_pt = _weight_operands(wf)
+            xk = _mark_padded(torch.empty(M, Kp, dtype=torch.bfloat16, device=dev)) if ctx.needs_input_grad[1] else None
+            P = torch.empty(M, 36, dtype=torch.float32, device=dev)
+            _mfma_linear(x.view(M, C), C, w_p, None, 0, P, 36, xk)
+            call("dsw_sd_stencil_fwd", ptr(P), 36, ptr(ps[1]), B, H, W, ptr(t0), stream(dev))
+            call("dsw_sparse_disc_tail_fwd", ptr(t0), *[ptr(p) for p in ps[2:]], B, H, W, w, ptr(u), ptr(sd), dtype_code(out_dtype),
+                 stream(dev))
+            ctx.save_for_backward(xk if xk is not None else x, w_pt, ps[2], ps[4], t0, u)
+        else:
+            call("dsw_sparse_disc_fwd", ptr(x), dtype_code(x.dtype), *[ptr(p) for p in ps], B, H, W, C, w, ptr(t0), ptr(u),
+                 ptr(sd), dtype_code(out_dtype), stream(dev))
+            ctx.save_for_backward(x, ps[0], ps[2], ps[4], t0, u)
+        ctx.meta = (w, [(p.shape, p.dtype) for p in (w0, b0, w2, b2, w4, b4)], sink, mfma, (x.shape, x.dtype))
         return sd
 
     @staticmethod
     def backward(ctx, dsd):
         x, w0, w2, w4, t0, u = ctx.saved_tensors
-        w, pmeta, sink = ctx.meta
-        B, H, W, C = x.shape
+        w, pmeta, sink, mfma, (xshape, xdtype) = ctx.meta
+        B, H, W, C = xshape
         dev = x.device
         dsd = dsd.contiguous()
         if not ctx.needs_input_grad[0]:
             sink = None
-        dx, acc = _dx_target(sink, x.shape, x.dtype, x.device)
+        dx, acc = _dx_target(sink, xshape, xdtype, dev)
         f32 = dict(dtype=torch.float32, device=dev)
         g = [torch.empty(4 * C * 9, **f32), torch.empty(4, **f32), torch.empty(16 * w * w, **f32), torch.empty(4, **f32),
              torch.empty(144, **f32), torch.empty(4, **f32)]
-        nfl = _lib.load().dsw_sparse_disc_bwd_scratch(B, H, W, C, w)
-        scratch = torch.empty(int(nfl), **f32)
-        call("dsw_sparse_disc_bwd", ptr(dsd), dtype_code(dsd.dtype), ptr(x), dtype_code(x.dtype), ptr(w0), ptr(w2), ptr(w4),
-             ptr(t0), ptr(u), B, H, W, C, w, ptr(dx), dtype_code(dx.dtype), acc, *[ptr(t) for t in g], ptr(scratch),
-             stream(dev))
-        grads = [t.view(shape).to(dt) for t, (shape, dt) in zip(g, pmeta)]
+        if mfma:
+            M = B * H * W
+            xk, w_pt = x, w0
+            du = torch.empty(B * 4 * (H // w) * (W // w), **f32)
+            dt0 = torch.empty(M, 4, **f32)
+            call("dsw_sparse_disc_tail_bwd", ptr(dsd), dtype_code(dsd.dtype), ptr(w2), ptr(w4), ptr(t0), ptr(u), B, H, W, w, ptr(du),
+                 ptr(dt0), ptr(g[2]), ptr(g[3]), ptr(g[4]), ptr(g[5]), stream(dev))
+            G = torch.empty(M, 64, dtype=torch.bfloat16, device=dev)
+            call("dsw_sd_gather_bwd", ptr(dt0), B, H, W, ptr(G), stream(dev))
+            if ctx.needs_input_grad[0]:
+                if dx.dtype == torch.float32:
+                    _mfma_linear(G, 64, w_pt, None, 0, dx.view(M, C), C, None, accumulate=bool(acc))
+                else:
+                    d32 = torch.empty(M, C, **f32)
+                    _mfma_linear(G, 64, w_pt, None, 0, d32, C, None)
+                    dx.view(M, C).add_(d32) if acc else dx.view(M, C).copy_(d32)
+            if ctx.needs_input_grad[1]:
+                Kp = xk.shape[1]
+                dwf = torch.empty(36, C, **f32)
+                dbf = torch.empty(36, **f32) if C < Kp else None
+                ws = torch.empty(int(_lib.load().dsw_linear_wgrad_workspace(M, 36)), **f32)
+                call("dsw_linear_wgrad", ptr(G), 64, ptr(xk), Kp, M, 36, C, ptr(dwf), None if dbf is None else ptr(dbf), ptr(ws), stream(dev))
+                g[0] = dwf.view(3, 3, 4, C).permute(2, 3, 0, 1).contiguous()
+                g[1] = dbf[16:20] if dbf is not None else dt0.sum(0)
+            else:
+                g[0] = g[1] = None
+        else:
+            nfl = _lib.load().dsw_sparse_disc_bwd_scratch(B, H, W, C, w)
+            scratch = torch.empty(int(nfl), **f32)
+            call("dsw_sparse_disc_bwd", ptr(dsd), dtype_code(dsd.dtype), ptr(x), dtype_code(x.dtype), ptr(w0), ptr(w2), ptr(w4),
+                 ptr(t0), ptr(u), B, H, W, C, w, ptr(dx), dtype_code(dx.dtype), acc, *[ptr(t) for t in g], ptr(scratch),
+                 stream(dev))
+        grads = [None if t is None else t.reshape(shape).to(dt) for t, (shape, dt) in zip(g, pmeta)]
         return (_dx_deliver(sink, dx), *grads, None, None, None)
 
 
@@ -632,11 +679,12 @@ def _mfma_operand(t2):
     return None
 
 
-def _mfma_linear(a2, K, w_op, bias, N, out, ncols, a_copy):
-    """out[:, :ncols] = a2[:, :K] @ w_op[:ncols, :]^T (+ bias); a_copy (optional) receives a2 in padded bf16 rows"""
+def _mfma_linear(a2, K, w_op, bias, N, out, ncols, a_copy, accumulate=False):
+    """out[:, :ncols] (+)= a2[:, :K] @ w_op[:ncols, :]^T (+ bias); a_copy (optional) receives a2 in padded bf16 rows"""
     call("dsw_linear", ctypes.c_void_p(a2.data_ptr()), dtype_code(a2.dtype), a2.stride(0) if a2.shape[0] > 1 else a2.shape[1],
          a2.shape[0], K, ptr(w_op), w_op.shape[0], w_op.shape[1], None if bias is None else ptr(bias), N, ptr(out),
-         dtype_code(out.dtype), out.shape[1], ncols, None if a_copy is None else ptr(a_copy),
+         dtype_code(out.dtype), out.stride(0) if out.shape[0] > 1 else out.shape[1], ncols, 1 if accumulate else 0,
+         None if a_copy is None else ptr(a_copy),
          0 if a_copy is None else a_copy.shape[1], stream(out.device))
 
 
