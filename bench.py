@@ -86,6 +86,7 @@ def kernel_rooflines(device, iters=20, warm=3, k=4, attention=True):
     # DS-MSA side: k windows per image (config B: 4), all passing, random corners
     x = torch.randn(B_PER_GPU, HW, HW, C, device=device)
     _window_rooflines(device, iters, warm, k, x, out)
+    _projection_rooflines(device, iters, warm, x, out)
     for v in out.values():
         if "achieved" in v:
             v["frac"] = v["achieved"] / v["peak"]
@@ -108,10 +109,15 @@ def _attention_rooflines(device, iters, warm, out):
                                                 grid=(B_PER_GPU, HW, HW)), iters, warm)
     t_b = time_calls(lambda: torch.autograd.grad(o, (qkv, tab), do, retain_graph=True), iters, warm)
     flops_f, flops_b = 4.0 * T * L * C, 8.0 * T * L * C
-    out["win_attn_fwd"] = dict(bound="mfma", achieved=flops_f / t_f / 1e12, peak=MFMA_BF16_PEAK_TFLOPS,
-                               unit="TFLOP/s", us=t_f * 1e6, algorithmic=flops_f)
-    out["win_attn_bwd"] = dict(bound="mfma", achieved=flops_b / t_b / 1e12, peak=MFMA_BF16_PEAK_TFLOPS,
-                               unit="TFLOP/s", us=t_b * 1e6, algorithmic=flops_b)
+    # algorithmic HBM bytes (bf16): forward reads qkv, writes out (+ lse); backward reads qkv, out, dout
+    # (+ lse), writes dqkv.  At head dim 30 both passes need more time on the HBM roofline than on the
+    # MFMA one (128 flop/byte against the machine's 312), so
+    # HBM is the roofline that bounds them; the MFMA rate is reported next to it.
+    by_f = T * (3 * C + C) * 2 + T * HEADS * 4
+    by_b = T * (3 * C + C + C + 3 * C) * 2 + T * HEADS * 4
+    for name, t, fl, by in (("win_attn_fwd", t_f, flops_f, by_f), ("win_attn_bwd", t_b, flops_b, by_b)):
+        out[name] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t * 1e6, algorithmic=by,
+                         flops=fl, mfma_tflops=fl / t / 1e12, mfma_frac=fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS)
 
 
 def _window_rooflines(device, iters, warm, k, x, out):
@@ -166,6 +172,42 @@ def _window_rooflines(device, iters, warm, k, x, out):
                                    us=t_sc * 1e6, algorithmic=by_sc)
     out["scatter_mean_bwd"] = dict(bound="hbm", achieved=by_scb / t_scb / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                    us=t_scb * 1e6, algorithmic=by_scb, note="three kernels: dx, window side, reduce")
+
+
+def _projection_rooflines(device, iters, warm, x, out):
+    """The projection kernels at the windowed-MSA shapes (all tokens), through the C ABI: qkv from the
+    fp32 stream (with the bf16 copy for the weight gradient), its input gradient back into an fp32
+    buffer, and its weight + bias gradient."""
+    from visiontransformer_amd._lib import call, dtype_code, load, ptr, stream
+    bf = torch.bfloat16
+    M, K, N = x.numel() // C, C, 3 * C
+    Kp, Np = (K + 63) // 64 * 64, (N + 63) // 64 * 64
+    st = stream(device)
+    f32c, bfc = dtype_code(torch.float32), dtype_code(bf)
+    w = torch.randn(N, K, device=device) * 0.05
+    bias = torch.randn(N, device=device)
+    w_p = torch.empty(Np, Kp, device=device, dtype=bf)
+    w_pt = torch.empty(Kp, Np, device=device, dtype=bf)
+    call("dsw_weight_prep", ptr(w), f32c, N, K, ptr(w_p), ptr(w_pt), st)
+    x2 = x.view(M, K)
+    y = torch.empty(M, Np, device=device, dtype=bf)
+    xk = torch.empty(M, Kp, device=device, dtype=bf)
+    fwd = lambda: call("dsw_linear", ptr(x2), f32c, K, M, K, ptr(w_p), Np, Kp, ptr(bias), N, ptr(y), bfc, Np, Np, 0, ptr(xk), Kp, st)
+    t_f = time_calls(fwd, iters, warm)
+    dx = torch.empty(M, K, device=device)
+    dgrad = lambda: call("dsw_linear", ptr(y), bfc, Np, M, Np, ptr(w_pt), Kp, Np, None, 0, ptr(dx), f32c, K, K, 0, None, 0, st)
+    t_d = time_calls(dgrad, iters, warm)
+    dw, db = torch.empty(N, K, device=device), torch.empty(N, device=device)
+    ws = torch.empty(load().dsw_linear_wgrad_workspace(M, N), device=device)
+    wgrad = lambda: call("dsw_linear_wgrad", ptr(y), Np, ptr(xk), Kp, M, N, K, ptr(dw), ptr(db), ptr(ws), st)
+    t_w = time_calls(wgrad, iters, warm)
+    by_f = M * (K * 4 + Np * 2 + Kp * 2)
+    by_d = M * (Np * 2 + K * 4)
+    by_w = M * (Np * 2 + Kp * 2)
+    for name, t, by, note in (("linear_qkv_fwd", t_f, by_f, "fp32 in, bf16 out + bf16 copy of the input"),
+                              ("linear_qkv_dgrad", t_d, by_d, "bf16 in, fp32 out"),
+                              ("linear_qkv_wgrad", t_w, by_w, "two kernels: split-K product, fixed-order sum")):
+        out[name] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t * 1e6, algorithmic=by, note=note)
 
 
 def pmc_traffic(kernel):
@@ -298,8 +340,8 @@ def main():
         if not args.no_kernels:
             ks = kernel_rooflines(device)
             dom = ks["win_attn_bwd"]
-            line["roofline"] = {"bound": "mfma", "kernel": "win_attn_bwd_kernel<bf16,w16,d32>", "achieved": dom["achieved"],
-                                "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"],
+            line["roofline"] = {"bound": "hbm", "kernel": "win_attn_bwd_kernel<bf16,w16,d32>", "achieved": dom["achieved"],
+                                "peak": dom["peak"], "unit": "GB/s", "frac": dom["frac"], "mfma_frac": dom["mfma_frac"],
                                 "traffic": pmc_traffic("win_attn_bwd_kernel<unsigned short, 16, 32, true, true>"),
                                 "us_per_launch": dom["us"]}
             line["kernels"] = ks
