@@ -20,6 +20,9 @@ def build(name, edit):
     print("built", name)
 V = {
  "base": lambda s: s,
+ "noDQst": lambda s: s.replace("            if (ee < d) {\n#pragma unroll\n                for (int r = 0; r < 4; ++r) io<T>::st(dqkv + trow(qb * 32 + 16 * mq + 4 * l4 + r) * C3 + qoff + ee, v[r] * scale);", "            if (ee < d && scale == 12345.f) {\n#pragma unroll\n                for (int r = 0; r < 4; ++r) io<T>::st(dqkv + trow(qb * 32 + 16 * mq + 4 * l4 + r) * C3 + qoff + ee, v[r] * scale);"),
+ "noDKVst": lambda s: s.replace("                if (2 * dw < d) {\n                    T *dst = dqkv + trow(32 * tile + row) * C3 + (which == 0 ? koff : voff) + 2 * dw;", "                if (2 * dw < d && scale == 12345.f) {\n                    T *dst = dqkv + trow(32 * tile + row) * C3 + (which == 0 ? koff : voff) + 2 * dw;"),
+ "noBGws": lambda s: s.replace("                dst[it] = acc;\n            }\n        } else {\n            const int dj = (tid % (2 * WS)) - (WS - 1);", "                if (scale == 12345.f) dst[it] = acc;\n            }\n        } else {\n            const int dj = (tid % (2 * WS)) - (WS - 1);"),
  "noKt": lambda s: s.replace("Kl[e * KTS + row] = (T)(k2 & 0xffffu);", "if (row == 99999) Kl[e * KTS + row] = (T)(k2 & 0xffffu);").replace("Kl[(e + 1) * KTS + row] = (T)(k2 >> 16);", "if (row == 99999) Kl[(e + 1) * KTS + row] = (T)(k2 >> 16);"),
  "noDsW": lambda s: s.replace("*reinterpret_cast<uint2 *>(dsrow + 4 * ((c0 & 4) | ((c0 & 3) ^ fk))) = make_uint2(db.x, db.y);", "if (fk == 99) *reinterpret_cast<uint2 *>(dsrow) = make_uint2(db.x, db.y);").replace("*reinterpret_cast<uint2 *>(dsrow + 4 * ((c1 & 4) | ((c1 & 3) ^ fk))) = make_uint2(db.z, db.w);", "if (fk == 98) *reinterpret_cast<uint2 *>(dsrow) = make_uint2(db.z, db.w);"),
  "noTrQG": lambda s: s.replace("const uint2 g0 = lds_read_tr16(gtr + (16 * s) * QS + 32 * u), g1 = lds_read_tr16(gtr + (16 * s + 8) * QS + 32 * u);", "const uint2 g0 = make_uint2(pb.x, pb.y), g1 = make_uint2(pb.z, pb.w);").replace("const uint2 q0 = lds_read_tr16(qtr + (16 * s) * QS + 32 * u), q1 = lds_read_tr16(qtr + (16 * s + 8) * QS + 32 * u);", "const uint2 q0 = make_uint2(db.x, db.y), q1 = make_uint2(db.z, db.w);"),

@@ -664,23 +664,24 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
 
 // d_table[t][h] = sum over windows of ws[(win*heads + h)*T + t], in a fixed order: 16 window
 // groups (window index mod 16) summed by 16 threads each, then the 16 partials in group order.
+// A block takes 16 consecutive entries t of one head: each read instruction covers 64-byte runs of ws.
 __global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int heads, int T,
                                                                float *__restrict__ d_table) {
     __shared__ float part[16][17];
     const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + e;  // entry index t*heads + h
+    const int chunks = (T + 15) / 16;
+    const int h = blockIdx.x / chunks, t = (blockIdx.x - h * chunks) * 16 + e;
     float acc = 0.f;
-    if (i < T * heads) {
-        const int t = i / heads, h = i - t * heads;
+    if (t < T) {
         for (int wdx = grp; wdx < n_win; wdx += 16) acc += ws[((size_t)wdx * heads + h) * T + t];
     }
     part[grp][e] = acc;
     __syncthreads();
-    if (grp == 0 && i < T * heads) {
+    if (grp == 0 && t < T) {
         float tot = 0.f;
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) tot += part[k2][e];
-        d_table[i] = tot;
+        d_table[(size_t)t * heads + h] = tot;
     }
 }
 
@@ -839,7 +840,7 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
     if (rc) return rc;
     if (bias) {
         const int T2 = (2 * WS - 1) * (2 * WS - 1);
-        hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((T2 * g.heads + 15) / 16), dim3(256), 0, st, ws_table,
+        hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(g.heads * ((T2 + 15) / 16)), dim3(256), 0, st, ws_table,
                            g.n_win, g.heads, T2, d_table);
         rc = check_launch("bias_grad_reduce_kernel");
         if (rc) return rc;
