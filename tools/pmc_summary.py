@@ -16,7 +16,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"dsw::(\w+)", name)
+    m = re.search(r"dsw::(?:\(anonymous namespace\)::)?(\w+)", name)
     if not m:
         return None
     args = re.search(r"<([^>]*)>", name)
