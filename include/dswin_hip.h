@@ -311,6 +311,19 @@ int dsw_sparse_disc_tail_bwd(const void *dsd, int dsd_dtype, const float *w2, co
                              const float *u, int B, int H, int W, int w, float *du, float *dt0, float *dw2,
                              float *db2, float *dw4, float *db4, void *stream);
 
+/* RMSNorm over channel rows of the fp32 stream (the nn.RMSNorm layers of the reference's ViTBlock,
+ * DSwinT_arch.py:343-345, applied at :355-357): out[m][c] = x[m][c] * rstd[m] * weight[c] with
+ * rstd[m] = rsqrt(mean_c x[m][c]^2 + eps), written as fp32 or bf16 with row stride ldo >= C (columns
+ * C..ldo-1 are set to zero: the projection kernels take such rows as they are).  C % 4 == 0, C <= 256.
+ *   rstd: fp32 [M] (NULL when no backward follows).
+ * Backward: dx (fp32 [M][C]) and per-block partial sums of d(weight): partial is
+ * dsw_rmsnorm_blocks(M) x C floats, to be summed over its rows (e.g. dsw_colsum). */
+int dsw_rmsnorm_blocks(long long M);
+int dsw_rmsnorm_fwd(const float *x, const float *weight, float eps, long long M, int C, void *out, int out_dtype,
+                    long long ldo, float *rstd, void *stream);
+int dsw_rmsnorm_bwd(const void *dy, int dy_dtype, long long ld_dy, const float *x, const float *weight,
+                    const float *rstd, long long M, int C, float *dx, float *partial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -470,3 +470,36 @@ def test_linear_function_against_torch(cuda0):
             res.append((y.float(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
         for got, ref in zip(res[1], res[0]):
             assert rel_err(got, ref) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C", [(1, 4), (77, 180), (4099, 192), (1000, 256)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16_padded"])
+def test_rms_norm(cuda0, M, C, mode):
+    """K.rms_norm against nn.RMSNorm: fp32 output and gradients to 1e-5; the bf16 padded form
+    (under autocast, for a projection) equal to the fp32 result rounded to bf16, padding columns zero."""
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(M + C)
+    norm = torch.nn.RMSNorm(C).to(cuda0)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+    x = (torch.randn(M, C, device=cuda0) * 3).requires_grad_()
+    dy = torch.randn(M, C, device=cuda0)
+    ref = norm(x)
+    gx, gw = torch.autograd.grad(ref, (x, norm.weight), dy)
+    if mode == "fp32":
+        got = K.rms_norm(x, norm)
+        assert got.dtype == torch.float32 and rel_err(got, ref) < 1e-5
+        hx, hw = torch.autograd.grad(got, (x, norm.weight), dy)
+        assert rel_err(hx, gx) < 1e-5 and rel_err(hw, gw) < 1e-5
+    else:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got = K.rms_norm(x, norm, for_projection=True)
+        assert got.dtype == torch.bfloat16 and got.shape == (M, C)
+        assert rel_err(got.float(), ref.to(torch.bfloat16).float()) < 1e-2
+        ldo = (C + 63) // 64 * 64
+        if ldo != C:
+            buf = got._base
+            assert buf.shape == (M, ldo) and buf[:, C:].abs().max().item() == 0
+        hx, hw = torch.autograd.grad(got, (x, norm.weight), dy.to(torch.bfloat16))
+        assert rel_err(hx, gx) < 2e-2 and rel_err(hw, gw) < 2e-2

@@ -55,6 +55,9 @@ SIGNATURES = {
     "dsw_sparse_disc_tail_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "dsw_linear_wgrad_workspace": (_Z, [ctypes.c_longlong, _I]),
     "dsw_linear_wgrad": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _I, _I, _P, _P, _P, _P]),
+    "dsw_rmsnorm_blocks": (_I, [ctypes.c_longlong]),
+    "dsw_rmsnorm_fwd": (_I, [_P, _P, _F, ctypes.c_longlong, _I, _P, _I, ctypes.c_longlong, _P, _P]),
+    "dsw_rmsnorm_bwd": (_I, [_P, _I, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, _P, _P, _P]),
     "dsw_colsum_blocks": (_I, [ctypes.c_longlong]),
     "dsw_colsum": (_I, [_P, _I, ctypes.c_longlong, _I, _P, _P, _P]),
     "dsw_dwconv3x3_bwd_blocks": (_I, [_I, _I, _I]),

@@ -834,3 +834,58 @@ def linear(x, lin, pad_out=False):
     out_features columns); for callers whose consumers accept such views."""
     act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
     return _LinearFn.apply(x, lin.weight, lin.bias, act, bool(pad_out))
+
+
+# ---------------------------------------------------------------------------------------------
+# RMSNorm in front of the attention modules / the MLP (DSwinT_arch.py:343-345, :355-357)
+# ---------------------------------------------------------------------------------------------
+class _RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, eps, out_dtype, pad_out):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        M = x2.shape[0]
+        ldo = _ceil_pad(C) if pad_out else C
+        w32 = weight.detach().float().contiguous()
+        out = _mark_padded(torch.empty(M, ldo, dtype=out_dtype, device=x.device))
+        need_bwd = any(ctx.needs_input_grad[:2])
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device) if need_bwd else None
+        call("dsw_rmsnorm_fwd", ptr(x2), ptr(w32), float(eps), M, C, ptr(out), dtype_code(out_dtype), ldo,
+             None if rstd is None else ptr(rstd), stream(x.device))
+        if need_bwd:
+            ctx.save_for_backward(x2, w32, rstd)
+        ctx.meta = (x.shape, weight.dtype)
+        return out[:, :C].view(x.shape) if ldo != C else out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w32, rstd = ctx.saved_tensors
+        xshape, wdt = ctx.meta
+        M, C = x2.shape
+        dy2 = dy.reshape(-1, C)
+        if dy2.dtype not in (torch.float32, torch.bfloat16) or dy2.stride(1) != 1 or (M > 1 and dy2.stride(0) % 4) or \
+                dy2.data_ptr() % (4 * dy2.element_size()):
+            dy2 = dy2.float().contiguous()
+        dx = torch.empty(M, C, dtype=torch.float32, device=x2.device)
+        nblk = _lib.load().dsw_rmsnorm_blocks(M)
+        partial = torch.empty(nblk, C, dtype=torch.float32, device=x2.device)
+        call("dsw_rmsnorm_bwd", ctypes.c_void_p(dy2.data_ptr()), dtype_code(dy2.dtype), dy2.stride(0) if M > 1 else C, ptr(x2), ptr(w32),
+             ptr(rstd), M, C, ptr(dx), ptr(partial), stream(x2.device))
+        dw = colsum(partial).to(wdt) if ctx.needs_input_grad[1] else None
+        return dx.view(xshape), dw, None, None, None
+
+
+def rms_norm(x, norm, for_projection=False):
+    """`norm(x)` for an nn.RMSNorm over the last dimension of the fp32 stream.  for_projection: the
+    result feeds a projection - under bf16 autocast it is produced in bf16 rows padded to 64
+    elements (what autocast's cast in front of the Linear would make of it, without the fp32 round
+    trip) and returned as a view of the first C columns."""
+    C = x.shape[-1]
+    ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and _ceil_pad(C) <= 256
+          and norm.weight is not None and tuple(norm.normalized_shape) == (C,))
+    if not ok:
+        return norm(x)
+    eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
+    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    to_act = for_projection and act == torch.bfloat16
+    return _RMSNormFn.apply(x, norm.weight, eps, act if to_act else torch.float32, to_act)

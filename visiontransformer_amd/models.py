@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import dswin, msft
+from . import functional as K
 
 
 # ------------------------------------------------------------------------------------------------
@@ -44,7 +45,22 @@ class GatedMLP(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.act(self.fc1_gate(x)) * self.fc1_content(x)))
+        if not x.is_cuda:
+            return self.drop(self.fc2(self.act(self.fc1_gate(x)) * self.fc1_content(x)))
+        # gate and content share their input: one projection onto both (the rows of the two weights
+        # stacked), read from wherever x lies, then the gated product and fc2 through the same kernels
+        H = self.fc1_gate.out_features
+        both = _Stacked(torch.cat([self.fc1_gate.weight, self.fc1_content.weight]),
+                        torch.cat([self.fc1_gate.bias, self.fc1_content.bias]))
+        h = K.linear(x, both, pad_out=True)
+        return self.drop(K.linear(self.act(h[..., :H]) * h[..., H:], self.fc2))
+
+
+class _Stacked:
+    """weight / bias pair with the attribute names of an nn.Linear"""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
 
 
 class DSWTViTBlock(nn.Module):
@@ -64,9 +80,10 @@ class DSWTViTBlock(nn.Module):
         self.drop_path = nn.Dropout(drop_path)
 
     def forward(self, x):
-        x = x + self.rezero1 * self.drop_path(self.wmsa(self.ln1(x)))
-        x = x + self.rezero3 * self.drop_path(self.sdwa(self.ln3(x)))
-        x = x + self.rezero2 * self.drop_path(self.mlp1(self.ln2(x)))
+        # x + rezero * branch in one pass (addcmul broadcasts the scalar and promotes a bf16 branch)
+        x = torch.addcmul(x, self.rezero1, self.drop_path(self.wmsa(K.rms_norm(x, self.ln1, for_projection=True))))
+        x = torch.addcmul(x, self.rezero3, self.drop_path(self.sdwa(K.rms_norm(x, self.ln3))))
+        x = torch.addcmul(x, self.rezero2, self.drop_path(self.mlp1(K.rms_norm(x, self.ln2, for_projection=True))))
         return x
 
 
@@ -198,7 +215,7 @@ class MSFBlock_3(nn.Module):
             z = self.level_ds[i](z)
             maps.append(self.level_layer[i](z))
         lv = self.post_level_fuse(torch.cat(maps, dim=1))
-        return self.rezero * self.fuse(torch.cat([x, lv], dim=1)) + x
+        return torch.addcmul(x, self.rezero, self.fuse(torch.cat([x, lv], dim=1)))
 
 
 class MSFTResidualBlock(nn.Module):
