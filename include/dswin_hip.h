@@ -324,6 +324,16 @@ int dsw_rmsnorm_fwd(const float *x, const float *weight, float eps, long long M,
 int dsw_rmsnorm_bwd(const void *dy, int dy_dtype, long long ld_dy, const float *x, const float *weight,
                     const float *rstd, long long M, int C, float *dx, float *partial, void *stream);
 
+/* The gated activation of the reference's MLP (DSwinT_arch.py:47-69, fc2(act(fc1_gate(x)) *
+ * fc1_content(x))) on h = [gate | content] rows (the two fc1 projections computed as one product):
+ * out[m][j] = silu(h[m][j]) * h[m][H + j], j < H; columns H..ldo-1 of out are zeroed.  Backward:
+ * dh[m][j] and dh[m][H + j] from dout and h, row stride ldh, columns 2H..ldh-1 zeroed.
+ * H and all row strides are multiples of 4 elements; fp32 or bf16 on either side. */
+int dsw_gated_silu_fwd(const void *h, int h_dtype, long long ldh, int H, long long M, void *out, int out_dtype,
+                       long long ldo, void *stream);
+int dsw_gated_silu_bwd(const void *dout, int dout_dtype, long long ld_dout, const void *h, int h_dtype,
+                       long long ldh, int H, long long M, void *dh, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

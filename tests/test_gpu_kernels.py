@@ -503,3 +503,29 @@ def test_rms_norm(cuda0, M, C, mode):
             assert buf.shape == (M, ldo) and buf[:, C:].abs().max().item() == 0
         hx, hw = torch.autograd.grad(got, (x, norm.weight), dy.to(torch.bfloat16))
         assert rel_err(hx, gx) < 2e-2 and rel_err(hw, gw) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H,padded", [(5, 4, False), (333, 360, True), (1000, 64, False)])
+def test_gated_silu(cuda0, dtype, M, H, padded):
+    """silu(gate) * content on [gate | content] rows (dense, or a view of rows padded to 64) against torch,
+    forward and backward; padding columns of the results are zero."""
+    import torch.nn.functional as F
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(M + H)
+    ld = (2 * H + 63) // 64 * 64 if padded else 2 * H
+    buf = torch.zeros(M, ld, device=cuda0, dtype=dtype)
+    buf[:, :2 * H] = torch.randn(M, 2 * H, device=cuda0).to(dtype)
+    h = buf[:, :2 * H].detach().requires_grad_()
+    dy = torch.randn(M, H, device=cuda0).to(dtype)
+    hr = h.detach().float().requires_grad_()
+    ref = F.silu(hr[:, :H]) * hr[:, H:]
+    gr, = torch.autograd.grad(ref, hr, dy.float())
+    got = K.gated_silu(h, pad_out=True)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert got.shape == (M, H) and got.dtype == dtype and rel_err(got.float(), ref) < tol
+    if got._base is not None and got._base.shape[1] > H:
+        assert got._base[:, H:].abs().max().item() == 0
+    gg, = torch.autograd.grad(got, h, dy)
+    assert rel_err(gg.float(), gr) < tol

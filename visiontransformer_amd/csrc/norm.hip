@@ -147,3 +147,88 @@ extern "C" int dsw_rmsnorm_bwd(const void *dy, int dy_dtype, long long ld_dy, co
     });
     return check_launch("rmsnorm_bwd_kernel");
 }
+
+// ---- gated SiLU of the MLP (DSwinT_arch.py:47-69: fc2(act(fc1_gate(x)) * fc1_content(x))) ----------
+// h holds gate | content side by side in one row (the two fc1 projections computed as one product):
+//   out[m][j] = silu(h[m][j]) * h[m][H + j],  j < H;  columns H..ldo-1 of out are set to zero.
+namespace dsw {
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+template <typename TH, typename TO>
+__global__ __launch_bounds__(256) void gated_silu_fwd_kernel(const TH *__restrict__ h, long long ldh, int H, long long M,
+                                                             TO *__restrict__ out, long long ldo) {
+    const int per_row = (int)(ldo / 4);
+    const long long items = M * per_row;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const long long m = it / per_row;
+        const int j = (int)(it - m * per_row) * 4;
+        float4 y = f4zero();
+        if (j < H) {
+            const float4 g = io<TH>::ld4(h + m * ldh + j), c = io<TH>::ld4(h + m * ldh + H + j);
+            y = make_float4(g.x * sigmoidf_(g.x) * c.x, g.y * sigmoidf_(g.y) * c.y, g.z * sigmoidf_(g.z) * c.z, g.w * sigmoidf_(g.w) * c.w);
+        }
+        io<TO>::st4(out + m * ldo + j, y);
+    }
+}
+
+// dh[m][j] = dout c s (1 + g (1 - s)),  dh[m][H + j] = dout g s,  s = sigmoid(g);  columns 2H..ldh-1 := 0
+template <typename TH, typename TO>
+__global__ __launch_bounds__(256) void gated_silu_bwd_kernel(const TO *__restrict__ dout, long long ldg, const TH *__restrict__ h,
+                                                             long long ldh, int H, long long M, TH *__restrict__ dh) {
+    const int per_row = (int)(ldh / 4);
+    const long long items = M * per_row;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const long long m = it / per_row;
+        const int j = (int)(it - m * per_row) * 4;
+        float4 r = f4zero();
+        if (j < 2 * H) {
+            const int jj = j < H ? j : j - H;
+            const float4 g = io<TH>::ld4(h + m * ldh + jj), c = io<TH>::ld4(h + m * ldh + H + jj), d = io<TO>::ld4(dout + m * ldg + jj);
+            const float gs[4] = {g.x, g.y, g.z, g.w}, cs[4] = {c.x, c.y, c.z, c.w}, ds[4] = {d.x, d.y, d.z, d.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s = sigmoidf_(gs[e]);
+                o[e] = j < H ? ds[e] * cs[e] * s * (1.f + gs[e] * (1.f - s)) : ds[e] * gs[e] * s;
+            }
+            r = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        io<TH>::st4(dh + m * ldh + j, r);
+    }
+}
+
+int gs_check(const char *who, long long M, int H, long long ldh, long long ld2) {
+    if (M <= 0 || H <= 0 || ldh < 2 * H || ld2 < H) return fail(DSW_EINVAL, "%s: bad sizes M=%lld H=%d ld=%lld / %lld", who, M, H, ldh, ld2);
+    if (H % 4 || ldh % 4 || ld2 % 4) return fail(DSW_EUNSUPPORTED, "%s: H and the row strides must be multiples of 4 (H=%d, %lld, %lld)", who, H, ldh, ld2);
+    return DSW_OK;
+}
+unsigned gs_blocks(long long items) { return (unsigned)((items + 255) / 256 < 16384 ? (items + 255) / 256 : 16384); }
+
+}  // namespace
+}  // namespace dsw
+
+extern "C" int dsw_gated_silu_fwd(const void *h, int h_dtype, long long ldh, int H, long long M, void *out, int out_dtype, long long ldo,
+                                  void *stream) {
+    int rc = gs_check("dsw_gated_silu_fwd", M, H, ldh, ldo);
+    if (rc) return rc;
+    DSW_REQUIRE(h && out, "dsw_gated_silu_fwd: null pointer");
+    DSW_DISPATCH_DTYPE(h_dtype, TH, DSW_DISPATCH_DTYPE(out_dtype, TO, {
+        hipLaunchKernelGGL((gated_silu_fwd_kernel<TH, TO>), dim3(gs_blocks(M * (ldo / 4))), dim3(256), 0, as_stream(stream), (const TH *)h, ldh,
+                           H, M, (TO *)out, ldo);
+    }));
+    return check_launch("gated_silu_fwd_kernel");
+}
+
+extern "C" int dsw_gated_silu_bwd(const void *dout, int dout_dtype, long long ld_dout, const void *h, int h_dtype, long long ldh, int H,
+                                  long long M, void *dh, void *stream) {
+    int rc = gs_check("dsw_gated_silu_bwd", M, H, ldh, ld_dout);
+    if (rc) return rc;
+    DSW_REQUIRE(dout && h && dh, "dsw_gated_silu_bwd: null pointer");
+    DSW_DISPATCH_DTYPE(h_dtype, TH, DSW_DISPATCH_DTYPE(dout_dtype, TO, {
+        hipLaunchKernelGGL((gated_silu_bwd_kernel<TH, TO>), dim3(gs_blocks(M * (ldh / 4))), dim3(256), 0, as_stream(stream), (const TO *)dout,
+                           ld_dout, (const TH *)h, ldh, H, M, (TH *)dh);
+    }));
+    return check_launch("gated_silu_bwd_kernel");
+}

@@ -889,3 +889,41 @@ def rms_norm(x, norm, for_projection=False):
     act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
     to_act = for_projection and act == torch.bfloat16
     return _RMSNormFn.apply(x, norm.weight, eps, act if to_act else torch.float32, to_act)
+
+
+# ---------------------------------------------------------------------------------------------
+# gated activation of the MLP (DSwinT_arch.py:47-69)
+# ---------------------------------------------------------------------------------------------
+class _GatedSiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, H, pad_out):
+        h2, ldh = _row_view4(h, 2 * H)
+        M = h2.shape[0]
+        ldo = _ceil_pad(H) if pad_out else H
+        out = _mark_padded(torch.empty(M, ldo, dtype=h.dtype, device=h.device))
+        call("dsw_gated_silu_fwd", _dptr(h2), dtype_code(h2.dtype), ldh, H, M, ptr(out), dtype_code(out.dtype), ldo, stream(h.device))
+        ctx.save_for_backward(h2)
+        ctx.meta = (h.shape, H, ldh)
+        return (out[:, :H] if ldo != H else out).view(h.shape[:-1] + (H,))
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2, = ctx.saved_tensors
+        hshape, H, ldh = ctx.meta
+        M = h2.shape[0]
+        if dout.dtype != h2.dtype:
+            dout = dout.to(h2.dtype)
+        d2, ldg = _row_view4(dout, H)
+        # the gradient keeps the row stride of h: padded rows (padding zeroed) go on to the projection's backward
+        dh = _mark_padded(torch.empty(M, ldh, dtype=h2.dtype, device=h2.device))
+        call("dsw_gated_silu_bwd", _dptr(d2), dtype_code(d2.dtype), ldg, _dptr(h2), dtype_code(h2.dtype), ldh, H, M, ptr(dh),
+             stream(h2.device))
+        return (dh[:, :2 * H] if ldh != 2 * H else dh).view(hshape), None, None
+
+
+def gated_silu(h, pad_out=False):
+    """silu(h[..., :H]) * h[..., H:] for h = [gate | content] (fp32 or bf16 on the GPU)"""
+    H = h.shape[-1] // 2
+    if not (h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[-1] == 2 * H and H % 4 == 0):
+        return torch.nn.functional.silu(h[..., :H]) * h[..., H:]
+    return _GatedSiluFn.apply(h, H, bool(pad_out))

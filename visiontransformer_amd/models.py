@@ -53,6 +53,8 @@ class GatedMLP(nn.Module):
         both = _Stacked(torch.cat([self.fc1_gate.weight, self.fc1_content.weight]),
                         torch.cat([self.fc1_gate.bias, self.fc1_content.bias]))
         h = K.linear(x, both, pad_out=True)
+        if isinstance(self.act, nn.SiLU):
+            return self.drop(K.linear(K.gated_silu(h, pad_out=True), self.fc2))
         return self.drop(K.linear(self.act(h[..., :H]) * h[..., H:], self.fc2))
 
 
