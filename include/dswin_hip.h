@@ -334,6 +334,17 @@ int dsw_gated_silu_fwd(const void *h, int h_dtype, long long ldh, int H, long lo
 int dsw_gated_silu_bwd(const void *dout, int dout_dtype, long long ld_dout, const void *h, int h_dtype,
                        long long ldh, int H, long long M, void *dh, void *stream);
 
+/* The ReZero residual of the reference's ViTBlock (DSwinT_arch.py:355-357), y = x + r * branch, in one
+ * pass: x, y fp32 [M][C]; branch fp32 or bf16 with row stride ldb; r one fp32 value on the device.
+ * Backward (dx = dy needs no kernel): d_branch = r * dy in branch's dtype with row stride ld_db (columns
+ * C..ld_db-1 zeroed) and partial[i] = block i's share of dr = sum dy * branch; partial holds
+ * dsw_rezero_blocks(M, ld_db) floats, summed by the caller.  C and the strides are multiples of 4. */
+int dsw_rezero_blocks(long long M, long long ld);
+int dsw_rezero_fwd(const float *x, const void *branch, int b_dtype, long long ldb, const float *r, long long M,
+                   int C, float *y, void *stream);
+int dsw_rezero_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r, long long M,
+                   int C, void *d_branch, long long ld_db, float *partial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

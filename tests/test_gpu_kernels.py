@@ -529,3 +529,26 @@ def test_gated_silu(cuda0, dtype, M, H, padded):
         assert got._base[:, H:].abs().max().item() == 0
     gg, = torch.autograd.grad(got, h, dy)
     assert rel_err(gg.float(), gr) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bdtype,padded", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
+def test_rezero_residual(cuda0, bdtype, padded):
+    """x + r * branch in one kernel against torch.addcmul, with the gradients of all three inputs."""
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(7)
+    B, H, W, C = 2, 9, 11, 180
+    x = torch.randn(B, H, W, C, device=cuda0, requires_grad=True)
+    r = torch.nn.Parameter(torch.tensor([0.37], device=cuda0))
+    ld = 192 if padded else C
+    buf = torch.zeros(B * H * W, ld, device=cuda0, dtype=bdtype)
+    buf[:, :C] = torch.randn(B * H * W, C, device=cuda0).to(bdtype)
+    br = buf[:, :C].view(B, H, W, C).detach().requires_grad_()
+    dy = torch.randn(B, H, W, C, device=cuda0)
+    ref = torch.addcmul(x, r, br)
+    gx, gr, gb = torch.autograd.grad(ref, (x, r, br), dy)
+    got = K.rezero_residual(x, r, br)
+    hx, hr, hb = torch.autograd.grad(got, (x, r, br), dy)
+    tol = 1e-5 if bdtype == torch.float32 else 1e-2
+    assert rel_err(got, ref) < 1e-6 and rel_err(hx, gx) < 1e-6
+    assert rel_err(hr, gr) < 1e-4 and rel_err(hb.float(), gb.float()) < tol

@@ -232,3 +232,86 @@ extern "C" int dsw_gated_silu_bwd(const void *dout, int dout_dtype, long long ld
     }));
     return check_launch("gated_silu_bwd_kernel");
 }
+
+// ---- ReZero residual of the reference's ViTBlock (DSwinT_arch.py:355-357): y = x + r * branch -------
+// x, y: the fp32 stream [M][C]; branch: fp32 or bf16 rows with their own stride (the padded views the
+// attention modules and the MLP return); r: one fp32 parameter on the device.
+namespace dsw {
+namespace {
+
+template <typename TB>
+__global__ __launch_bounds__(256) void rezero_fwd_kernel(const float *__restrict__ x, const TB *__restrict__ b, long long ldb,
+                                                         const float *__restrict__ r, long long M, int C, float *__restrict__ y) {
+    const float rv = *r;
+    const int per_row = C / 4;
+    const long long items = M * per_row;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const long long m = it / per_row;
+        const int j = (int)(it - m * per_row) * 4;
+        const float4 xv = *reinterpret_cast<const float4 *>(x + m * C + j), bv = io<TB>::ld4(b + m * ldb + j);
+        *reinterpret_cast<float4 *>(y + m * C + j) = xv + bv * rv;
+    }
+}
+
+// db = r * dy (rows of stride ld_db, padding columns zeroed), partial[block] = sum over its items of dy * b
+template <typename TB>
+__global__ __launch_bounds__(256) void rezero_bwd_kernel(const float *__restrict__ dy, const TB *__restrict__ b, long long ldb,
+                                                         const float *__restrict__ r, long long M, int C, TB *__restrict__ db,
+                                                         long long ld_db, float *__restrict__ partial) {
+    __shared__ float red[4];
+    const float rv = *r;
+    const int per_row = (int)(ld_db / 4), nv = C / 4;
+    const long long items = M * per_row;
+    float acc = 0.f;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const long long m = it / per_row;
+        const int jv = (int)(it - m * per_row), j = jv * 4;
+        float4 o = f4zero();
+        if (jv < nv) {
+            const float4 g = *reinterpret_cast<const float4 *>(dy + m * C + j), bv = io<TB>::ld4(b + m * ldb + j);
+            acc += g.x * bv.x + g.y * bv.y + g.z * bv.z + g.w * bv.w;
+            o = g * rv;
+        }
+        io<TB>::st4(db + m * ld_db + j, o);
+    }
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+constexpr int RZ_BLOCKS = 2048;
+int rz_check(const char *who, long long M, int C, long long ldb) {
+    if (M <= 0 || C <= 0 || ldb < C) return fail(DSW_EINVAL, "%s: bad sizes M=%lld C=%d ldb=%lld", who, M, C, ldb);
+    if (C % 4 || ldb % 4) return fail(DSW_EUNSUPPORTED, "%s: C and the row strides must be multiples of 4 (C=%d ldb=%lld)", who, C, ldb);
+    return DSW_OK;
+}
+unsigned rz_blocks(long long items) { return (unsigned)((items + 255) / 256 < RZ_BLOCKS ? (items + 255) / 256 : RZ_BLOCKS); }
+
+}  // namespace
+}  // namespace dsw
+
+extern "C" int dsw_rezero_blocks(long long M, long long ld) { return M > 0 && ld > 0 ? (int)rz_blocks(M * (ld / 4)) : 0; }
+
+extern "C" int dsw_rezero_fwd(const float *x, const void *branch, int b_dtype, long long ldb, const float *r, long long M, int C, float *y,
+                              void *stream) {
+    int rc = rz_check("dsw_rezero_fwd", M, C, ldb);
+    if (rc) return rc;
+    DSW_REQUIRE(x && branch && r && y, "dsw_rezero_fwd: null pointer");
+    DSW_DISPATCH_DTYPE(b_dtype, TB, {
+        hipLaunchKernelGGL(rezero_fwd_kernel<TB>, dim3(rz_blocks(M * (C / 4))), dim3(256), 0, as_stream(stream), x, (const TB *)branch, ldb, r,
+                           M, C, y);
+    });
+    return check_launch("rezero_fwd_kernel");
+}
+
+extern "C" int dsw_rezero_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r, long long M, int C,
+                              void *d_branch, long long ld_db, float *partial, void *stream) {
+    int rc = rz_check("dsw_rezero_bwd", M, C, ldb);
+    if (rc) return rc;
+    if (ld_db < C || ld_db % 4) return fail(DSW_EUNSUPPORTED, "dsw_rezero_bwd: gradient row stride %lld (a multiple of 4, >= C)", ld_db);
+    DSW_REQUIRE(dy && branch && r && d_branch && partial, "dsw_rezero_bwd: null pointer");
+    DSW_DISPATCH_DTYPE(b_dtype, TB, {
+        hipLaunchKernelGGL(rezero_bwd_kernel<TB>, dim3(rz_blocks(M * (ld_db / 4))), dim3(256), 0, as_stream(stream), dy, (const TB *)branch,
+                           ldb, r, M, C, (TB *)d_branch, ld_db, partial);
+    });
+    return check_launch("rezero_bwd_kernel");
+}

@@ -927,3 +927,51 @@ def gated_silu(h, pad_out=False):
     if not (h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[-1] == 2 * H and H % 4 == 0):
         return torch.nn.functional.silu(h[..., :H]) * h[..., H:]
     return _GatedSiluFn.apply(h, H, bool(pad_out))
+
+
+# ---------------------------------------------------------------------------------------------
+# ReZero residual of the ViTBlock (DSwinT_arch.py:355-357)
+# ---------------------------------------------------------------------------------------------
+class _RezeroFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, branch):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        b2, ldb = _row_view4(branch, C)
+        M = x2.shape[0]
+        r32 = r.detach().float().reshape(1).contiguous()
+        y = torch.empty(M, C, dtype=torch.float32, device=x.device)
+        call("dsw_rezero_fwd", ptr(x2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(y), stream(x.device))
+        ctx.save_for_backward(b2, r32)
+        ctx.meta = (x.shape, branch.shape, ldb, r.shape, r.dtype)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        b2, r32 = ctx.saved_tensors
+        xshape, bshape, ldb, rshape, rdt = ctx.meta
+        M, C = b2.shape
+        dy2 = dy.reshape(-1, C)
+        if dy2.dtype != torch.float32 or not dy2.is_contiguous():
+            dy2 = dy2.float().contiguous()
+        db = dr = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            ld_db = ldb if ldb > C else C     # padded rows stay padded on the way back
+            dbuf = _mark_padded(torch.empty(M, ld_db, dtype=b2.dtype, device=b2.device))
+            partial = torch.empty(_lib.load().dsw_rezero_blocks(M, ld_db), dtype=torch.float32, device=b2.device)
+            call("dsw_rezero_bwd", ptr(dy2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(dbuf), ld_db, ptr(partial),
+                 stream(b2.device))
+            db = (dbuf[:, :C] if ld_db != C else dbuf).view(bshape)
+            dr = partial.sum().reshape(rshape).to(rdt)
+        return dy, dr, db
+
+
+def rezero_residual(x, r, branch):
+    """x + r * branch for the fp32 stream x [..., C], a one-element parameter r and a branch of the same
+    shape in fp32 / bf16 (dense or a view of padded rows)."""
+    C = x.shape[-1]
+    ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and r.numel() == 1
+          and branch.shape == x.shape and branch.dtype in (torch.float32, torch.bfloat16))
+    if not ok:
+        return torch.addcmul(x, r, branch)
+    return _RezeroFn.apply(x, r, branch)

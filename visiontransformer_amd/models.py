@@ -82,10 +82,10 @@ class DSWTViTBlock(nn.Module):
         self.drop_path = nn.Dropout(drop_path)
 
     def forward(self, x):
-        # x + rezero * branch in one pass (addcmul broadcasts the scalar and promotes a bf16 branch)
-        x = torch.addcmul(x, self.rezero1, self.drop_path(self.wmsa(K.rms_norm(x, self.ln1, for_projection=True))))
-        x = torch.addcmul(x, self.rezero3, self.drop_path(self.sdwa(K.rms_norm(x, self.ln3))))
-        x = torch.addcmul(x, self.rezero2, self.drop_path(self.mlp1(K.rms_norm(x, self.ln2, for_projection=True))))
+        # x + rezero * branch in one pass over the fp32 stream, the branch read where it lies
+        x = K.rezero_residual(x, self.rezero1, self.drop_path(self.wmsa(K.rms_norm(x, self.ln1, for_projection=True))))
+        x = K.rezero_residual(x, self.rezero3, self.drop_path(self.sdwa(K.rms_norm(x, self.ln3))))
+        x = K.rezero_residual(x, self.rezero2, self.drop_path(self.mlp1(K.rms_norm(x, self.ln2, for_projection=True))))
         return x
 
 
