@@ -246,3 +246,28 @@ def test_msft_model_golden(cuda0):
     assert y.shape == g["y"].shape
     assert rel_err(y, g["y"]) < TOL
     _check_grads(mod, g, x, y, cuda0)
+
+
+def test_prepared_weights_follow_the_parameters(cuda0):
+    """Without autograd the bf16 operands of a projection are kept per parameter: an in-place update of
+    the parameter (optimizer step, load_state_dict) must be seen by the next call."""
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(180, 540).to(cuda0)
+    x = torch.randn(300, 180, device=cuda0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y0 = K.linear(x, lin).float()
+        y1 = K.linear(x, lin).float()
+        assert torch.equal(y0, y1)
+        lin.weight.mul_(2.0)
+        lin.bias.zero_()
+        y2 = K.linear(x, lin).float()
+        ref = torch.nn.functional.linear(x, lin.weight, lin.bias).float()
+    assert rel_err(y2, ref) < 2e-2 and rel_err(y2, y0) > 0.1
+    mlp_mod = __import__("visiontransformer_amd.models", fromlist=["GatedMLP"]).GatedMLP(180, ffn_scale=2).to(cuda0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a = mlp_mod(x).float()
+        mlp_mod.fc1_content.weight.mul_(0.5)
+        b = mlp_mod(x).float()
+        ref = mlp_mod.fc2(torch.nn.functional.silu(mlp_mod.fc1_gate(x)) * mlp_mod.fc1_content(x)).float()
+    assert rel_err(b, ref) < 3e-2 and rel_err(a, b) > 0.05

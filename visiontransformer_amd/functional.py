@@ -5,6 +5,7 @@ passes raw device pointers and the current HIP stream to the library, and saves 
 exactly what the backward kernels read.  Nothing here computes on the CPU.
 """
 import ctypes
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -658,14 +659,28 @@ def _cast_padded(t2, act):
     return cast_rows(t2, act, _ceil_pad(t2.shape[1]))
 
 
+_PREP_CACHE = {}
+
+
 def _weight_operands(weight):
-    """nn.Linear weight [N, K] -> zero-padded bf16 [ceil64(N), ceil64(K)] and its transpose (one launch)"""
+    """nn.Linear weight [N, K] -> zero-padded bf16 [ceil64(N), ceil64(K)] and its transpose (one launch).
+    Without autograd (inference) the pair is kept per parameter and reused until the parameter is
+    modified in place or replaced; with autograd the weights change every step and nothing is kept."""
     N, Kd = weight.shape
+    caching = not torch.is_grad_enabled()
+    if caching:
+        e = _PREP_CACHE.get(id(weight))
+        if e is not None and e[0]() is weight and e[1] == weight._version and e[2] == weight.data_ptr():
+            return e[3], e[4]
     Np, Kp = _ceil_pad(N), _ceil_pad(Kd)
     w = weight.detach()
     w_p = torch.empty(Np, Kp, dtype=torch.bfloat16, device=w.device)
     w_pt = torch.empty(Kp, Np, dtype=torch.bfloat16, device=w.device)
     call("dsw_weight_prep", ptr(w), dtype_code(w.dtype), N, Kd, ptr(w_p), ptr(w_pt), stream(w.device))
+    if caching:
+        if len(_PREP_CACHE) > 4096:
+            _PREP_CACHE.clear()
+        _PREP_CACHE[id(weight)] = (weakref.ref(weight), weight._version, weight.data_ptr(), w_p, w_pt)
     return w_p, w_pt
 
 

@@ -31,6 +31,13 @@ class LastChannelConv2D(nn.Module):
         return self.conv(x.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
 
 
+class _Stacked:
+    """weight / bias pair with the attribute names of an nn.Linear"""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+
+
 class GatedMLP(nn.Module):
     """SiLU-gated MLP (DSwinT_arch.py:47-69); registered under the reference's name `MLP`."""
 
@@ -44,25 +51,30 @@ class GatedMLP(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
+    def _stacked(self):
+        """rows of fc1_gate and fc1_content stacked; kept between calls when autograd is off and the
+        parameters have not been modified"""
+        ps = (self.fc1_gate.weight, self.fc1_content.weight, self.fc1_gate.bias, self.fc1_content.bias)
+        if torch.is_grad_enabled():
+            return _Stacked(torch.cat(ps[:2]), torch.cat(ps[2:]))
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        kept = getattr(self, "_kept_fc1", None)
+        if kept is None or kept[0] != key:
+            kept = (key, _Stacked(torch.cat(ps[:2]).detach(), torch.cat(ps[2:]).detach()))
+            object.__setattr__(self, "_kept_fc1", kept)
+        return kept[1]
+
     def forward(self, x):
         if not x.is_cuda:
             return self.drop(self.fc2(self.act(self.fc1_gate(x)) * self.fc1_content(x)))
         # gate and content share their input: one projection onto both (the rows of the two weights
         # stacked), read from wherever x lies, then the gated product and fc2 through the same kernels
         H = self.fc1_gate.out_features
-        both = _Stacked(torch.cat([self.fc1_gate.weight, self.fc1_content.weight]),
-                        torch.cat([self.fc1_gate.bias, self.fc1_content.bias]))
+        both = self._stacked()
         h = K.linear(x, both, pad_out=True)
         if isinstance(self.act, nn.SiLU):
             return self.drop(K.linear(K.gated_silu(h, pad_out=True), self.fc2))
         return self.drop(K.linear(self.act(h[..., :H]) * h[..., H:], self.fc2))
-
-
-class _Stacked:
-    """weight / bias pair with the attribute names of an nn.Linear"""
-
-    def __init__(self, weight, bias):
-        self.weight, self.bias = weight, bias
 
 
 class DSWTViTBlock(nn.Module):
