@@ -345,6 +345,18 @@ int dsw_rezero_fwd(const float *x, const void *branch, int b_dtype, long long ld
 int dsw_rezero_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r, long long M,
                    int C, void *d_branch, long long ld_db, float *partial, void *stream);
 
+/* Dense 3x3 convolution, stride 1, zero padding 1, on an NHWC tensor (the LastChannelConv2D layers of the
+ * reference's model assembly, DSwinT_arch.py:36-44, used at :372 and :420), forward only, on the matrix
+ * cores: the product kernel of dsw_linear with one k slab per tap, the rows of tap t read shifted by
+ * (t / 3 - 1, t % 3 - 1) pixels and as zero outside the image.
+ *   x:   [B][H][W][ldx] fp32 or bf16 (rounded to bf16 on load), below 2 GiB.
+ *   w_p: bf16 [wrows][ldw] with w_p[co][t * ceil64(C) + ci] = weight[co][ci][t / 3][t % 3], zero elsewhere
+ *        (dsw_weight_prep of the tap-major, channel-padded matrix).
+ *   out: [B*H*W][ldo] fp32 or bf16, columns 0..ncols-1 written; bias fp32 [N] or NULL. */
+int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p,
+                     int wrows, int ldw, const float *bias, int N, void *out, int out_dtype, long long ldo,
+                     int ncols, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -552,3 +552,24 @@ def test_rezero_residual(cuda0, bdtype, padded):
     tol = 1e-5 if bdtype == torch.float32 else 1e-2
     assert rel_err(got, ref) < 1e-6 and rel_err(hx, gx) < 1e-6
     assert rel_err(hr, gr) < 1e-4 and rel_err(hb.float(), gb.float()) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Ci,Co,xdtype", [(1, 5, 7, 12, 8, torch.float32), (2, 33, 20, 180, 180, torch.float32),
+                                                (1, 64, 64, 192, 64, torch.bfloat16), (3, 16, 16, 64, 256, torch.float32)])
+def test_conv3x3_nhwc(cuda0, B, H, W, Ci, Co, xdtype):
+    """The NHWC 3x3 convolution (inference, bf16 autocast) against F.conv2d on the same bf16-rounded
+    operands: borders, image boundaries inside the batch, channel counts off the 64 grid."""
+    import torch.nn.functional as F
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(B + H + Ci)
+    conv = torch.nn.Conv2d(Ci, Co, 3, 1, 1).to(cuda0)
+    x = torch.randn(B, H, W, Ci, device=cuda0).to(xdtype)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        got = K.conv3x3_nhwc(x, conv)
+    assert got is not None and got.shape == (B, H, W, Co) and got.dtype == torch.bfloat16
+    bf = torch.bfloat16
+    ref = F.conv2d(x.to(bf).float().permute(0, 3, 1, 2), conv.weight.to(bf).float(), conv.bias.float(), padding=1).permute(0, 2, 3, 1)
+    assert ((got.float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert K.conv3x3_nhwc(x, conv) is None      # autograd on: the stock convolution is used

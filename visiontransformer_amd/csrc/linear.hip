@@ -112,7 +112,7 @@ template <typename TA, typename TC, int KS, bool PERSIST>
 __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
-    long long lda_copy, int chunks_per_block, int accumulate) {
+    long long lda_copy, int chunks_per_block, int accumulate, int convH, int convW) {
     using cfg = LnCfg<KS>;
     constexpr int LS = cfg::LS, NKS = cfg::NKS;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -131,7 +131,12 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     // staging: 8 threads per row, 8 elements each = 64 columns; a slab is KS / 64 such column groups
     // (immediate offsets) over 4 (A: 128 rows) or 2 (weight chunk: 64 rows) row groups
     const int srow = tid >> 3, scol = (tid & 7) * 8;
-    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + (size_t)m0 * lda, ((size_t)(rows - 1) * lda + K) * sizeof(TA));
+    // 3x3 convolution mode (convH > 0, several-slab kernel only): the rows are the pixels of NHWC images
+    // and slab s reads the rows shifted by tap s / kslabs, zero outside the image: the descriptor then
+    // covers the whole tensor, and a row that falls outside gets an offset beyond it (reads as zero).
+    const bool conv = PERSIST && convH > 0;
+    const __amdgpu_buffer_rsrc_t rs_a = conv ? make_rsrc(A, ((size_t)(M - 1) * lda + K) * sizeof(TA))
+                                             : make_rsrc(A + (size_t)m0 * lda, ((size_t)(rows - 1) * lda + K) * sizeof(TA));
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(Wp, (size_t)wrows * ldw * sizeof(bf16_t));
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(bias, bias != nullptr ? (size_t)N * sizeof(float) : 0);
     // bf16 copy of A: plain stores from the first block column
@@ -141,6 +146,16 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     unsigned a_off[4], w_off[2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) a_off[p] = (unsigned)(((size_t)(p * 32 + srow) * lda + scol) * sizeof(TA));
+    int py[4], pxw[4];
+    if (conv) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int px = m0 + p * 32 + srow;
+            pxw[p] = px % convW;
+            py[p] = px < M ? (px / convW) % convH : -4;  // rows beyond M: never inside
+        }
+    }
+    const int kslabs = conv ? nslab / 9 : nslab;
 #pragma unroll
     for (int q = 0; q < 2; ++q) w_off[q] = (unsigned)(((q * 32 + srow) * ldw + scol) * sizeof(bf16_t));
 
@@ -223,7 +238,16 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     for (int slab = 0; slab < nslab; ++slab) {
         {
             a_piece<TA> ap[cfg::A_PIECES];
-            const unsigned soff = (unsigned)(slab * KS * sizeof(TA));
+            const int tap = slab / kslabs, kslab = slab - tap * kslabs;
+            const unsigned soff = (unsigned)(kslab * KS * sizeof(TA));
+            if (conv) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool in = py[p] + dy >= 0 && py[p] + dy < convH && pxw[p] + dx >= 0 && pxw[p] + dx < convW;
+                    a_off[p] = in ? (unsigned)(((size_t)(m0 + p * 32 + srow + dy * convW + dx) * lda + scol) * sizeof(TA)) : 0x80000000u;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -234,7 +258,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int j = 0; j < KS / 64; ++j) {
-                    const uint4 v = ap[p * (KS / 64) + j].pack(slab * KS + j * 64 + scol, K);
+                    const uint4 v = ap[p * (KS / 64) + j].pack(kslab * KS + j * 64 + scol, K);
                     *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * LS + j * 64 + scol) = v;
                     if (copy_row != nullptr && p * 32 + srow < rows)
                         *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + slab * KS + j * 64) = v;
@@ -444,7 +468,8 @@ int set_lds(const void *kern, size_t lds, const char *who) {
 
 template <typename TA, typename TC, int KS>
 int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
-                  void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, int accumulate, hipStream_t st) {
+                  void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, int accumulate, int convH, int convW,
+                  hipStream_t st) {
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
@@ -464,12 +489,12 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
         auto kern = linear_nt_kernel<TA, TC, KS, true>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, accumulate);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, accumulate, convH, convW);
     } else {
         auto kern = linear_nt_kernel<TA, TC, KS, false>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, accumulate);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, accumulate, convH, convW);
     }
     return check_launch("linear_nt_kernel");
 }
@@ -516,12 +541,45 @@ extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M
     int rc = DSW_OK;
 #define DSW_LINEAR_KS(KSV)                                                                                                     \
     DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
-        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, accumulate, st); \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, accumulate, 0, 0, st); \
     }))
     if (KS == 192) DSW_LINEAR_KS(192);
     else if (KS == 128) DSW_LINEAR_KS(128);
     else DSW_LINEAR_KS(64);
 #undef DSW_LINEAR_KS
+    return rc;
+}
+
+extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,
+                                const float *bias, int N, void *out, int out_dtype, long long ldo, int ncols, void *stream) {
+    const long long M = (long long)B * H * W;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ncols <= 0 || wrows <= 0)
+        return fail(DSW_EINVAL, "dsw_conv3x3_nhwc: bad sizes B=%d H=%d W=%d C=%d ncols=%d", B, H, W, C, ncols);
+    DSW_REQUIRE(x && w_p && out, "dsw_conv3x3_nhwc: null pointer");
+    const int Kp = (C + 63) / 64 * 64;
+    const size_t xs = x_dtype == DSW_F32 ? 4 : 2;
+    if (M > 0x7fffff00LL || (size_t)M * ldx * xs >= 0x80000000ull)
+        return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc: the input must stay below 2 GiB (%lld pixels x %lld)", M, ldx);
+    if (C % 4 || ldx < C || ldx % 4 || ((uintptr_t)x & (x_dtype == DSW_F32 ? 15 : 7)))
+        return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc: C and the pixel stride must be multiples of 4, the base aligned to 4 elements");
+    if (ldw < 9 * Kp || ldw % 8 || ((uintptr_t)w_p & 15))
+        return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc: the weight needs rows of 9 x %d elements (tap-major, channels padded to 64)", Kp);
+    if (ncols % 4 || ldo < ncols || ldo % 4 || ((uintptr_t)out & 15))
+        return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc: ncols and the output stride must be multiples of 4, the base 16-byte aligned");
+    if (bias != nullptr && (N <= 0 || N % 4 || N > ncols || ((uintptr_t)bias & 15)))
+        return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc: bias needs N %% 4 == 0, N <= ncols, a 16-byte aligned base");
+    const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 ? 128 : 64);
+    const int nslab = 9 * (Kp / KS);
+    hipStream_t st = as_stream(stream);
+    int rc = DSW_OK;
+#define DSW_CONV_KS(KSV)                                                                                                          \
+    DSW_DISPATCH_DTYPE(x_dtype, TA, DSW_DISPATCH_DTYPE(out_dtype, TC, {                                                           \
+        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, nullptr, 0, 0, H, W, st); \
+    }))
+    if (KS == 192) DSW_CONV_KS(192);
+    else if (KS == 128) DSW_CONV_KS(128);
+    else DSW_CONV_KS(64);
+#undef DSW_CONV_KS
     return rc;
 }
 

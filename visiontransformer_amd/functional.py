@@ -990,3 +990,44 @@ def rezero_residual(x, r, branch):
     if not ok:
         return torch.addcmul(x, r, branch)
     return _RezeroFn.apply(x, r, branch)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense 3x3 convolution on NHWC (LastChannelConv2D, DSwinT_arch.py:36-44), inference
+# ---------------------------------------------------------------------------------------------
+def _conv3x3_operand(weight):
+    """Conv2d weight [Co, Ci, 3, 3] -> bf16 [ceil64(Co), 9 * ceil64(Ci)], tap-major with the channels of
+    every tap padded to 64; kept per parameter like the projection weights (autograd is off here)."""
+    e = _PREP_CACHE.get(("conv3x3", id(weight)))
+    if e is not None and e[0]() is weight and e[1] == weight._version and e[2] == weight.data_ptr():
+        return e[3]
+    Co, Ci = weight.shape[:2]
+    Kp = _ceil_pad(Ci)
+    taps = torch.zeros(Co, 9, Kp, dtype=torch.float32, device=weight.device)
+    taps[:, :, :Ci] = weight.detach().float().permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+    w_p = torch.empty(_ceil_pad(Co), 9 * Kp, dtype=torch.bfloat16, device=weight.device)
+    call("dsw_weight_prep", ptr(taps), dtype_code(torch.float32), Co, 9 * Kp, ptr(w_p), None, stream(weight.device))
+    _PREP_CACHE[("conv3x3", id(weight))] = (weakref.ref(weight), weight._version, weight.data_ptr(), w_p)
+    return w_p
+
+
+def conv3x3_nhwc(x, conv):
+    """`conv` (an nn.Conv2d with a 3x3 kernel, stride 1, padding 1, one group) applied to the NHWC tensor
+    x [B, H, W, Ci] -> [B, H, W, Co], or None when this call is not one the kernel takes (autograd on,
+    not bf16 autocast, other geometry): the caller then uses the stock convolution."""
+    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    B, H, W, Ci = x.shape
+    ok = (not torch.is_grad_enabled() and x.is_cuda and act == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)
+          and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+          and conv.groups == 1 and conv.padding_mode == "zeros" and Ci % 4 == 0 and conv.out_channels % 4 == 0
+          and B * H * W * Ci * x.element_size() < 2 ** 31)
+    if not ok:
+        return None
+    x = x.contiguous()
+    Co = conv.out_channels
+    w_p = _conv3x3_operand(conv.weight)
+    b32 = None if conv.bias is None else conv.bias.detach().float().contiguous()
+    out = torch.empty(B, H, W, Co, dtype=act, device=x.device)
+    call("dsw_conv3x3_nhwc", ptr(x), dtype_code(x.dtype), Ci, B, H, W, Ci, ptr(w_p), w_p.shape[0], w_p.shape[1],
+         None if b32 is None else ptr(b32), Co, ptr(out), dtype_code(act), Co, Co, stream(x.device))
+    return out
