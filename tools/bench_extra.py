@@ -73,7 +73,7 @@ def workload_c(dev):
     for m in model.modules():
         if hasattr(m, "attn_drop"):
             m.attn_drop = 0.0
-    B = 8
+    B = int(os.environ.get("C_BATCH", "32"))
     x = torch.randn(B, 3, 64, 64, device=dev)
     target = torch.randn(B, 3, 256, 256, device=dev)
 

@@ -14,11 +14,13 @@ cfg = dict(MSFT_CONFIG_C)
 if "full" not in sys.argv:
     cfg["n_blocks"] = 1; cfg["n_sub_blocks"] = 1
 net = MSFTransformer(**cfg).to(dev).train()
-x = torch.randn(8, 3, 64, 64, device=dev)
+import os
+x = torch.randn(int(os.environ.get("C_BATCH", "8")), 3, 64, 64, device=dev)
 def step():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = net(x)
     y.float().square().mean().backward()
+    net.zero_grad(set_to_none=True)
 for _ in range(2): step()
 torch.cuda.synchronize()
 names = {m: n for n, m in net.named_modules()}

@@ -779,12 +779,12 @@ __global__ __launch_bounds__(256) void lepe_bwd_pre_kernel(AttnGeom g, const T *
 }
 
 // d_lepe_w[c][tap], d_lepe_b[c] = sum over windows (ascending) of the partials
-__global__ void lepe_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int C, float *__restrict__ d_w,
-                                        float *__restrict__ d_b) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * 10) return;
-    float acc = 0.f;
-    for (int wdx = 0; wdx < n_win; ++wdx) acc += ws[(size_t)wdx * C * 10 + i];
+__global__ __launch_bounds__(256) void lepe_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int C, float *__restrict__ d_w,
+                                                               float *__restrict__ d_b) {
+    __shared__ float red[8][33];
+    int i;
+    float acc;
+    if (!column_sum_32x8(ws, n_win, C * 10, red, i, acc)) return;
     const int c = i / 10, k = i - c * 10;
     if (k < 9) d_w[c * 9 + k] = acc;
     else d_b[c] = acc;
@@ -846,7 +846,7 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
         if (rc) return rc;
     }
     if (lepe) {
-        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3((g.C * 10 + 255) / 256), dim3(256), 0, st, ws_lepe, g.n_win, g.C,
+        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3((g.C * 10 + 31) / 32), dim3(256), 0, st, ws_lepe, g.n_win, g.C,
                            d_lepe_w, d_lepe_b);
         rc = check_launch("lepe_grad_reduce_kernel");
     }

@@ -119,6 +119,24 @@ __device__ __forceinline__ float block_max(float v, float *red) {
         else return ::dsw::fail(DSW_EUNSUPPORTED, "dtype code %d", (int)(code));   \
     } while (0)
 
+// dst[c] = sum_r src[r][c] for a row-major [rows][cols] fp32 matrix of per-block partial sums, in a fixed
+// order: a block takes 32 consecutive columns, its 8 thread slices every 8th row, and the slices are
+// added in slice order.  The body of the small reduction kernels at the end of the backward passes.
+__device__ __forceinline__ bool column_sum_32x8(const float *__restrict__ src, int rows, int cols, float (*red)[33], int &col, float &total) {
+    const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    col = blockIdx.x * 32 + e;
+    float acc = 0.f;
+    if (col < cols)
+        for (int r = sl; r < rows; r += 8) acc += src[(size_t)r * cols + col];
+    red[sl][e] = acc;
+    __syncthreads();
+    if (sl != 0 || col >= cols) return false;
+    total = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) total += red[k][e];
+    return true;
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace dsw

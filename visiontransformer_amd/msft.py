@@ -29,7 +29,7 @@ class PatchMerging(nn.Module):
     def forward(self, x):
         t = K.unshuffle_nhwc_layernorm(x, self.norm.weight, self.norm.bias, self.scale, self.norm.eps,
                                        out_dtype=_ln_out_dtype(x))
-        return K.shuffle_nchw(self.linear(t), 1)
+        return K.shuffle_nchw(K.linear(t, self.linear) if t.is_cuda else self.linear(t), 1)
 
 
 class PatchUnMerging(nn.Module):
@@ -45,7 +45,7 @@ class PatchUnMerging(nn.Module):
     def forward(self, x):
         t = K.unshuffle_nhwc_layernorm(x, self.norm.weight, self.norm.bias, 1, self.norm.eps,
                                        out_dtype=_ln_out_dtype(x))
-        return K.shuffle_nchw(self.linear(t), self.scale)
+        return K.shuffle_nchw(K.linear(t, self.linear) if t.is_cuda else self.linear(t), self.scale)
 
 
 class WindowedMSA(nn.Module):
@@ -79,7 +79,7 @@ class WindowedMSA(nn.Module):
 
 
 class MLP(nn.Module):
-    """msft_arch.py:19-33 (stock torch; not on the kernel path)."""
+    """msft_arch.py:19-33: Linear - GELU - Linear - Dropout; the Linears run in the projection kernels."""
 
     def __init__(self, in_features, hidden_features=None, out_features=None, ffn_scale=4, drop=0.):
         super().__init__()
@@ -89,7 +89,10 @@ class MLP(nn.Module):
                                  nn.Linear(hidden_features, out_features), nn.Dropout(drop))
 
     def forward(self, x):
-        return self.mlp(x)
+        if not x.is_cuda:
+            return self.mlp(x)
+        # the two Linears through the projection kernels (they read the LayerNorm's fp32 output where it lies)
+        return self.mlp[3](K.linear(self.mlp[1](K.linear(x, self.mlp[0])), self.mlp[2]))
 
 
 class ViTBlock(nn.Module):
