@@ -357,6 +357,17 @@ int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, in
                      int wrows, int ldw, const float *bias, int N, void *out, int out_dtype, long long ldo,
                      int ncols, void *stream);
 
+/* LayerNorm over channel rows of the fp32 stream (the nn.LayerNorm layers of msft's ViTBlock,
+ * msft_arch.py:152-153, applied at :163-165): out = (x - mean) * rstd * weight + bias, written as fp32 or
+ * bf16 with row stride ldo >= C (columns C..ldo-1 zeroed), like dsw_rmsnorm_fwd.  C % 4 == 0, C <= 256;
+ * mean, rstd: fp32 [M], both or neither.  Backward: dx fp32 [M][C]; partial holds dsw_rmsnorm_blocks(M)
+ * rows of [d(weight) | d(bias)] (2 C floats each) to be summed over rows. */
+int dsw_layernorm_fwd(const float *x, const float *weight, const float *bias, float eps, long long M, int C,
+                      void *out, int out_dtype, long long ldo, float *mean, float *rstd, void *stream);
+int dsw_layernorm_bwd(const void *dy, int dy_dtype, long long ld_dy, const float *x, const float *weight,
+                      const float *mean, const float *rstd, long long M, int C, float *dx, float *partial,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -573,3 +573,35 @@ def test_conv3x3_nhwc(cuda0, B, H, W, Ci, Co, xdtype):
     assert ((got.float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert K.conv3x3_nhwc(x, conv) is None      # autograd on: the stock convolution is used
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C", [(3, 8), (77, 96), (4099, 216), (1000, 256)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16_padded"])
+def test_layer_norm(cuda0, M, C, mode):
+    """K.layer_norm against nn.LayerNorm, as test_rms_norm."""
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(M + C)
+    norm = torch.nn.LayerNorm(C).to(cuda0)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(M, C, device=cuda0) * 3 + 1).requires_grad_()
+    dy = torch.randn(M, C, device=cuda0)
+    ref = norm(x)
+    gx, gw, gb = torch.autograd.grad(ref, (x, norm.weight, norm.bias), dy)
+    if mode == "fp32":
+        got = K.layer_norm(x, norm)
+        assert got.dtype == torch.float32 and rel_err(got, ref) < 1e-5
+        hx, hw, hb = torch.autograd.grad(got, (x, norm.weight, norm.bias), dy)
+        assert rel_err(hx, gx) < 1e-4 and rel_err(hw, gw) < 1e-5 and rel_err(hb, gb) < 1e-5
+    else:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got = K.layer_norm(x, norm, for_projection=True)
+        assert got.dtype == torch.bfloat16 and got.shape == (M, C)
+        assert rel_err(got.float(), ref.to(torch.bfloat16).float()) < 1e-2
+        ldo = (C + 63) // 64 * 64
+        if ldo != C:
+            assert got._base.shape == (M, ldo) and got._base[:, C:].abs().max().item() == 0
+        hx, hw, hb = torch.autograd.grad(got, (x, norm.weight, norm.bias), dy.to(torch.bfloat16))
+        assert rel_err(hx, gx) < 2e-2 and rel_err(hw, gw) < 2e-2 and rel_err(hb, gb) < 2e-2

@@ -315,3 +315,154 @@ extern "C" int dsw_rezero_bwd(const float *dy, const void *branch, int b_dtype, 
     });
     return check_launch("rezero_bwd_kernel");
 }
+
+// ---- LayerNorm over channel rows (the nn.LayerNorm layers of msft's ViTBlock, msft_arch.py:152-153, applied
+// at :163-165), same lane layout as the RMSNorm above: out = (x - mean) * rstd * w + b -------------------
+namespace dsw {
+namespace {
+
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ b, float eps, long long M, int C,
+                                                            TO *__restrict__ out, long long ldo, float *__restrict__ mean,
+                                                            float *__restrict__ rstd) {
+    const int sub = threadIdx.x & (RN_LPR - 1), rloc = threadIdx.x / RN_LPR;
+    const int nv = C / 4, nvo = (int)(ldo / 4);
+    float4 wv[RN_MAXV], bv[RN_MAXV];
+#pragma unroll
+    for (int i = 0; i < RN_MAXV; ++i) {
+        const bool live = sub + RN_LPR * i < nv;
+        wv[i] = live ? *reinterpret_cast<const float4 *>(w + 4 * (sub + RN_LPR * i)) : f4zero();
+        bv[i] = live && b != nullptr ? *reinterpret_cast<const float4 *>(b + 4 * (sub + RN_LPR * i)) : f4zero();
+    }
+    for (long long r0 = (long long)blockIdx.x * RN_RPB; r0 < M; r0 += (long long)gridDim.x * RN_RPB) {
+        const long long row = r0 + rloc;
+        const bool ok = row < M;
+        float4 v[RN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < RN_MAXV; ++i) {
+            v[i] = ok && sub + RN_LPR * i < nv ? *reinterpret_cast<const float4 *>(x + row * C + 4 * (sub + RN_LPR * i)) : f4zero();
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+        const float mu = group16_sum(s) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < RN_MAXV; ++i) {
+            if (sub + RN_LPR * i < nv) {
+                v[i] = make_float4(v[i].x - mu, v[i].y - mu, v[i].z - mu, v[i].w - mu);
+                ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            }
+        }
+        const float rs = rsqrtf(group16_sum(ss) / (float)C + eps);
+        if (ok) {
+            if (sub == 0 && rstd != nullptr) {
+                mean[row] = mu;
+                rstd[row] = rs;
+            }
+#pragma unroll
+            for (int i = 0; i < RN_MAXV; ++i) {
+                const int j = sub + RN_LPR * i;
+                if (j < nvo) {
+                    const float4 y = j < nv ? make_float4(v[i].x * rs * wv[i].x + bv[i].x, v[i].y * rs * wv[i].y + bv[i].y,
+                                                          v[i].z * rs * wv[i].z + bv[i].z, v[i].w * rs * wv[i].w + bv[i].w)
+                                            : f4zero();
+                    io<TO>::st4(out + row * ldo + 4 * j, y);
+                }
+            }
+        }
+    }
+}
+
+// dx = rstd (g - mean(g) - xh mean(g xh)), g = dy w, xh = (x - mean) rstd;  partial row = [sum dy xh | sum dy]
+template <typename TG>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG *__restrict__ dy, long long ldg, const float *__restrict__ x,
+                                                            const float *__restrict__ w, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, long long M, int C, float *__restrict__ dx,
+                                                            float *__restrict__ partial) {
+    __shared__ float4 red[RN_RPB][RN_LPR * RN_MAXV];
+    const int sub = threadIdx.x & (RN_LPR - 1), rloc = threadIdx.x / RN_LPR;
+    const int nv = C / 4;
+    float4 wv[RN_MAXV], dwacc[RN_MAXV], dbacc[RN_MAXV];
+#pragma unroll
+    for (int i = 0; i < RN_MAXV; ++i) {
+        wv[i] = sub + RN_LPR * i < nv ? *reinterpret_cast<const float4 *>(w + 4 * (sub + RN_LPR * i)) : f4zero();
+        dwacc[i] = dbacc[i] = f4zero();
+    }
+    for (long long r0 = (long long)blockIdx.x * RN_RPB; r0 < M; r0 += (long long)gridDim.x * RN_RPB) {
+        const long long row = r0 + rloc;
+        const bool ok = row < M;
+        const float rs = ok ? rstd[row] : 0.f, mu = ok ? mean[row] : 0.f;
+        float4 xh[RN_MAXV], g[RN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < RN_MAXV; ++i) {
+            const bool live = ok && sub + RN_LPR * i < nv;
+            const float4 xv = live ? *reinterpret_cast<const float4 *>(x + row * C + 4 * (sub + RN_LPR * i)) : make_float4(mu, mu, mu, mu);
+            const float4 gy = live ? io<TG>::ld4(dy + row * ldg + 4 * (sub + RN_LPR * i)) : f4zero();
+            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            g[i] = make_float4(gy.x * wv[i].x, gy.y * wv[i].y, gy.z * wv[i].z, gy.w * wv[i].w);
+            s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+            s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+            dwacc[i] = dwacc[i] + make_float4(gy.x * xh[i].x, gy.y * xh[i].y, gy.z * xh[i].z, gy.w * xh[i].w);
+            dbacc[i] = dbacc[i] + gy;
+        }
+        s1 = group16_sum(s1) / (float)C;
+        s2 = group16_sum(s2) / (float)C;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < RN_MAXV; ++i)
+                if (sub + RN_LPR * i < nv)
+                    *reinterpret_cast<float4 *>(dx + row * C + 4 * (sub + RN_LPR * i)) =
+                        make_float4((g[i].x - s1 - xh[i].x * s2) * rs, (g[i].y - s1 - xh[i].y * s2) * rs, (g[i].z - s1 - xh[i].z * s2) * rs,
+                                    (g[i].w - s1 - xh[i].w * s2) * rs);
+        }
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RN_MAXV; ++i) red[rloc][sub + RN_LPR * i] = which ? dbacc[i] : dwacc[i];
+        __syncthreads();
+        if (threadIdx.x < RN_LPR * RN_MAXV) {
+            const int i = threadIdx.x / RN_LPR, s = threadIdx.x % RN_LPR, j = s + RN_LPR * i;
+            if (j < nv) {
+                float4 a = f4zero();
+#pragma unroll
+                for (int r = 0; r < RN_RPB; ++r) a = a + red[r][s + RN_LPR * i];
+                *reinterpret_cast<float4 *>(partial + (size_t)blockIdx.x * 2 * C + which * C + 4 * j) = a;
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace dsw
+
+extern "C" int dsw_layernorm_fwd(const float *x, const float *weight, const float *bias, float eps, long long M, int C, void *out,
+                                 int out_dtype, long long ldo, float *mean, float *rstd, void *stream) {
+    if (M <= 0 || C <= 0 || ldo < C) return fail(DSW_EINVAL, "dsw_layernorm_fwd: bad sizes M=%lld C=%d ldo=%lld", M, C, ldo);
+    if (C % 4 || ldo % 4 || C > 4 * RN_LPR * RN_MAXV || ldo > 4 * RN_LPR * RN_MAXV)
+        return fail(DSW_EUNSUPPORTED, "dsw_layernorm_fwd: C and the output row stride must be multiples of 4, at most %d (C=%d ldo=%lld)",
+                    4 * RN_LPR * RN_MAXV, C, ldo);
+    DSW_REQUIRE(x && weight && out && ((mean == nullptr) == (rstd == nullptr)), "dsw_layernorm_fwd: null pointer");
+    DSW_DISPATCH_DTYPE(out_dtype, TO, {
+        hipLaunchKernelGGL(layernorm_fwd_kernel<TO>, dim3(rn_blocks(M)), dim3(256), 0, as_stream(stream), x, weight, bias, eps, M, C,
+                           (TO *)out, ldo, mean, rstd);
+    });
+    return check_launch("layernorm_fwd_kernel");
+}
+
+extern "C" int dsw_layernorm_bwd(const void *dy, int dy_dtype, long long ld_dy, const float *x, const float *weight, const float *mean,
+                                 const float *rstd, long long M, int C, float *dx, float *partial, void *stream) {
+    if (M <= 0 || C <= 0 || ld_dy < C) return fail(DSW_EINVAL, "dsw_layernorm_bwd: bad sizes M=%lld C=%d ld_dy=%lld", M, C, ld_dy);
+    if (C % 4 || ld_dy % 4 || C > 4 * RN_LPR * RN_MAXV)
+        return fail(DSW_EUNSUPPORTED, "dsw_layernorm_bwd: C and the gradient's row stride must be multiples of 4, C at most %d (C=%d ld_dy=%lld)",
+                    4 * RN_LPR * RN_MAXV, C, ld_dy);
+    DSW_REQUIRE(dy && x && weight && mean && rstd && dx && partial, "dsw_layernorm_bwd: null pointer");
+    DSW_DISPATCH_DTYPE(dy_dtype, TG, {
+        hipLaunchKernelGGL(layernorm_bwd_kernel<TG>, dim3(rn_blocks(M)), dim3(256), 0, as_stream(stream), (const TG *)dy, ld_dy, x, weight,
+                           mean, rstd, M, C, dx, partial);
+    });
+    return check_launch("layernorm_bwd_kernel");
+}

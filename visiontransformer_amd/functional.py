@@ -1031,3 +1031,57 @@ def conv3x3_nhwc(x, conv):
     call("dsw_conv3x3_nhwc", ptr(x), dtype_code(x.dtype), Ci, B, H, W, Ci, ptr(w_p), w_p.shape[0], w_p.shape[1],
          None if b32 is None else ptr(b32), Co, ptr(out), dtype_code(act), Co, Co, stream(x.device))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm of msft's ViTBlock (msft_arch.py:152-153, :163-165)
+# ---------------------------------------------------------------------------------------------
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype, pad_out):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        M = x2.shape[0]
+        ldo = _ceil_pad(C) if pad_out else C
+        w32 = weight.detach().float().contiguous()
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        out = _mark_padded(torch.empty(M, ldo, dtype=out_dtype, device=x.device))
+        need_bwd = any(ctx.needs_input_grad[:3])
+        stats = torch.empty(2, M, dtype=torch.float32, device=x.device) if need_bwd else None
+        call("dsw_layernorm_fwd", ptr(x2), ptr(w32), None if b32 is None else ptr(b32), float(eps), M, C, ptr(out), dtype_code(out_dtype),
+             ldo, None if stats is None else ptr(stats[0]), None if stats is None else ptr(stats[1]), stream(x.device))
+        if need_bwd:
+            ctx.save_for_backward(x2, w32, stats)
+        ctx.meta = (x.shape, weight.dtype, None if bias is None else bias.dtype)
+        return out[:, :C].view(x.shape) if ldo != C else out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w32, stats = ctx.saved_tensors
+        xshape, wdt, bdt = ctx.meta
+        M, C = x2.shape
+        dy2 = dy.reshape(-1, C)
+        if dy2.dtype not in (torch.float32, torch.bfloat16) or dy2.stride(1) != 1 or (M > 1 and dy2.stride(0) % 4) or \
+                dy2.data_ptr() % (4 * dy2.element_size()):
+            dy2 = dy2.float().contiguous()
+        dx = torch.empty(M, C, dtype=torch.float32, device=x2.device)
+        nblk = _lib.load().dsw_rmsnorm_blocks(M)
+        partial = torch.empty(nblk, 2 * C, dtype=torch.float32, device=x2.device)
+        call("dsw_layernorm_bwd", ctypes.c_void_p(dy2.data_ptr()), dtype_code(dy2.dtype), dy2.stride(0) if M > 1 else C, ptr(x2), ptr(w32),
+             ptr(stats[0]), ptr(stats[1]), M, C, ptr(dx), ptr(partial), stream(x2.device))
+        dwb = colsum(partial)
+        dw = dwb[:C].to(wdt) if ctx.needs_input_grad[1] else None
+        db = dwb[C:].to(bdt) if bdt is not None and ctx.needs_input_grad[2] else None
+        return dx.view(xshape), dw, db, None, None, None
+
+
+def layer_norm(x, norm, for_projection=False):
+    """`norm(x)` for an nn.LayerNorm over the last dimension of the fp32 stream; for_projection as in rms_norm."""
+    C = x.shape[-1]
+    ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and _ceil_pad(C) <= 256
+          and norm.weight is not None and tuple(norm.normalized_shape) == (C,))
+    if not ok:
+        return norm(x)
+    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    to_act = for_projection and act == torch.bfloat16
+    return _LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps, act if to_act else torch.float32, to_act)

@@ -110,7 +110,8 @@ class ViTBlock(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         t = K.unshuffle_nhwc(x, 1).view(B, H * W, C)
-        n1 = torch.nn.functional.layer_norm(t, (C,), self.ln1.weight, self.ln1.bias, self.ln1.eps)
+        # both LayerNorms feed projections: under bf16 autocast they write bf16 padded rows directly
+        n1 = K.layer_norm(t, self.ln1, for_projection=True)
         t = self.drop_path(self.msa(n1, H, W)) + t
-        t = self.drop_path(self.mlp(self.ln2(t))) + t
+        t = self.drop_path(self.mlp(K.layer_norm(t, self.ln2, for_projection=True))) + t
         return K.shuffle_nchw(t.view(B, H, W, C), 1)
