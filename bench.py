@@ -198,7 +198,7 @@ def _projection_rooflines(device, iters, warm, x, out):
     dgrad = lambda: call("dsw_linear", ptr(y), bfc, Np, M, Np, ptr(w_pt), Kp, Np, None, 0, ptr(dx), f32c, K, K, 0, None, 0, st)
     t_d = time_calls(dgrad, iters, warm)
     dw, db = torch.empty(N, K, device=device), torch.empty(N, device=device)
-    ws = torch.empty(load().dsw_linear_wgrad_workspace(M, N), device=device)
+    ws = torch.empty(load().dsw_linear_wgrad_workspace(M, N, K), device=device)
     wgrad = lambda: call("dsw_linear_wgrad", ptr(y), Np, ptr(xk), Kp, M, N, K, ptr(dw), ptr(db), ptr(ws), st)
     t_w = time_calls(wgrad, iters, warm)
     by_f = M * (K * 4 + Np * 2 + Kp * 2)

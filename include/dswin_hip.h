@@ -285,10 +285,10 @@ int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, co
 /* Weight and bias gradient of those projections (torch.nn.Linear backward behind the same call
  * sites): dw[n][k] = sum_m dy[m][n] x[m][k], db[n] = sum_m dy[m][n], fp32, summed in a fixed order.
  *   dy: bf16 [M][ldy], ldy >= ceil64(N), columns N.. zero;  x: bf16 [M][ldx], ldx >= ceil64(K),
- *   columns K.. zero (the a_copy output of dsw_linear has this form).  K <= 192, K % 4 == 0.
+ *   columns K.. zero (the a_copy output of dsw_linear has this form).  K % 4 == 0.
  *   dw: fp32 [N][K] dense;  db: fp32 [N] or NULL (needs K < ceil64(K): the sum rides in the first
- *   padding column of x);  workspace: dsw_linear_wgrad_workspace(M, N) floats. */
-size_t dsw_linear_wgrad_workspace(long long M, int N);
+ *   padding column of x);  workspace: dsw_linear_wgrad_workspace(M, N, K) floats. */
+size_t dsw_linear_wgrad_workspace(long long M, int N, int K);
 int dsw_linear_wgrad(const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K,
                      float *dw, float *db, float *workspace, void *stream);
 

@@ -415,7 +415,8 @@ def test_linear_kernel(cuda0, M, K, N, a_dtype, c_dtype, pad_a, pad_c, copy):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K,N", [(300, 180, 540), (1000, 96, 100), (4096 + 24, 192, 64), (128 * 300 + 5, 180, 180)])
+@pytest.mark.parametrize("M,K,N", [(300, 180, 540), (1000, 96, 100), (4096 + 24, 192, 64), (128 * 300 + 5, 180, 180),
+                                   (2000, 360, 180), (3000, 216, 648), (700, 432, 216)])
 def test_linear_wgrad_kernel(cuda0, M, K, N):
     """dsw_linear_wgrad (weight and bias gradient of a projection) against a float64 product of
     the same bf16 operands, and bitwise reproducible."""
@@ -431,7 +432,7 @@ def test_linear_wgrad_kernel(cuda0, M, K, N):
     for _ in range(2):
         dw = torch.full((N, K), float("nan"), device=cuda0)
         db = torch.full((N,), float("nan"), device=cuda0) if K < Kp else None
-        ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, N), device=cuda0)
+        ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, N, K), device=cuda0)
         _lib.call("dsw_linear_wgrad", _lib.ptr(dy), Np, _lib.ptr(x), Kp, M, N, K, _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
                   _lib.ptr(ws), _lib.stream(cuda0))
         outs.append((dw, db))

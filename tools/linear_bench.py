@@ -69,7 +69,7 @@ def wcase(M, K, N):
     x = torch.zeros(M, Kp, device=dev, dtype=bf); x[:, :K] = torch.randn(M, K, device=dev).to(bf)
     dy = torch.zeros(M, Np, device=dev, dtype=bf); dy[:, :N] = torch.randn(M, N, device=dev).to(bf)
     dw = torch.full((N, K), float("nan"), device=dev); db = torch.full((N,), float("nan"), device=dev) if K < Kp else None
-    ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, N), device=dev)
+    ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, N, K), device=dev)
     f = lambda: _lib.call("dsw_linear_wgrad", _lib.ptr(dy), Np, _lib.ptr(x), Kp, M, N, K, _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
                           _lib.ptr(ws), _lib.stream(dev))
     f()

@@ -53,7 +53,7 @@ SIGNATURES = {
     "dsw_sd_gather_bwd": (_I, [_P, _I, _I, _I, _P, _P]),
     "dsw_sparse_disc_tail_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "dsw_sparse_disc_tail_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "dsw_linear_wgrad_workspace": (_Z, [ctypes.c_longlong, _I]),
+    "dsw_linear_wgrad_workspace": (_Z, [ctypes.c_longlong, _I, _I]),
     "dsw_linear_wgrad": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _I, _I, _P, _P, _P, _P]),
     "dsw_rmsnorm_blocks": (_I, [ctypes.c_longlong]),
     "dsw_rmsnorm_fwd": (_I, [_P, _P, _F, ctypes.c_longlong, _I, _P, _I, ctypes.c_longlong, _P, _P]),

@@ -333,7 +333,7 @@ constexpr size_t WG_LDS = (size_t)2 * WG_BM * WG_LS * sizeof(bf16_t);
 
 __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_t *__restrict__ dY, long long ldy,
                                                                       const bf16_t *__restrict__ X, long long ldx, int M, int K, int Kp,
-                                                                      int Np, int rows_per_block, float *__restrict__ partial) {
+                                                                      int Np, int Kpr, int rows_per_block, float *__restrict__ partial) {
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t *Ys = reinterpret_cast<bf16_t *>(smem);
     bf16_t *Xs = Ys + WG_BM * WG_LS;
@@ -343,15 +343,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
     const int m_begin = blockIdx.y * rows_per_block;
     const int rows = min(M - m_begin, rows_per_block);  // >= 1 by the grid's construction
     const int nst = (rows + WG_BM - 1) / WG_BM;
-    const bool ones = K < Kp;
+    const int k0 = blockIdx.z * WG_TK;  // this block's columns of X
+    const bool ones = K < Kp && K >= k0 && K < k0 + WG_TK;
 
     // staging: piece = 8 consecutive columns; 24 pieces per row, 16 rows per pass of the block
     const int prow = tid / 24, pc = tid - prow * 24;
-    const bool y_ok = n0 + pc * 8 < Np, x_ok = pc * 8 < Kp;
+    const bool y_ok = n0 + pc * 8 < Np, x_ok = k0 + pc * 8 < Kp;
     const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(dY + (size_t)m_begin * ldy + n0, ((size_t)(rows - 1) * ldy + (Np - n0)) * sizeof(bf16_t));
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(X + (size_t)m_begin * ldx, ((size_t)(rows - 1) * ldx + Kp) * sizeof(bf16_t));
     const unsigned y_off = (unsigned)(((size_t)prow * ldy + pc * 8) * sizeof(bf16_t));
-    const unsigned x_off = (unsigned)(((size_t)prow * ldx + pc * 8) * sizeof(bf16_t));
+    const unsigned x_off = (unsigned)(((size_t)prow * ldx + k0 + pc * 8) * sizeof(bf16_t));
     const unsigned y_step = (unsigned)(16 * ldy * sizeof(bf16_t)), x_step = (unsigned)(16 * ldx * sizeof(bf16_t));
 
     uint4 yr[WG_PIECES], xr[WG_PIECES];
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
             uint4 y = yr[i], x = xr[i];
             if (!y_ok) y = make_uint4(0u, 0u, 0u, 0u);
             if (!x_ok) x = make_uint4(0u, 0u, 0u, 0u);
-            if (ones && pc == (K >> 3) && st * WG_BM + r < rows) {
+            if (ones && pc == ((K - k0) >> 3) && st * WG_BM + r < rows) {
                 // element K & 7 of this piece := 1.0 (K % 4 == 0: element 0 or 4)
                 if (K & 4) x.z = (x.z & 0xffff0000u) | 0x3f80u;
                 else x.x = (x.x & 0xffff0000u) | 0x3f80u;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
         }
     }
     // lane = output column k, registers = rows n: 128-byte runs per row
-    float *pb = partial + (size_t)blockIdx.y * Np * WG_TK;
+    float *pb = partial + (size_t)blockIdx.y * Np * Kpr + k0;
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
@@ -428,24 +429,24 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 64 + ta * 32 + rho(r) + 4 * hh;
-                if (n < Np) pb[(size_t)n * WG_TK + wk * 96 + tb * 32 + l31] = acc[ta][tb][r];
+                if (n < Np) pb[(size_t)n * Kpr + wk * 96 + tb * 32 + l31] = acc[ta][tb][r];
             }
 }
 
 // dw[n][k] = sum_s partial[s][n][k] (n < N, k < K); db[n] = sum_s partial[s][n][K].  A workgroup sums 16
 // groups of 4 columns, its 16 thread slices taking every 16th partial block; the slices meet in LDS and
 // are added in slice order (a fixed tree: bitwise reproducible).
-__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *__restrict__ partial, int S, int Np, int N, int K,
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *__restrict__ partial, int S, int Np, int Kpr, int N, int K,
                                                                   float *__restrict__ dw, float *__restrict__ db) {
     __shared__ float4 red[16][16];
     const int it = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + it;  // (n, group of 4 columns)
-    const int n = i / (WG_TK / 4), k4 = (i - n * (WG_TK / 4)) * 4;
+    const int n = i / (Kpr / 4), k4 = (i - n * (Kpr / 4)) * 4;
     const bool live = n < N && (k4 < K || (k4 == K && db != nullptr));
     float4 a = f4zero();
     if (live) {
-        const float4 *p = reinterpret_cast<const float4 *>(partial + (size_t)n * WG_TK + k4);
-        const size_t stride = (size_t)Np * WG_TK / 4;
+        const float4 *p = reinterpret_cast<const float4 *>(partial + (size_t)n * Kpr + k4);
+        const size_t stride = (size_t)Np * Kpr / 4;
         for (int s0 = sl; s0 < S; s0 += 16) a = a + p[(size_t)s0 * stride];
     }
     red[sl][it] = a;
@@ -583,8 +584,8 @@ extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B
     return rc;
 }
 
-static void wgrad_split(long long M, int Np, int *rows_per_block, int *S) {
-    const int nb = (Np + WG_TN - 1) / WG_TN;
+static void wgrad_split(long long M, int Np, int Kp, int *rows_per_block, int *S) {
+    const int nb = ((Np + WG_TN - 1) / WG_TN) * ((Kp + WG_TK - 1) / WG_TK);
     long long want = 256 / nb;  // about one workgroup per CU: every extra one adds a partial block to write and re-read
     if (want < 1) want = 1;
     long long rpb = (M + want - 1) / want;
@@ -593,20 +594,19 @@ static void wgrad_split(long long M, int Np, int *rows_per_block, int *S) {
     *S = (int)((M + rpb - 1) / rpb);
 }
 
-extern "C" size_t dsw_linear_wgrad_workspace(long long M, int N) {
-    if (M <= 0 || N <= 0 || M > 0x7fffff00LL) return 0;
-    const int Np = (N + 63) / 64 * 64;
+extern "C" size_t dsw_linear_wgrad_workspace(long long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || M > 0x7fffff00LL) return 0;
+    const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64, Kpr = (Kp + WG_TK - 1) / WG_TK * WG_TK;
     int rpb, S;
-    wgrad_split(M, Np, &rpb, &S);
-    return (size_t)S * Np * WG_TK;
+    wgrad_split(M, Np, Kp, &rpb, &S);
+    return (size_t)S * Np * Kpr;
 }
 
 extern "C" int dsw_linear_wgrad(const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K, float *dw,
                                 float *db, float *workspace, void *stream) {
     if (M <= 0 || M > 0x7fffff00LL || N <= 0 || K <= 0) return fail(DSW_EINVAL, "dsw_linear_wgrad: bad sizes M=%lld N=%d K=%d", M, N, K);
     DSW_REQUIRE(dy && x && dw && workspace, "dsw_linear_wgrad: null pointer");
-    const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64;
-    if (Kp > WG_TK) return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: K=%d (at most %d)", K, WG_TK);
+    const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64, Kpr = (Kp + WG_TK - 1) / WG_TK * WG_TK;
     if (K % 4) return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: K=%d must be a multiple of 4", K);
     if (db != nullptr && K == Kp)
         return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: the bias gradient rides in a padding column of x, K=%d leaves none", K);
@@ -615,15 +615,17 @@ extern "C" int dsw_linear_wgrad(const void *dy, long long ldy, const void *x, lo
                                       "16-byte aligned (ldy=%lld ldx=%lld)", Np, Kp, ldy, ldx);
     if (((uintptr_t)dw & 15) || ((uintptr_t)workspace & 15)) return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: dw / workspace must be 16-byte aligned");
     int rpb, S;
-    wgrad_split(M, Np, &rpb, &S);
+    wgrad_split(M, Np, Kp, &rpb, &S);
+    if ((long long)rpb * (ldy > ldx ? ldy : ldx) * 2 >= 0x7fffffffLL)
+        return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: a block's row range (%d rows) exceeds 2 GiB", rpb);
     hipStream_t st = as_stream(stream);
     int rc = set_lds((const void *)linear_wgrad_kernel, WG_LDS, "dsw_linear_wgrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((Np + WG_TN - 1) / WG_TN, S), dim3(WG_THREADS), WG_LDS, st, (const bf16_t *)dy, ldy,
-                       (const bf16_t *)x, ldx, (int)M, K, Kp, Np, rpb, workspace);
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((Np + WG_TN - 1) / WG_TN, S, Kpr / WG_TK), dim3(WG_THREADS), WG_LDS, st, (const bf16_t *)dy,
+                       ldy, (const bf16_t *)x, ldx, (int)M, K, Kp, Np, Kpr, rpb, workspace);
     rc = check_launch("linear_wgrad_kernel");
     if (rc) return rc;
-    const int items = N * (WG_TK / 4);
-    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((items + 15) / 16), dim3(256), 0, st, workspace, S, Np, N, K, dw, db);
+    const int items = N * (Kpr / 4);
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((items + 15) / 16), dim3(256), 0, st, workspace, S, Np, Kpr, N, K, dw, db);
     return check_launch("linear_wgrad_reduce_kernel");
 }

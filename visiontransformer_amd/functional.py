@@ -540,7 +540,7 @@ class _SparseDiscFn(torch.autograd.Function):
                 Kp = xk.shape[1]
                 dwf = torch.empty(36, C, **f32)
                 dbf = torch.empty(36, **f32) if C < Kp else None
-                ws = torch.empty(int(_lib.load().dsw_linear_wgrad_workspace(M, 36)), **f32)
+                ws = torch.empty(int(_lib.load().dsw_linear_wgrad_workspace(M, 36, C)), **f32)
                 call("dsw_linear_wgrad", ptr(G), 64, ptr(xk), Kp, M, 36, C, ptr(dwf), None if dbf is None else ptr(dbf), ptr(ws), stream(dev))
                 g[0] = dwf.view(3, 3, 4, C).permute(2, 3, 0, 1).contiguous()
                 g[1] = dbf[16:20] if dbf is not None else dt0.sum(0)
@@ -820,13 +820,13 @@ class _LinearFn(torch.autograd.Function):
             want_db = bdt is not None and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
                 Ndy, Kx = dyk.shape[1], xk.shape[1]
-                if (mfma and Kp <= 192 and Kd % 4 == 0 and Ndy == Np and Kx == Kp and xk.dtype == act and dyk.is_contiguous()
+                if (mfma and Kd % 4 == 0 and Ndy == Np and Kx == Kp and xk.dtype == act and dyk.is_contiguous()
                         and xk.is_contiguous() and dyk.data_ptr() % 16 == 0 and xk.data_ptr() % 16 == 0):
                     # own split-K kernel; the bias gradient rides in x's first padding column when there is one
                     dw = torch.empty(N, Kd, dtype=torch.float32, device=dyk.device)
                     fused_db = want_db and Kd < Kp
                     dbf = torch.empty(N, dtype=torch.float32, device=dyk.device) if fused_db else None
-                    ws = torch.empty(int(_lib.load().dsw_linear_wgrad_workspace(T, N)), dtype=torch.float32, device=dyk.device)
+                    ws = torch.empty(int(_lib.load().dsw_linear_wgrad_workspace(T, N, Kd)), dtype=torch.float32, device=dyk.device)
                     call("dsw_linear_wgrad", ptr(dyk), Np, ptr(xk), Kp, T, N, Kd, ptr(dw), None if dbf is None else ptr(dbf), ptr(ws),
                          stream(dyk.device))
                     dw = dw.to(wdt)
