@@ -316,13 +316,15 @@ int dsw_sparse_disc_tail_bwd(const void *dsd, int dsd_dtype, const float *w2, co
  * rstd[m] = rsqrt(mean_c x[m][c]^2 + eps), written as fp32 or bf16 with row stride ldo >= C (columns
  * C..ldo-1 are set to zero: the projection kernels take such rows as they are).  C % 4 == 0, C <= 256.
  *   rstd: fp32 [M] (NULL when no backward follows).
- * Backward: dx (fp32 [M][C]) and per-block partial sums of d(weight): partial is
+ * Backward: dx (fp32 [M][C]; with dx_add != NULL, fp32 [M][C], dx = dx_add + the norm's gradient: dx_add is
+ * the gradient that reached x through the residual connection around the normalised branch) and per-block partial sums of d(weight): partial is
  * dsw_rmsnorm_blocks(M) x C floats, to be summed over its rows (e.g. dsw_colsum). */
 int dsw_rmsnorm_blocks(long long M);
 int dsw_rmsnorm_fwd(const float *x, const float *weight, float eps, long long M, int C, void *out, int out_dtype,
                     long long ldo, float *rstd, void *stream);
 int dsw_rmsnorm_bwd(const void *dy, int dy_dtype, long long ld_dy, const float *x, const float *weight,
-                    const float *rstd, long long M, int C, float *dx, float *partial, void *stream);
+                    const float *rstd, long long M, int C, float *dx, const float *dx_add, float *partial,
+                    void *stream);
 
 /* The gated activation of the reference's MLP (DSwinT_arch.py:47-69, fc2(act(fc1_gate(x)) *
  * fc1_content(x))) on h = [gate | content] rows (the two fc1 projections computed as one product):

@@ -271,3 +271,37 @@ def test_prepared_weights_follow_the_parameters(cuda0):
         b = mlp_mod(x).float()
         ref = mlp_mod.fc2(torch.nn.functional.silu(mlp_mod.fc1_gate(x)) * mlp_mod.fc1_content(x)).float()
     assert rel_err(b, ref) < 3e-2 and rel_err(a, b) > 0.05
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_vitblock_prenorm_gradient_sink(cuda0, autocast):
+    """The DSWT ViTBlock lets the two gradients of x of every `x + r * f(norm(x))` meet inside the norm's
+    backward kernel.  Same gradients as with autograd adding them (the norm and residual run as stock
+    torch ops when the sink is off), and the caller's output gradient is left untouched."""
+    from visiontransformer_amd import functional as K, models
+    torch.manual_seed(11)
+    blk = models.DSWTViTBlock(16, 180, n_heads=6).to(cuda0).eval()
+    with torch.no_grad():
+        for r in (blk.rezero1, blk.rezero2, blk.rezero3):
+            r.fill_(0.3)
+    x = torch.randn(2, 32, 32, 180, device=cuda0, requires_grad=True)
+    dy = torch.randn(2, 32, 32, 180, device=cuda0)
+    dy0 = dy.clone()
+    res = []
+    for fused in (True, False):
+        blk.zero_grad(set_to_none=True)
+        x.grad = None
+        orig = K.prenorm_sink
+        if not fused:
+            K.prenorm_sink = lambda *a, **k: None
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                y = blk(x)
+            y.backward(dy)
+        finally:
+            K.prenorm_sink = orig
+        res.append({"x": x.grad.clone(), **{n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None}})
+    assert torch.equal(dy, dy0)
+    tol = 2e-2 if autocast else 1e-5
+    for k in res[1]:
+        assert rel_err(res[0][k], res[1][k]) < tol, k

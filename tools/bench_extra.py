@@ -91,13 +91,34 @@ def workload_c(dev):
             "config": {"workload": "C: MSFT dim 192, levels 2, w 8, 8 blocks x 3, batch %d of 64x64 LR" % B}}
 
 
+def workload_t(dev):
+    """DSWT default network, x4 training step (fwd + bwd, bf16 autocast, L1 loss) on 64x64 LR patches"""
+    from visiontransformer_amd.models import DSWT_DEFAULT, DSWTransformer
+    torch.manual_seed(0)
+    model = DSWTransformer(**DSWT_DEFAULT).to(dev).train()
+    B = int(os.environ.get("T_BATCH", "32"))
+    x = torch.rand(B, 3, 64, 64, device=dev)
+    target = torch.rand(B, 3, 256, 256, device=dev)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(x)
+        torch.nn.functional.l1_loss(y.float(), target).backward()
+        model.zero_grad(set_to_none=True)
+
+    dt = sync_time(step, 5, warm=2)
+    return {"metric": "training patches/sec (DSWT x4, fwd+bwd)", "value": B / dt, "unit": "patches/s", "n_gpus": 1,
+            "ms_per_step": dt * 1e3, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "T: DSWT default (8 blocks x 3, dim 180, w 16), batch %d of 64x64 LR" % B}}
+
+
 def main():
     dev = torch.device("cuda:0")
     from visiontransformer_amd import _lib
     _lib.load()
     which = [a.upper() for a in sys.argv[1:]] or ["D", "E", "C"]
     for w in which:
-        print(json.dumps({"D": workload_d, "E": workload_e, "C": workload_c}[w](dev)), flush=True)
+        print(json.dumps({"D": workload_d, "E": workload_e, "C": workload_c, "T": workload_t}[w](dev)), flush=True)
 
 
 if __name__ == "__main__":

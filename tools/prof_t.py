@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""torch profiler view of one DSWT training step (batch 32 of 64x64 LR, bf16): top kernels / ops"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from visiontransformer_amd import _lib
+from visiontransformer_amd.models import DSWT_DEFAULT, DSWTransformer
+dev = torch.device("cuda:0"); _lib.load()
+torch.manual_seed(0)
+m = DSWTransformer(**DSWT_DEFAULT).to(dev).train()
+B = int(os.environ.get("T_BATCH", "32"))
+x = torch.rand(B, 3, 64, 64, device=dev); tgt = torch.rand(B, 3, 256, 256, device=dev)
+def step():
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+    torch.nn.functional.l1_loss(y.float(), tgt).backward()
+    m.zero_grad(set_to_none=True)
+for _ in range(3): step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(); torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=90))

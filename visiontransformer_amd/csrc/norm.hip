@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float *__restric
 template <typename TG>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG *__restrict__ dy, long long ldg, const float *__restrict__ x,
                                                           const float *__restrict__ w, const float *__restrict__ rstd, long long M, int C,
-                                                          float *__restrict__ dx, float *__restrict__ partial) {
+                                                          float *__restrict__ dx, const float *__restrict__ dx_add, float *__restrict__ partial) {
     __shared__ float4 red[RN_RPB][RN_LPR * RN_MAXV];
     const int sub = threadIdx.x & (RN_LPR - 1), rloc = threadIdx.x / RN_LPR;
     const int nv = C / 4;
@@ -89,8 +89,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG *__restrict__
         if (ok) {
 #pragma unroll
             for (int i = 0; i < RN_MAXV; ++i)
-                if (sub + RN_LPR * i < nv)
-                    *reinterpret_cast<float4 *>(dx + row * C + 4 * (sub + RN_LPR * i)) = (g[i] - xh[i] * dot) * rs;
+                if (sub + RN_LPR * i < nv) {
+                    const size_t at = (size_t)row * C + 4 * (sub + RN_LPR * i);
+                    const float4 v = (g[i] - xh[i] * dot) * rs;
+                    *reinterpret_cast<float4 *>(dx + at) = dx_add != nullptr ? *reinterpret_cast<const float4 *>(dx_add + at) + v : v;
+                }
         }
     }
 #pragma unroll
@@ -135,7 +138,7 @@ extern "C" int dsw_rmsnorm_fwd(const float *x, const float *weight, float eps, l
 }
 
 extern "C" int dsw_rmsnorm_bwd(const void *dy, int dy_dtype, long long ld_dy, const float *x, const float *weight, const float *rstd,
-                               long long M, int C, float *dx, float *partial, void *stream) {
+                               long long M, int C, float *dx, const float *dx_add, float *partial, void *stream) {
     if (M <= 0 || C <= 0 || ld_dy < C) return fail(DSW_EINVAL, "dsw_rmsnorm_bwd: bad sizes M=%lld C=%d ld_dy=%lld", M, C, ld_dy);
     if (C % 4 || ld_dy % 4 || C > 4 * RN_LPR * RN_MAXV)
         return fail(DSW_EUNSUPPORTED, "dsw_rmsnorm_bwd: C and the gradient's row stride must be multiples of 4, C at most %d (C=%d ld_dy=%lld)",
@@ -143,7 +146,7 @@ extern "C" int dsw_rmsnorm_bwd(const void *dy, int dy_dtype, long long ld_dy, co
     DSW_REQUIRE(dy && x && weight && rstd && dx && partial, "dsw_rmsnorm_bwd: null pointer");
     DSW_DISPATCH_DTYPE(dy_dtype, TG, {
         hipLaunchKernelGGL(rmsnorm_bwd_kernel<TG>, dim3(rn_blocks(M)), dim3(256), 0, as_stream(stream), (const TG *)dy, ld_dy, x, weight, rstd,
-                           M, C, dx, partial);
+                           M, C, dx, dx_add, partial);
     });
     return check_launch("rmsnorm_bwd_kernel");
 }

@@ -856,7 +856,7 @@ def linear(x, lin, pad_out=False):
 # ---------------------------------------------------------------------------------------------
 class _RMSNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, eps, out_dtype, pad_out):
+    def forward(ctx, x, weight, eps, out_dtype, pad_out, sink=None):
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         M = x2.shape[0]
@@ -869,41 +869,54 @@ class _RMSNormFn(torch.autograd.Function):
              None if rstd is None else ptr(rstd), stream(x.device))
         if need_bwd:
             ctx.save_for_backward(x2, w32, rstd)
-        ctx.meta = (x.shape, weight.dtype)
+        ctx.meta = (x.shape, weight.dtype, sink)
         return out[:, :C].view(x.shape) if ldo != C else out.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w32, rstd = ctx.saved_tensors
-        xshape, wdt = ctx.meta
+        xshape, wdt, sink = ctx.meta
         M, C = x2.shape
         dy2 = dy.reshape(-1, C)
         if dy2.dtype not in (torch.float32, torch.bfloat16) or dy2.stride(1) != 1 or (M > 1 and dy2.stride(0) % 4) or \
                 dy2.data_ptr() % (4 * dy2.element_size()):
             dy2 = dy2.float().contiguous()
-        dx = torch.empty(M, C, dtype=torch.float32, device=x2.device)
+        if not ctx.needs_input_grad[0]:
+            sink = None
+        # the gradient that reached x around the branch (the residual's dy), if it is already there: the
+        # kernel writes its sum with the norm's gradient into a fresh buffer (the other tensor is only read)
+        prev = sink.buf if sink is not None else None
+        if prev is not None:
+            prev = prev.reshape(M, C)
+            if prev.dtype != torch.float32 or not prev.is_contiguous():
+                prev = prev.float().contiguous()
+        dx = torch.empty(xshape, dtype=torch.float32, device=x2.device)
         nblk = _lib.load().dsw_rmsnorm_blocks(M)
         partial = torch.empty(nblk, C, dtype=torch.float32, device=x2.device)
         call("dsw_rmsnorm_bwd", ctypes.c_void_p(dy2.data_ptr()), dtype_code(dy2.dtype), dy2.stride(0) if M > 1 else C, ptr(x2), ptr(w32),
-             ptr(rstd), M, C, ptr(dx), ptr(partial), stream(x2.device))
+             ptr(rstd), M, C, ptr(dx), None if prev is None else ptr(prev), ptr(partial), stream(x2.device))
         dw = colsum(partial).to(wdt) if ctx.needs_input_grad[1] else None
-        return dx.view(xshape), dw, None, None, None
+        return _dx_deliver(sink, dx), dw, None, None, None, None
 
 
-def rms_norm(x, norm, for_projection=False):
+def _norm_kernel_ok(x, norm):
+    C = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and _ceil_pad(C) <= 256
+            and norm.weight is not None and tuple(norm.normalized_shape) == (C,))
+
+
+def rms_norm(x, norm, for_projection=False, sink=None):
     """`norm(x)` for an nn.RMSNorm over the last dimension of the fp32 stream.  for_projection: the
     result feeds a projection - under bf16 autocast it is produced in bf16 rows padded to 64
     elements (what autocast's cast in front of the Linear would make of it, without the fp32 round
     trip) and returned as a view of the first C columns."""
-    C = x.shape[-1]
-    ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and _ceil_pad(C) <= 256
-          and norm.weight is not None and tuple(norm.normalized_shape) == (C,))
-    if not ok:
+    if not _norm_kernel_ok(x, norm):
+        assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
         return norm(x)
     eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
     act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
     to_act = for_projection and act == torch.bfloat16
-    return _RMSNormFn.apply(x, norm.weight, eps, act if to_act else torch.float32, to_act)
+    return _RMSNormFn.apply(x, norm.weight, eps, act if to_act else torch.float32, to_act, sink)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -949,7 +962,7 @@ def gated_silu(h, pad_out=False):
 # ---------------------------------------------------------------------------------------------
 class _RezeroFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, branch):
+    def forward(ctx, x, r, branch, sink=None):
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         b2, ldb = _row_view4(branch, C)
@@ -958,13 +971,13 @@ class _RezeroFn(torch.autograd.Function):
         y = torch.empty(M, C, dtype=torch.float32, device=x.device)
         call("dsw_rezero_fwd", ptr(x2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(y), stream(x.device))
         ctx.save_for_backward(b2, r32)
-        ctx.meta = (x.shape, branch.shape, ldb, r.shape, r.dtype)
+        ctx.meta = (x.shape, branch.shape, ldb, r.shape, r.dtype, sink)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         b2, r32 = ctx.saved_tensors
-        xshape, bshape, ldb, rshape, rdt = ctx.meta
+        xshape, bshape, ldb, rshape, rdt, sink = ctx.meta
         M, C = b2.shape
         dy2 = dy.reshape(-1, C)
         if dy2.dtype != torch.float32 or not dy2.is_contiguous():
@@ -978,18 +991,35 @@ class _RezeroFn(torch.autograd.Function):
                  stream(b2.device))
             db = (dbuf[:, :C] if ld_db != C else dbuf).view(bshape)
             dr = partial.sum().reshape(rshape).to(rdt)
-        return dy, dr, db
+        if sink is None or not ctx.needs_input_grad[0]:
+            return dy, dr, db, None
+        # the residual's share of x's gradient is dy itself: the norm's backward reads it and writes the sum
+        if sink.buf is not None:  # the norm's gradient came first: its buffer is ours to add into
+            sink.buf.view(M, C).add_(dy2)
+            return sink.deliver(sink.buf), dr, db, None
+        return sink.deliver(dy2.view(xshape)), dr, db, None
 
 
-def rezero_residual(x, r, branch):
+def rezero_residual(x, r, branch, sink=None):
     """x + r * branch for the fp32 stream x [..., C], a one-element parameter r and a branch of the same
     shape in fp32 / bf16 (dense or a view of padded rows)."""
     C = x.shape[-1]
     ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and r.numel() == 1
           and branch.shape == x.shape and branch.dtype in (torch.float32, torch.bfloat16))
     if not ok:
+        assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
         return torch.addcmul(x, r, branch)
-    return _RezeroFn.apply(x, r, branch)
+    return _RezeroFn.apply(x, r, branch, sink)
+
+
+def prenorm_sink(x, norm, r):
+    """For y = x + r * f(norm(x)): a GradSink through which the two gradients of x (the residual's dy and
+    the norm's dx) meet in one buffer instead of being added by autograd in a pass of its own; None when
+    no gradient is needed or either op would not run in its kernel."""
+    C = x.shape[-1]
+    if not (torch.is_grad_enabled() and x.requires_grad and _norm_kernel_ok(x, norm) and r.numel() == 1):
+        return None
+    return GradSink(2)
 
 
 # ---------------------------------------------------------------------------------------------

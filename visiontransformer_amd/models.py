@@ -97,10 +97,15 @@ class DSWTViTBlock(nn.Module):
         self.drop_path = nn.Dropout(drop_path)
 
     def forward(self, x):
-        # x + rezero * branch in one pass over the fp32 stream, the branch read where it lies
-        x = K.rezero_residual(x, self.rezero1, self.drop_path(self.wmsa(K.rms_norm(x, self.ln1, for_projection=True))))
-        x = K.rezero_residual(x, self.rezero3, self.drop_path(self.sdwa(K.rms_norm(x, self.ln3))))
-        x = K.rezero_residual(x, self.rezero2, self.drop_path(self.mlp1(K.rms_norm(x, self.ln2, for_projection=True))))
+        # x + rezero * branch(norm(x)): one pass over the fp32 stream for the residual, the branch read where
+        # it lies, and the two gradients of x meeting in one buffer (K.prenorm_sink)
+        for norm, rz, branch, proj in ((self.ln1, self.rezero1, self.wmsa, True), (self.ln3, self.rezero3, self.sdwa, False),
+                                       (self.ln2, self.rezero2, self.mlp1, True)):
+            sink = K.prenorm_sink(x, norm, rz)
+            b = self.drop_path(branch(K.rms_norm(x, norm, for_projection=proj, sink=sink)))
+            if sink is not None and not (b.shape == x.shape and b.dtype in (torch.float32, torch.bfloat16)):
+                raise RuntimeError("branch output of an unexpected form")
+            x = K.rezero_residual(x, rz, b, sink=sink)
         return x
 
 
