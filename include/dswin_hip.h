@@ -348,16 +348,23 @@ int dsw_rezero_bwd(const float *dy, const void *branch, int b_dtype, long long l
                    int C, void *d_branch, long long ld_db, float *partial, void *stream);
 
 /* Dense 3x3 convolution, stride 1, zero padding 1, on an NHWC tensor (the LastChannelConv2D layers of the
- * reference's model assembly, DSwinT_arch.py:36-44, used at :372 and :420), forward only, on the matrix
- * cores: the product kernel of dsw_linear with one k slab per tap, the rows of tap t read shifted by
+ * reference's model assembly, DSwinT_arch.py:36-44, used at :372 and :420) on the matrix cores: the product kernel of dsw_linear with one k slab per tap, the rows of tap t read shifted by
  * (t / 3 - 1, t % 3 - 1) pixels and as zero outside the image.
  *   x:   [B][H][W][ldx] fp32 or bf16 (rounded to bf16 on load), below 2 GiB.
  *   w_p: bf16 [wrows][ldw] with w_p[co][t * ceil64(C) + ci] = weight[co][ci][t / 3][t % 3], zero elsewhere
  *        (dsw_weight_prep of the tap-major, channel-padded matrix).
- *   out: [B*H*W][ldo] fp32 or bf16, columns 0..ncols-1 written; bias fp32 [N] or NULL. */
+ *   out: [B*H*W][ldo] fp32 or bf16, columns 0..ncols-1 written; bias fp32 [N] or NULL.
+ *   x_copy: NULL or bf16 [B*H*W][ld_copy]: x rounded to bf16, channels padded to 64 with zeros. */
 int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p,
                      int wrows, int ldw, const float *bias, int N, void *out, int out_dtype, long long ldo,
-                     int ncols, void *stream);
+                     int ncols, void *x_copy, long long ld_copy, void *stream);
+/* Its weight and bias gradient: dw[co][t][ci] = sum_px dy[px][co] x[px + off(t)][ci] (tap-major, fp32
+ * [Co][9][Ci]), db[co] = sum_px dy[px][co]; dy, x bf16 in zero-padded rows as for dsw_linear_wgrad (x_copy
+ * of the forward call has that form).  The input gradient is the same convolution applied to dy with the
+ * flipped, transposed weight.  workspace: dsw_conv3x3_wgrad_workspace(B, H, W, Co, Ci) floats. */
+size_t dsw_conv3x3_wgrad_workspace(int B, int H, int W, int Co, int Ci);
+int dsw_conv3x3_wgrad(const void *dy, long long ldy, const void *x, long long ldx, int B, int H, int W, int Co,
+                      int Ci, float *dw, float *db, float *workspace, void *stream);
 
 /* LayerNorm over channel rows of the fp32 stream (the nn.LayerNorm layers of msft's ViTBlock,
  * msft_arch.py:152-153, applied at :163-165): out = (x - mean) * rstd * weight + bias, written as fp32 or

@@ -572,8 +572,19 @@ def test_conv3x3_nhwc(cuda0, B, H, W, Ci, Co, xdtype):
     bf = torch.bfloat16
     ref = F.conv2d(x.to(bf).float().permute(0, 3, 1, 2), conv.weight.to(bf).float(), conv.bias.float(), padding=1).permute(0, 2, 3, 1)
     assert ((got.float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
+    # training: input, weight and bias gradients against autograd through F.conv2d on the same rounded operands
+    xg = x.detach().clone().requires_grad_()
+    dy = torch.randn(B, H, W, Co, device=cuda0)
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        assert K.conv3x3_nhwc(x, conv) is None      # autograd on: the stock convolution is used
+        y = K.conv3x3_nhwc(xg, conv)
+    conv.zero_grad(set_to_none=True)
+    y.backward(dy.to(bf))
+    xr = x.to(bf).float().requires_grad_()
+    wr = conv.weight.detach().to(bf).float().requires_grad_()
+    br = conv.bias.detach().float().requires_grad_()
+    F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1).permute(0, 2, 3, 1).backward(dy.to(bf).float())
+    assert rel_err(xg.grad.float(), xr.grad) < 2e-2
+    assert rel_err(conv.weight.grad, wr.grad) < 2e-2 and rel_err(conv.bias.grad, br.grad) < 2e-2
 
 
 @pytest.mark.gpu

@@ -260,8 +260,9 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 for (int j = 0; j < KS / 64; ++j) {
                     const uint4 v = ap[p * (KS / 64) + j].pack(kslab * KS + j * 64 + scol, K);
                     *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * LS + j * 64 + scol) = v;
-                    if (copy_row != nullptr && p * 32 + srow < rows)
-                        *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + slab * KS + j * 64) = v;
+                    // (convolution: the centre tap's rows are the block's own rows)
+                    if (copy_row != nullptr && p * 32 + srow < rows && (!conv || tap == 4))
+                        *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + kslab * KS + j * 64) = v;
                 }
             write_b();
         }
@@ -333,7 +334,7 @@ constexpr size_t WG_LDS = (size_t)2 * WG_BM * WG_LS * sizeof(bf16_t);
 
 __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_t *__restrict__ dY, long long ldy,
                                                                       const bf16_t *__restrict__ X, long long ldx, int M, int K, int Kp,
-                                                                      int Np, int Kpr, int rows_per_block, float *__restrict__ partial) {
+                                                                      int Np, int Kpr, int rows_per_block, int convH, int convW, float *__restrict__ partial) {
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t *Ys = reinterpret_cast<bf16_t *>(smem);
     bf16_t *Xs = Ys + WG_BM * WG_LS;
@@ -343,14 +344,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
     const int m_begin = blockIdx.y * rows_per_block;
     const int rows = min(M - m_begin, rows_per_block);  // >= 1 by the grid's construction
     const int nst = (rows + WG_BM - 1) / WG_BM;
-    const int k0 = blockIdx.z * WG_TK;  // this block's columns of X
-    const bool ones = K < Kp && K >= k0 && K < k0 + WG_TK;
+    // 3x3 convolution mode (convH > 0): rows are the pixels of NHWC images, blockIdx.z also runs over the 9
+    // taps, and a tap's block reads the rows of X shifted by the tap's offset (zero outside the image): its
+    // part of the result is dW[:, tap, :], laid side by side in the partial rows.
+    const bool conv = convH > 0;
+    const int nkb = Kpr / WG_TK;
+    const int tap = conv ? blockIdx.z / nkb : 0, kb = blockIdx.z - tap * nkb;
+    const int shift = conv ? (tap / 3 - 1) * convW + (tap % 3 - 1) : 0;
+    const int k0 = kb * WG_TK;  // this block's columns of X
+    const bool ones = K < Kp && K >= k0 && K < k0 + WG_TK && (!conv || tap == 4);
 
     // staging: piece = 8 consecutive columns; 24 pieces per row, 16 rows per pass of the block
     const int prow = tid / 24, pc = tid - prow * 24;
     const bool y_ok = n0 + pc * 8 < Np, x_ok = k0 + pc * 8 < Kp;
     const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(dY + (size_t)m_begin * ldy + n0, ((size_t)(rows - 1) * ldy + (Np - n0)) * sizeof(bf16_t));
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(X + (size_t)m_begin * ldx, ((size_t)(rows - 1) * ldx + Kp) * sizeof(bf16_t));
+    const __amdgpu_buffer_rsrc_t rs_x = conv ? make_rsrc(X, ((size_t)(M - 1) * ldx + Kp) * sizeof(bf16_t))
+                                             : make_rsrc(X + (size_t)m_begin * ldx, ((size_t)(rows - 1) * ldx + Kp) * sizeof(bf16_t));
     const unsigned y_off = (unsigned)(((size_t)prow * ldy + pc * 8) * sizeof(bf16_t));
     const unsigned x_off = (unsigned)(((size_t)prow * ldx + k0 + pc * 8) * sizeof(bf16_t));
     const unsigned y_step = (unsigned)(16 * ldy * sizeof(bf16_t)), x_step = (unsigned)(16 * ldx * sizeof(bf16_t));
@@ -361,7 +370,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
 #pragma unroll
         for (int i = 0; i < WG_PIECES; ++i) {
             yr[i] = buf_load16(rs_y, y_off + i * y_step, ys);
-            xr[i] = buf_load16(rs_x, x_off + i * x_step, xs);
+            if (conv) {
+                const int m = m_begin + st * WG_BM + prow + 16 * i;
+                const int xw = m % convW, yh = (m / convW) % convH;
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const bool in = m < M && yh + dy >= 0 && yh + dy < convH && xw + dx >= 0 && xw + dx < convW;
+                xr[i] = buf_load16(rs_x, in ? (unsigned)(((size_t)(m + shift) * ldx + k0 + pc * 8) * sizeof(bf16_t)) : 0x80000000u, 0u);
+            } else {
+                xr[i] = buf_load16(rs_x, x_off + i * x_step, xs);
+            }
         }
     };
     auto write_stage = [&](int st) {
@@ -421,7 +438,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
         }
     }
     // lane = output column k, registers = rows n: 128-byte runs per row
-    float *pb = partial + (size_t)blockIdx.y * Np * Kpr + k0;
+    const int prl = (conv ? 9 : 1) * Kpr;  // partial row length
+    float *pb = partial + (size_t)blockIdx.y * Np * prl + tap * Kpr + k0;
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
@@ -429,24 +447,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 64 + ta * 32 + rho(r) + 4 * hh;
-                if (n < Np) pb[(size_t)n * Kpr + wk * 96 + tb * 32 + l31] = acc[ta][tb][r];
+                if (n < Np) pb[(size_t)n * prl + wk * 96 + tb * 32 + l31] = acc[ta][tb][r];
             }
 }
 
-// dw[n][k] = sum_s partial[s][n][k] (n < N, k < K); db[n] = sum_s partial[s][n][K].  A workgroup sums 16
-// groups of 4 columns, its 16 thread slices taking every 16th partial block; the slices meet in LDS and
-// are added in slice order (a fixed tree: bitwise reproducible).
-__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *__restrict__ partial, int S, int Np, int Kpr, int N, int K,
-                                                                  float *__restrict__ dw, float *__restrict__ db) {
+// dw[n][t][k] = sum_s partial[s][n][t * Kpr + k] (n < N, k < K, t < ntap); db[n] = the same sum at column K of
+// tap ntap / 2 (the only tap, or the centre one).  A workgroup sums 16 groups of 4 columns, its 16 thread
+// slices taking every 16th partial block; the slices meet in LDS and are added in slice order (a fixed tree:
+// bitwise reproducible).
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *__restrict__ partial, int S, int Np, int Kpr, int ntap, int N,
+                                                                  int K, float *__restrict__ dw, float *__restrict__ db) {
     __shared__ float4 red[16][16];
     const int it = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + it;  // (n, group of 4 columns)
-    const int n = i / (Kpr / 4), k4 = (i - n * (Kpr / 4)) * 4;
-    const bool live = n < N && (k4 < K || (k4 == K && db != nullptr));
+    const int prl = ntap * Kpr;
+    const int i = blockIdx.x * 16 + it;  // (n, tap, group of 4 columns)
+    const int n = i / (prl / 4), c4 = (i - n * (prl / 4)) * 4, tap = c4 / Kpr, k4 = c4 - tap * Kpr;
+    const bool live = n < N && (k4 < K || (k4 == K && db != nullptr && tap == ntap / 2));
     float4 a = f4zero();
     if (live) {
-        const float4 *p = reinterpret_cast<const float4 *>(partial + (size_t)n * Kpr + k4);
-        const size_t stride = (size_t)Np * Kpr / 4;
+        const float4 *p = reinterpret_cast<const float4 *>(partial + (size_t)n * prl + c4);
+        const size_t stride = (size_t)Np * prl / 4;
         for (int s0 = sl; s0 < S; s0 += 16) a = a + p[(size_t)s0 * stride];
     }
     red[sl][it] = a;
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *_
     if (sl == 0 && live) {
 #pragma unroll
         for (int j = 1; j < 16; ++j) a = a + red[j][it];
-        if (k4 < K) *reinterpret_cast<float4 *>(dw + (size_t)n * K + k4) = a;
+        if (k4 < K) *reinterpret_cast<float4 *>(dw + ((size_t)n * ntap + tap) * K + k4) = a;
         else db[n] = a.x;
     }
 }
@@ -552,7 +572,8 @@ extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M
 }
 
 extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,
-                                const float *bias, int N, void *out, int out_dtype, long long ldo, int ncols, void *stream) {
+                                const float *bias, int N, void *out, int out_dtype, long long ldo, int ncols, void *x_copy,
+                                long long ld_copy, void *stream) {
     const long long M = (long long)B * H * W;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_conv3x3_nhwc: bad sizes B=%d H=%d W=%d C=%d ncols=%d", B, H, W, C, ncols);
@@ -569,13 +590,15 @@ extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B
         return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc: ncols and the output stride must be multiples of 4, the base 16-byte aligned");
     if (bias != nullptr && (N <= 0 || N % 4 || N > ncols || ((uintptr_t)bias & 15)))
         return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc: bias needs N %% 4 == 0, N <= ncols, a 16-byte aligned base");
+    if (x_copy != nullptr && (ld_copy < Kp || ld_copy % 8 || ((uintptr_t)x_copy & 15)))
+        return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc: the bf16 copy of x needs rows of >= %d elements, a multiple of 8", Kp);
     const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 ? 128 : 64);
     const int nslab = 9 * (Kp / KS);
     hipStream_t st = as_stream(stream);
     int rc = DSW_OK;
 #define DSW_CONV_KS(KSV)                                                                                                          \
     DSW_DISPATCH_DTYPE(x_dtype, TA, DSW_DISPATCH_DTYPE(out_dtype, TC, {                                                           \
-        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, nullptr, 0, 0, H, W, st); \
+        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, 0, H, W, st); \
     }))
     if (KS == 192) DSW_CONV_KS(192);
     else if (KS == 128) DSW_CONV_KS(128);
@@ -584,9 +607,10 @@ extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B
     return rc;
 }
 
-static void wgrad_split(long long M, int Np, int Kp, int *rows_per_block, int *S) {
-    const int nb = ((Np + WG_TN - 1) / WG_TN) * ((Kp + WG_TK - 1) / WG_TK);
+static void wgrad_split(long long M, int Np, int Kp, int ntap, int *rows_per_block, int *S) {
+    const int nb = ((Np + WG_TN - 1) / WG_TN) * ((Kp + WG_TK - 1) / WG_TK) * ntap;
     long long want = 256 / nb;  // about one workgroup per CU: every extra one adds a partial block to write and re-read
+    if (want < 8 && ntap > 1) want = 8;  // 9 taps: keep some row ranges so that a block's stream stays short
     if (want < 1) want = 1;
     long long rpb = (M + want - 1) / want;
     rpb = (rpb + WG_BM - 1) / WG_BM * WG_BM;
@@ -594,38 +618,52 @@ static void wgrad_split(long long M, int Np, int Kp, int *rows_per_block, int *S
     *S = (int)((M + rpb - 1) / rpb);
 }
 
-extern "C" size_t dsw_linear_wgrad_workspace(long long M, int N, int K) {
+static size_t wgrad_ws(long long M, int N, int K, int ntap) {
     if (M <= 0 || N <= 0 || K <= 0 || M > 0x7fffff00LL) return 0;
     const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64, Kpr = (Kp + WG_TK - 1) / WG_TK * WG_TK;
     int rpb, S;
-    wgrad_split(M, Np, Kp, &rpb, &S);
-    return (size_t)S * Np * Kpr;
+    wgrad_split(M, Np, Kp, ntap, &rpb, &S);
+    return (size_t)S * Np * Kpr * ntap;
+}
+
+extern "C" size_t dsw_linear_wgrad_workspace(long long M, int N, int K) { return wgrad_ws(M, N, K, 1); }
+extern "C" size_t dsw_conv3x3_wgrad_workspace(int B, int H, int W, int Co, int Ci) { return wgrad_ws((long long)B * H * W, Co, Ci, 9); }
+
+static int wgrad_launch(const char *who, const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K, int convH,
+                        int convW, float *dw, float *db, float *workspace, void *stream) {
+    if (M <= 0 || M > 0x7fffff00LL || N <= 0 || K <= 0) return fail(DSW_EINVAL, "%s: bad sizes M=%lld N=%d K=%d", who, M, N, K);
+    DSW_REQUIRE(dy && x && dw && workspace, "%s: null pointer", who);
+    const int ntap = convH > 0 ? 9 : 1;
+    const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64, Kpr = (Kp + WG_TK - 1) / WG_TK * WG_TK;
+    if (K % 4) return fail(DSW_EUNSUPPORTED, "%s: K=%d must be a multiple of 4", who, K);
+    if (db != nullptr && K == Kp) return fail(DSW_EUNSUPPORTED, "%s: the bias gradient rides in a padding column of x, K=%d leaves none", who, K);
+    if (ldy < Np || ldx < Kp || ldy % 8 || ldx % 8 || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15))
+        return fail(DSW_EUNSUPPORTED, "%s: dy / x need rows of >= %d / %d bf16 elements (zero padded), multiples of 8, 16-byte aligned "
+                                      "(ldy=%lld ldx=%lld)", who, Np, Kp, ldy, ldx);
+    if (((uintptr_t)dw & 15) || ((uintptr_t)workspace & 15)) return fail(DSW_EUNSUPPORTED, "%s: dw / workspace must be 16-byte aligned", who);
+    int rpb, S;
+    wgrad_split(M, Np, Kp, ntap, &rpb, &S);
+    if ((long long)rpb * (ldy > ldx ? ldy : ldx) * 2 >= 0x7fffffffLL || (ntap > 1 && (size_t)M * ldx * 2 >= 0x80000000ull))
+        return fail(DSW_EUNSUPPORTED, "%s: operands beyond 2 GiB per block (%d rows) or per tensor", who, rpb);
+    hipStream_t st = as_stream(stream);
+    int rc = set_lds((const void *)linear_wgrad_kernel, WG_LDS, who);
+    if (rc) return rc;
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((Np + WG_TN - 1) / WG_TN, S, ntap * (Kpr / WG_TK)), dim3(WG_THREADS), WG_LDS, st,
+                       (const bf16_t *)dy, ldy, (const bf16_t *)x, ldx, (int)M, K, Kp, Np, Kpr, rpb, convH, convW, workspace);
+    rc = check_launch("linear_wgrad_kernel");
+    if (rc) return rc;
+    const int items = N * (ntap * Kpr / 4);
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((items + 15) / 16), dim3(256), 0, st, workspace, S, Np, Kpr, ntap, N, K, dw, db);
+    return check_launch("linear_wgrad_reduce_kernel");
 }
 
 extern "C" int dsw_linear_wgrad(const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K, float *dw,
                                 float *db, float *workspace, void *stream) {
-    if (M <= 0 || M > 0x7fffff00LL || N <= 0 || K <= 0) return fail(DSW_EINVAL, "dsw_linear_wgrad: bad sizes M=%lld N=%d K=%d", M, N, K);
-    DSW_REQUIRE(dy && x && dw && workspace, "dsw_linear_wgrad: null pointer");
-    const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64, Kpr = (Kp + WG_TK - 1) / WG_TK * WG_TK;
-    if (K % 4) return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: K=%d must be a multiple of 4", K);
-    if (db != nullptr && K == Kp)
-        return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: the bias gradient rides in a padding column of x, K=%d leaves none", K);
-    if (ldy < Np || ldx < Kp || ldy % 8 || ldx % 8 || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15))
-        return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: dy / x need rows of >= %d / %d bf16 elements (zero padded), multiples of 8, "
-                                      "16-byte aligned (ldy=%lld ldx=%lld)", Np, Kp, ldy, ldx);
-    if (((uintptr_t)dw & 15) || ((uintptr_t)workspace & 15)) return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: dw / workspace must be 16-byte aligned");
-    int rpb, S;
-    wgrad_split(M, Np, Kp, &rpb, &S);
-    if ((long long)rpb * (ldy > ldx ? ldy : ldx) * 2 >= 0x7fffffffLL)
-        return fail(DSW_EUNSUPPORTED, "dsw_linear_wgrad: a block's row range (%d rows) exceeds 2 GiB", rpb);
-    hipStream_t st = as_stream(stream);
-    int rc = set_lds((const void *)linear_wgrad_kernel, WG_LDS, "dsw_linear_wgrad");
-    if (rc) return rc;
-    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((Np + WG_TN - 1) / WG_TN, S, Kpr / WG_TK), dim3(WG_THREADS), WG_LDS, st, (const bf16_t *)dy,
-                       ldy, (const bf16_t *)x, ldx, (int)M, K, Kp, Np, Kpr, rpb, workspace);
-    rc = check_launch("linear_wgrad_kernel");
-    if (rc) return rc;
-    const int items = N * (Kpr / 4);
-    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((items + 15) / 16), dim3(256), 0, st, workspace, S, Np, Kpr, N, K, dw, db);
-    return check_launch("linear_wgrad_reduce_kernel");
+    return wgrad_launch("dsw_linear_wgrad", dy, ldy, x, ldx, M, N, K, 0, 0, dw, db, workspace, stream);
+}
+
+extern "C" int dsw_conv3x3_wgrad(const void *dy, long long ldy, const void *x, long long ldx, int B, int H, int W, int Co, int Ci,
+                                 float *dw, float *db, float *workspace, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return fail(DSW_EINVAL, "dsw_conv3x3_wgrad: bad sizes B=%d H=%d W=%d", B, H, W);
+    return wgrad_launch("dsw_conv3x3_wgrad", dy, ldy, x, ldx, (long long)B * H * W, Co, Ci, H, W, dw, db, workspace, stream);
 }

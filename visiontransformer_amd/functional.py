@@ -1025,42 +1025,107 @@ def prenorm_sink(x, norm, r):
 # ---------------------------------------------------------------------------------------------
 # dense 3x3 convolution on NHWC (LastChannelConv2D, DSwinT_arch.py:36-44), inference
 # ---------------------------------------------------------------------------------------------
-def _conv3x3_operand(weight):
-    """Conv2d weight [Co, Ci, 3, 3] -> bf16 [ceil64(Co), 9 * ceil64(Ci)], tap-major with the channels of
-    every tap padded to 64; kept per parameter like the projection weights (autograd is off here)."""
-    e = _PREP_CACHE.get(("conv3x3", id(weight)))
-    if e is not None and e[0]() is weight and e[1] == weight._version and e[2] == weight.data_ptr():
-        return e[3]
-    Co, Ci = weight.shape[:2]
+def _taps_operand(w4):
+    """[Co, Ci, 3, 3] fp32 tensor -> bf16 [ceil64(Co), 9 * ceil64(Ci)], tap-major, channels of every tap padded to 64"""
+    Co, Ci = w4.shape[:2]
     Kp = _ceil_pad(Ci)
-    taps = torch.zeros(Co, 9, Kp, dtype=torch.float32, device=weight.device)
-    taps[:, :, :Ci] = weight.detach().float().permute(0, 2, 3, 1).reshape(Co, 9, Ci)
-    w_p = torch.empty(_ceil_pad(Co), 9 * Kp, dtype=torch.bfloat16, device=weight.device)
-    call("dsw_weight_prep", ptr(taps), dtype_code(torch.float32), Co, 9 * Kp, ptr(w_p), None, stream(weight.device))
-    _PREP_CACHE[("conv3x3", id(weight))] = (weakref.ref(weight), weight._version, weight.data_ptr(), w_p)
+    taps = torch.zeros(Co, 9, Kp, dtype=torch.float32, device=w4.device)
+    taps[:, :, :Ci] = w4.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+    w_p = torch.empty(_ceil_pad(Co), 9 * Kp, dtype=torch.bfloat16, device=w4.device)
+    call("dsw_weight_prep", ptr(taps), dtype_code(torch.float32), Co, 9 * Kp, ptr(w_p), None, stream(w4.device))
     return w_p
+
+
+def _conv3x3_operand(weight):
+    """Conv2d weight [Co, Ci, 3, 3] -> the kernel's operand; without autograd it is kept per parameter like
+    the projection weights."""
+    caching = not torch.is_grad_enabled()
+    if caching:
+        e = _PREP_CACHE.get(("conv3x3", id(weight)))
+        if e is not None and e[0]() is weight and e[1] == weight._version and e[2] == weight.data_ptr():
+            return e[3]
+    w_p = _taps_operand(weight.detach().float())
+    if caching:
+        _PREP_CACHE[("conv3x3", id(weight))] = (weakref.ref(weight), weight._version, weight.data_ptr(), w_p)
+    return w_p
+
+
+def _conv3x3_call(x2, B, H, W, Ci, w_p, bias32, Co, out, x_copy):
+    call("dsw_conv3x3_nhwc", _dptr(x2), dtype_code(x2.dtype), x2.stride(0), B, H, W, Ci, ptr(w_p), w_p.shape[0], w_p.shape[1],
+         None if bias32 is None else ptr(bias32), Co, ptr(out), dtype_code(out.dtype), out.shape[-1], Co,
+         None if x_copy is None else ptr(x_copy), 0 if x_copy is None else x_copy.shape[1], stream(out.device))
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """3x3 convolution on NHWC under bf16 autocast: product, input gradient (the same kernel on the
+    flipped, transposed weight) and weight / bias gradient (dsw_conv3x3_wgrad) on the matrix cores."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        B, H, W, Ci = x.shape
+        Co = weight.shape[0]
+        M = B * H * W
+        x2 = x.reshape(M, Ci)
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        out = torch.empty(B, H, W, Co, dtype=act, device=x.device)
+        xk = _mark_padded(torch.empty(M, _ceil_pad(Ci), dtype=torch.bfloat16, device=x.device)) if ctx.needs_input_grad[1] else None
+        _conv3x3_call(x2, B, H, W, Ci, _conv3x3_operand(weight), b32, Co, out, xk)
+        ctx.save_for_backward(xk if xk is not None else x2, weight)
+        ctx.meta = (x.shape, x.dtype, None if bias is None else bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xk, weight = ctx.saved_tensors
+        (B, H, W, Ci), xdt, bdt = ctx.meta
+        Co = weight.shape[0]
+        M = B * H * W
+        dev = dy.device
+        dy2 = dy.reshape(M, Co)
+        if _mfma_operand(dy2) is None:
+            dy2 = dy2.contiguous()
+        need_w = ctx.needs_input_grad[1] or (bdt is not None and ctx.needs_input_grad[2])
+        dyk = _padded_rows(dy2, torch.bfloat16)
+        fresh = dyk is None and need_w
+        if fresh:
+            dyk = _mark_padded(torch.empty(M, _ceil_pad(Co), dtype=torch.bfloat16, device=dev))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_t = _taps_operand(weight.detach().float().flip(2, 3).transpose(0, 1))   # [Ci, Co, 3, 3], taps mirrored
+            dx = torch.empty(B, H, W, Ci, dtype=xdt if xdt in (torch.float32, torch.bfloat16) else torch.float32, device=dev)
+            _conv3x3_call(dy2, B, H, W, Co, w_t, None, Ci, dx, dyk if fresh else None)
+            if dx.dtype != xdt:
+                dx = dx.to(xdt)
+        elif fresh:
+            dyk = _cast_padded(dy2, torch.bfloat16)
+        dw = db = None
+        if need_w:
+            Kp = xk.shape[1]
+            dwt = torch.empty(Co, 9, Ci, dtype=torch.float32, device=dev)
+            fused_db = bdt is not None and Ci < Kp
+            dbf = torch.empty(Co, dtype=torch.float32, device=dev) if fused_db else None
+            ws = torch.empty(int(_lib.load().dsw_conv3x3_wgrad_workspace(B, H, W, Co, Ci)), dtype=torch.float32, device=dev)
+            call("dsw_conv3x3_wgrad", ptr(dyk), dyk.shape[1], ptr(xk), Kp, B, H, W, Co, Ci, ptr(dwt), None if dbf is None else ptr(dbf),
+                 ptr(ws), stream(dev))
+            dw = dwt.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous().to(weight.dtype)
+            if bdt is not None:
+                db = (dbf if fused_db else colsum(dyk)[:Co]).to(bdt)
+        return dx, dw, db, None
 
 
 def conv3x3_nhwc(x, conv):
     """`conv` (an nn.Conv2d with a 3x3 kernel, stride 1, padding 1, one group) applied to the NHWC tensor
-    x [B, H, W, Ci] -> [B, H, W, Co], or None when this call is not one the kernel takes (autograd on,
-    not bf16 autocast, other geometry): the caller then uses the stock convolution."""
+    x [B, H, W, Ci] -> [B, H, W, Co], or None when this call is not one the kernels take (not bf16
+    autocast, other geometry): the caller then uses the stock convolution."""
     act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
     B, H, W, Ci = x.shape
-    ok = (not torch.is_grad_enabled() and x.is_cuda and act == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)
+    ok = (x.is_cuda and act == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)
           and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
           and conv.groups == 1 and conv.padding_mode == "zeros" and Ci % 4 == 0 and conv.out_channels % 4 == 0
-          and B * H * W * Ci * x.element_size() < 2 ** 31)
+          and B * H * W * max(_ceil_pad(Ci), _ceil_pad(conv.out_channels)) * 4 < 2 ** 31)
     if not ok:
         return None
-    x = x.contiguous()
-    Co = conv.out_channels
-    w_p = _conv3x3_operand(conv.weight)
-    b32 = None if conv.bias is None else conv.bias.detach().float().contiguous()
-    out = torch.empty(B, H, W, Co, dtype=act, device=x.device)
-    call("dsw_conv3x3_nhwc", ptr(x), dtype_code(x.dtype), Ci, B, H, W, Ci, ptr(w_p), w_p.shape[0], w_p.shape[1],
-         None if b32 is None else ptr(b32), Co, ptr(out), dtype_code(act), Co, Co, stream(x.device))
-    return out
+    return _Conv3x3Fn.apply(x.contiguous(), conv.weight, conv.bias, act)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ class LastChannelConv2D(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, groups=groups)
 
     def forward(self, x):
-        y = K.conv3x3_nhwc(x, self.conv)  # inference under bf16 autocast: NHWC kernel, no layout copies
+        y = K.conv3x3_nhwc(x, self.conv)  # bf16 autocast: NHWC kernels (fwd and bwd), no layout copies
         if y is not None:
             return y
         return self.conv(x.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
