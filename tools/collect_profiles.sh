@@ -4,6 +4,7 @@
 # FETCH_SIZE / WRITE_SIZE passes and two SQ-counter passes over `bench.py --pmc-target`; copies the
 # summaries into profiles/ under TAG.
 T=${1:-r1}
+rm -rf gpurun_out/$T
 /usr/local/graft/bin/gpurun --timeout 1200 -- "mkdir -p gpurun_out/$T/kt gpurun_out/$T/f gpurun_out/$T/w gpurun_out/$T/s1 gpurun_out/$T/s2; R=\$GRAFT_REPO_ROOT; O=\$R/gpurun_out/$T; cd /tmp && export TMPDIR=/tmp && \
 timeout -k 10 400 python3 \$R/bench.py > \$O/bench.json 2> \$O/bench.err && \
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d \$O/kt -- python3 \$R/bench.py --no-cpu-baseline > \$O/kt/run.log 2>&1 && \
