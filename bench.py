@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the DS-MSA / windowed-MSA hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "config B"): one DSWT attention pair - WindowedMSA followed
+Workload ("config B": the DS-MSA forward + backward case at batch 32): one DSWT attention pair - WindowedMSA followed
 by DeformableSparseWindowAttention, default model config (C=180, 6 heads, 16x16 windows) - forward
 and backward under bf16 autocast on a batch of 32 LR patches of 64x64 (activations [32,64,64,180]
 fp32, as the reference's ViTBlock feeds them).  A step = one forward + backward of that pair.
