@@ -212,6 +212,8 @@ int dsw_unshuffle_nhwc_fwd(const void *x, int dtype, int B, int c, int H, int W,
  * Convolutions that sit on the DS-MSA path, NHWC, so that the reference's NHWC->NCHW round trip
  * (DSwinT_arch.py:259, :317) disappears.  Weights and their gradients are fp32.
  *
+ * identity_if_zero (forward, may be NULL): a device counter, e.g. dsw_select_fwd's n_pass; when it holds 0
+ * the kernel copies x to y instead (the early return of DSwinT_arch.py:291-292 without a host read).
  * dsw_dwconv3x3_fwd/bwd: depthwise 3x3, stride 1, zero padding 1 (out_conv, DSwinT_arch.py:198,
  *   :317).  weight [C,9], bias [C] or NULL.  bwd writes dx, d_weight [C,9], d_bias [C];
  *   partial: caller scratch of (dsw_dwconv3x3_bwd_blocks(B,H,W) + 1) * C * 10 floats.
@@ -223,7 +225,7 @@ int dsw_unshuffle_nhwc_fwd(const void *x, int dtype, int B, int c, int H, int W,
  *   buffer of dsw_sparse_disc_bwd_scratch(B,H,W,C,w) floats.
  */
 int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B,
-                      int H, int W, int C, void *y, int y_dtype, void *stream);
+                      int H, int W, int C, void *y, int y_dtype, const int *identity_if_zero, void *stream);
 int dsw_dwconv3x3_bwd_blocks(int B, int H, int W);
 int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype, const float *weight,
                       int B, int H, int W, int C, void *dx, int dx_dtype, float *d_weight,

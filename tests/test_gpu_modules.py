@@ -305,3 +305,32 @@ def test_vitblock_prenorm_gradient_sink(cuda0, autocast):
     tol = 2e-2 if autocast else 1e-5
     for k in res[1]:
         assert rel_err(res[0][k], res[1][k]) < tol, k
+
+
+@pytest.mark.parametrize("gates", ["mixed", "closed"])
+def test_dsmsa_static_inference(cuda0, gates):
+    """Inference without the host read of the pass count: same values as the path that reads it, also when
+    no window passes (the module then returns its input)."""
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    torch.manual_seed(5)
+    mod = DeformableSparseWindowAttention(16, 180, 6).to(cuda0).eval()
+    with torch.no_grad():
+        mod.sparse_discriminator[4].weight.mul_(8.0)
+        mod.sparse_discriminator[4].bias[1] += -30.0 if gates == "closed" else 0.3
+        mod.pe.relative_position_bias_table.normal_(0, 0.5)
+    x = torch.randn(3, 64, 48, 180, device=cuda0)
+    outs = []
+    for static in (False, True):
+        mod.static_inference = static
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            outs.append(mod(x).float())
+        sel = mod.last_selection
+        if static:
+            n_pass = int(sel.n_dev.item())
+            assert sel.n == 3 * 3 and n_pass == n_dyn
+        else:
+            n_dyn = 0 if sel is None else sel.n
+    assert (n_dyn == 0) == (gates == "closed")
+    if gates == "mixed":
+        assert 0 < n_dyn < 9
+    assert rel_err(outs[1], outs[0]) < (1e-6 if gates == "mixed" else 1e-2)   # closed: bf16 copy of x against x

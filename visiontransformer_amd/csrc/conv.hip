@@ -43,7 +43,11 @@ constexpr int CW_ROWS = 8;
 template <typename TI, typename TO, bool FLIP>
 __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__restrict__ x, const float *__restrict__ wgt,
                                                                    const float *__restrict__ bias, int H, int W, int C,
-                                                                   int segs, TO *__restrict__ y) {
+                                                                   int segs, TO *__restrict__ y, const int *__restrict__ identity_if_zero) {
+    // identity_if_zero: a device counter; when it holds 0 the kernel copies its input instead of convolving
+    // (DS-MSA returns its input untouched when no window passed the gate, DSwinT_arch.py:291-292, and this
+    // lets a caller that never reads the count on the host keep that behaviour)
+    const bool ident = identity_if_zero != nullptr && *identity_if_zero == 0;
     extern __shared__ __attribute__((aligned(16))) float ws[];  // [9][C] + [C]
     for (int i = threadIdx.x; i < C * 9; i += CV_THREADS) {
         const int c = i / 9, t = i - c * 9;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
             acc = fma4(r1[bb], wq[3 + bb], acc);
             acc = fma4(r2[bb], wq[6 + bb], acc);
         }
-        io<TO>::st4(dst + (size_t)h * rs, acc);
+        io<TO>::st4(dst + (size_t)h * rs, ident ? r1[1] : acc);
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb) r0[bb] = r1[bb], r1[bb] = r2[bb];
     }
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(256) void sd_gather_bwd_kernel(const float *__restr
 using namespace dsw;
 
 extern "C" int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
-                                 int C, void *y, int y_dtype, void *stream) {
+                                 int C, void *y, int y_dtype, const int *identity_if_zero, void *stream) {
     int rc = check_conv("dsw_dwconv3x3_fwd", B, H, W, C);
     if (rc) return rc;
     DSW_REQUIRE(x && weight && y, "dsw_dwconv3x3_fwd: null pointer");
@@ -699,7 +703,7 @@ extern "C" int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight
     const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(x_dtype, TI, DSW_DISPATCH_DTYPE(y_dtype, TO, {
         hipLaunchKernelGGL((dwconv_stream_kernel<TI, TO, false>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds,
-                           as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, (TO *)y);
+                           as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, (TO *)y, identity_if_zero);
     }));
     return check_launch("dwconv_stream_kernel");
 }
@@ -720,7 +724,7 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
     const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
         hipLaunchKernelGGL((dwconv_stream_kernel<TG, TO, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds, st,
-                           (const TG *)dy, weight, (const float *)nullptr, H, W, C, segs, (TO *)dx);
+                           (const TG *)dy, weight, (const float *)nullptr, H, W, C, segs, (TO *)dx, (const int *)nullptr);
     }));
     rc = check_launch("dwconv_stream_kernel<flip>");
     if (rc) return rc;

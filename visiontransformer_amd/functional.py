@@ -39,6 +39,7 @@ class Selection:
     cand_idx: torch.Tensor
     cand_pass: torch.Tensor
     probs: torch.Tensor
+    n_dev: torch.Tensor = None   # static selection only: the number of passing windows, int32 [1] on the device
 
 
 class _SelectFn(torch.autograd.Function):
@@ -110,6 +111,38 @@ def select_windows(sd, sig, noise, tau, k, w, H, W):
     return Selection(n=win_b.numel(), win_b=win_b, win_cell=win_cell, win_h1=win_h1, win_w1=win_w1,
                      cellmap=cellmap, scores_delta=sdl, gates_delta=gdl, cand_idx=cand_idx,
                      cand_pass=cand_pass, probs=probs)
+
+
+def select_windows_static(sd, noise, tau, k, w, H, W):
+    """select_windows without the host read of the number of passing windows, for inference: every
+    candidate gets a window slot (B * k of them); the slots behind the passing ones hold a harmless
+    window (image 0, corner 0,0) that the cell map never points to, so the gather / attention /
+    projections run on all slots and the scatter writes back only the passing ones.  Selection.n_dev is
+    the pass count on the device."""
+    _lib.require_cuda(sd, noise)
+    B, four, Hw, Ww = sd.shape
+    assert four == 4
+    sd = sd.contiguous()
+    n = Hw * Ww
+    dev = sd.device
+    if noise is not None:
+        noise = noise.to(torch.float32).contiguous()
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    probs = torch.empty(B, n, **f32)
+    cand_idx = torch.empty(B, k, **i32)
+    cand_p = torch.empty(B, k, **f32)
+    cand_pass = torch.empty(B, k, **i32)
+    n_pass = torch.empty(1, **i32)
+    win = torch.zeros(4, B * k, **i32)
+    deltas = torch.zeros(2, B * k, **f32)
+    cellmap = torch.empty(B, Hw, Ww, **i32)
+    call("dsw_select_fwd", ptr(sd), None, dtype_code(sd.dtype), ptr(noise), _c_float(tau), B, Hw, Ww, k, w, H, W, ptr(probs),
+         ptr(cand_idx), ptr(cand_p), ptr(cand_pass), ptr(n_pass), ptr(win[0]), ptr(win[1]), ptr(win[2]), ptr(win[3]),
+         ptr(deltas[0]), ptr(deltas[1]), ptr(cellmap), stream(dev))
+    return Selection(n=B * k, win_b=win[0], win_cell=win[1], win_h1=win[2], win_w1=win[3], cellmap=cellmap,
+                     scores_delta=deltas[0], gates_delta=deltas[1], cand_idx=cand_idx, cand_pass=cand_pass, probs=probs,
+                     n_dev=n_pass)
 
 
 class GradSink:
@@ -434,7 +467,7 @@ def unshuffle_nhwc(x, scale=1):
 # ---------------------------------------------------------------------------------------------
 class _DWConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, out_dtype):
+    def forward(ctx, x, weight, bias, out_dtype, identity_if_zero=None):
         _lib.require_cuda(x)
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -442,7 +475,7 @@ class _DWConvFn(torch.autograd.Function):
         b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
         y = torch.empty(B, H, W, C, dtype=out_dtype, device=x.device)
         call("dsw_dwconv3x3_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(y),
-             dtype_code(out_dtype), stream(x.device))
+             dtype_code(out_dtype), None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
         ctx.save_for_backward(x, w32)
         ctx.meta = (weight.shape, weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -461,13 +494,16 @@ class _DWConvFn(torch.autograd.Function):
         partial = torch.empty((nblk + 1) * C * 10, dtype=torch.float32, device=dev)
         call("dsw_dwconv3x3_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype), ptr(w32), B, H, W, C,
              ptr(dx), dtype_code(dx.dtype), ptr(dw), ptr(db), ptr(partial), stream(dev))
-        return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), None
+        return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), None, None
 
 
-def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None):
+def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None, identity_if_zero=None):
     """Depthwise 3x3 conv, stride 1, zero padding 1, on an NHWC tensor (out_conv of DS-MSA,
-    DSwinT_arch.py:198, :317).  weight [C,1,3,3]."""
-    return _DWConvFn.apply(x, weight, bias, out_dtype or x.dtype)
+    DSwinT_arch.py:198, :317).  weight [C,1,3,3].  identity_if_zero: an int32 device counter; the result
+    is x itself (cast) when it holds 0 (inference only: the backward does not look at it)."""
+    if identity_if_zero is not None and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        raise RuntimeError("dwconv3x3_nhwc: identity_if_zero is for inference")
+    return _DWConvFn.apply(x, weight, bias, out_dtype or x.dtype, identity_if_zero)
 
 
 class _SparseDiscFn(torch.autograd.Function):
