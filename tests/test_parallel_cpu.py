@@ -45,6 +45,50 @@ def test_plan_tiles_cover_the_image_once():
     assert len(tiles) == 3 * 2
 
 
+def test_plan_tiles_rectangular_clipped():
+    H, W = 70, 45
+    cover = torch.zeros(H, W, dtype=torch.int32)
+    tiles = parallel.plan_tiles(H, W, tile=(48, 16), halo=4, clip=True)
+    assert len(tiles) == 2 * 3
+    for t in tiles:
+        cover[t.y0:t.y1, t.x0:t.x1] += 1
+        assert t.py0 == max(t.y0 - 4, 0) and t.py1 == min(t.y1 + 4, H)
+        assert t.px0 == max(t.x0 - 4, 0) and t.px1 == min(t.x1 + 4, W)
+    assert int(cover.min()) == 1 and int(cover.max()) == 1
+
+
+def test_balanced_grid():
+    # one rank, image within the limit: a single tile = whole-image inference
+    assert parallel.balanced_grid(540, 960, 1) == (544, 960)
+    assert len(parallel.plan_tiles(540, 960, (544, 960), 32, clip=True)) == 1
+    for world in (2, 4, 8):
+        th, tw = parallel.balanced_grid(540, 960, world)
+        assert th % 16 == 0 and tw % 16 == 0
+        tiles = parallel.plan_tiles(540, 960, (th, tw), 32, clip=True)
+        assert len(tiles) % world == 0
+        assert max(max(t.py1 - t.py0, t.px1 - t.px0) for t in tiles) <= 1024
+    # the side limit forces more tiles
+    th, tw = parallel.balanced_grid(540, 960, 1, max_side=320)
+    assert max(th, tw) + 64 <= 320 + 64 and len(parallel.plan_tiles(540, 960, (th, tw), 32, clip=True)) >= 8
+    with pytest.raises(ValueError):
+        parallel.balanced_grid(64, 64, 3, max_side=16, halo=32)
+
+
+def test_balanced_tiling_matches_whole_image_everywhere():
+    """clipped halo: border tiles see the image border as whole-image inference does, so with
+    halo >= receptive-field radius the tiled result is exact everywhere"""
+    model = _ToySR().eval()
+    lr = torch.randn(1, 3, 40, 52)
+    full = model(lr)
+    one = parallel.tiled_super_resolve(model, lr, 2, tile="balanced", halo=4)
+    assert torch.allclose(one, full, atol=1e-6)
+    parts = sum(parallel.tiled_super_resolve(model, lr, 2, tile="balanced", halo=4, rank=r, world=4, reduce=False)
+                for r in range(4))
+    assert torch.allclose(parts, full, atol=1e-6)
+    tiled = parallel.tiled_super_resolve(model, lr, 2, tile=(16, 32), halo=4, clip=True)
+    assert torch.allclose(tiled, full, atol=1e-6)
+
+
 def test_reflect_crop_matches_padding():
     img = torch.arange(2 * 3 * 6 * 7, dtype=torch.float32).view(2, 3, 6, 7)
     ref = torch.nn.functional.pad(img, (3, 3, 3, 3), mode="reflect")

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Measurements beyond the driver's bench line (one MI355X, synthetic data):
 
-  D  DSWT default model, x4 SR of one 960x540 LR image (-> 3840x2160), tiles of 256x256 LR + 32 px
-     halo, eval mode, bf16 autocast: output megapixels / s.
+  D  DSWT default model, x4 SR of one 960x540 LR image (-> 3840x2160), eval mode, bf16 autocast:
+     output megapixels / s with the balanced tile plan (one tile on one GPU), with tiles of
+     256x256 LR + 32 px halo, and the busiest rank's share of the 2 / 4 / 8 rank plans.
   E  config B with num_win_selected 0.5 / 1.0 (256 / 512 windows of 16x16, gates open, random
      offsets): gather / scatter kernels against the HBM roofline.
   C  MSFT (dim 192, levels 2, w 8), x4 training step (fwd + bwd, bf16 autocast) on 64x64 patches,
@@ -35,23 +36,35 @@ def sync_time(fn, iters, warm=1):
 
 def workload_d(dev):
     from visiontransformer_amd.models import DSWT_DEFAULT, dswt_from_config
-    from visiontransformer_amd.parallel import plan_tiles, tiled_super_resolve
+    from visiontransformer_amd.parallel import balanced_grid, plan_tiles, tiled_super_resolve
     torch.manual_seed(0)
     model = dswt_from_config(DSWT_DEFAULT).to(dev).eval()
     g = torch.Generator(device=dev).manual_seed(0)
     lr = (torch.randn(1, 3, 540, 960, device=dev, generator=g) * 0.5).clamp_(-1, 1)
 
-    def run():
+    def run(tile, rank=0, world=1, **kw):
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-            return tiled_super_resolve(model, lr, 4, tile=256, halo=32)
+            return tiled_super_resolve(model, lr, 4, tile=tile, halo=32, rank=rank, world=world, reduce=False, **kw)
 
-    out = run()
+    out = run("balanced")
     assert out.shape == (1, 3, 2160, 3840) and torch.isfinite(out).all()
-    dt = sync_time(run, 3)
-    return {"metric": "x4 SR output megapixels/sec (fwd)", "value": out.shape[2] * out.shape[3] / 1e6 / dt, "unit": "MP/s",
+    mp = out.shape[2] * out.shape[3] / 1e6
+    dt = sync_time(lambda: run("balanced"), 3)
+    dt256 = sync_time(lambda: run(256), 3)
+    # the busiest rank's share of the balanced plan for 2 / 4 / 8 ranks, timed on this one GPU: the
+    # per-image time of an N-GPU run before its one final reduction
+    shares = {}
+    for w in (2, 4, 8):
+        grid = balanced_grid(540, 960, w)
+        shares[str(w)] = {"core": list(grid), "tiles": len(plan_tiles(540, 960, grid, 32, True)),
+                          "rank0_s": sync_time(lambda: run("balanced", 0, w), 3)}
+    grid = balanced_grid(540, 960, 1)
+    return {"metric": "x4 SR output megapixels/sec (fwd)", "value": mp / dt, "unit": "MP/s",
             "n_gpus": 1, "s_per_image": dt, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "D: DSWT default (14.6 M params), 960x540 LR -> 3840x2160, %d tiles of 256x256 LR + 32 px halo"
-                                   % len(plan_tiles(540, 960, 256, 32))}}
+            "config": {"workload": "D: DSWT default (14.6 M params), 960x540 LR -> 3840x2160, balanced plan: %d tile(s) of %dx%d LR, "
+                                   "halo 32 clipped at the image border" % (len(plan_tiles(540, 960, grid, 32, True)), grid[0], grid[1])},
+            "tiles_256_halo_32": {"tiles": len(plan_tiles(540, 960, 256, 32)), "s_per_image": dt256, "MP/s": mp / dt256},
+            "rank0_share_by_world": shares}
 
 
 def workload_e(dev):

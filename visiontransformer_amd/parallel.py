@@ -63,14 +63,51 @@ class Tile:
     px1: int
 
 
-def plan_tiles(H, W, tile=256, halo=32) -> List[Tile]:
-    """Row-major list of tiles covering an H x W image; every core is at most tile x tile."""
+def plan_tiles(H, W, tile=256, halo=32, clip=False) -> List[Tile]:
+    """Row-major list of tiles covering an H x W image; every core is at most tile x tile
+    (tile: an int or (rows, columns)).  clip=True keeps the halo inside the image, so a tile at the
+    border sees the border as whole-image inference does instead of a reflected halo."""
+    th, tw = (tile, tile) if isinstance(tile, int) else tile
     tiles = []
-    for y0 in range(0, H, tile):
-        for x0 in range(0, W, tile):
-            y1, x1 = min(y0 + tile, H), min(x0 + tile, W)
-            tiles.append(Tile(y0, y1, x0, x1, y0 - halo, y1 + halo, x0 - halo, x1 + halo))
+    for y0 in range(0, H, th):
+        for x0 in range(0, W, tw):
+            y1, x1 = min(y0 + th, H), min(x0 + tw, W)
+            py0, py1, px0, px1 = y0 - halo, y1 + halo, x0 - halo, x1 + halo
+            if clip:
+                py0, py1, px0, px1 = max(py0, 0), min(py1, H), max(px0, 0), min(px1, W)
+            tiles.append(Tile(y0, y1, x0, x1, py0, py1, px0, px1))
     return tiles
+
+
+def balanced_grid(H, W, world=1, max_side=1024, halo=32, align=16):
+    """Core size (rows, columns) of the cheapest tiling of an H x W image whose tile count is a
+    multiple of `world` (every rank gets the same number of tiles) with padded tiles (core + halo
+    clipped at the image border) of at most max_side a side.  Cost = padded pixels computed by the
+    busiest rank; cores are multiples of `align` (the window size) so that only the last row and
+    column of tiles need the model's own padding.  world = 1 and a small enough image give a
+    single tile: whole-image inference, as toolkit/model_helper2.py:167-191 runs it."""
+    up = lambda v: -(-v // align) * align
+    best = None
+    for ny in range(1, -(-H // align) + 1):
+        th = up(-(-H // ny))
+        if -(-H // th) != ny:
+            continue
+        for nx in range(1, -(-W // align) + 1):
+            tw = up(-(-W // nx))
+            if -(-W // tw) != nx or (ny * nx) % world:
+                continue
+            tiles = plan_tiles(H, W, (th, tw), halo, clip=True)
+            if max(max(t.py1 - t.py0, t.px1 - t.px0) for t in tiles) > max_side:
+                continue
+            load = [0] * world
+            for i, t in enumerate(tiles):
+                load[i % world] += up(t.py1 - t.py0) * up(t.px1 - t.px0)
+            cost = (max(load), ny * nx)
+            if best is None or cost < best[0]:
+                best = (cost, (th, tw))
+    if best is None:
+        raise ValueError("no tiling of %dx%d into a multiple of %d tiles of at most %d a side" % (H, W, world, max_side))
+    return best[1]
 
 
 def _reflect_crop(img, py0, py1, px0, px1):
@@ -91,13 +128,17 @@ def _reflect_crop(img, py0, py1, px0, px1):
 
 
 @torch.no_grad()
-def tiled_super_resolve(model, lr, scale, tile=256, halo=32, rank=0, world=1, reduce=True):
+def tiled_super_resolve(model, lr, scale, tile=256, halo=32, rank=0, world=1, reduce=True, clip=False):
     """x`scale` super-resolution of lr [B,3,H,W] by tiles with halo.  Rank r computes tiles
     r, r + world, ...; with reduce=True the disjoint output regions are summed over the group so
-    every rank returns the whole image (a single collective, after all compute)."""
+    every rank returns the whole image (a single collective, after all compute).
+    tile="balanced" takes the tiling of balanced_grid for this image and world size (halo clipped
+    at the image border); otherwise tile / clip are passed to plan_tiles."""
     B, C, H, W = lr.shape
     out = torch.zeros(B, C, H * scale, W * scale, dtype=lr.dtype, device=lr.device)
-    for i, t in enumerate(plan_tiles(H, W, tile, halo)):
+    if tile == "balanced":
+        tile, clip = balanced_grid(H, W, world, halo=halo), True
+    for i, t in enumerate(plan_tiles(H, W, tile, halo, clip)):
         if i % world != rank:
             continue
         patch = _reflect_crop(lr, t.py0, t.py1, t.px0, t.px1)
