@@ -57,7 +57,7 @@ def workload_d(dev):
     for w in (2, 4, 8):
         grid = balanced_grid(540, 960, w)
         shares[str(w)] = {"core": list(grid), "tiles": len(plan_tiles(540, 960, grid, 32, True)),
-                          "rank0_s": sync_time(lambda: run("balanced", 0, w), 3)}
+                          "rank0_s": sync_time(lambda: run("balanced", 0, w), 5, warm=3)}
     grid = balanced_grid(540, 960, 1)
     return {"metric": "x4 SR output megapixels/sec (fwd)", "value": mp / dt, "unit": "MP/s",
             "n_gpus": 1, "s_per_image": dt, "dtype": "bf16", "data": "synthetic",
