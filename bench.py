@@ -18,6 +18,8 @@ The JSON line also carries
   roofline     - the dominant kernel (fused window-attention backward at the WMSA shape),
                  algorithmic FLOPs / its measured launch time against the dense bf16 MFMA peak;
   kernels      - the same measurement for every kernel of the path (GB/s or TFLOP/s);
+  sr_inference - the other half of the headline metric: x4 super-resolution of a 960x540 frame by the whole
+                 DSWT network, tiles sharded over the ranks (strong scaling), output megapixels / s;
   cpu_baseline - the CPU oracle (a PyTorch restatement of the reference) timed on this host's
                  cores on a bounded sample of the same workload (N = 1 only).
 """
@@ -254,6 +256,50 @@ def cpu_baseline(sample_batch=8, budget_s=15.0):
                        "fwd+bwd, batch %d of 64x64x180, %d iters, %.2f s/iter" % (sample_batch, iters, dt))
 
 
+SR_LR = (540, 960)  # x4 -> 3840 x 2160
+
+
+def sr_inference(device, rank, world, iters=3):
+    """x4 super-resolution of one 960x540 frame by the DSWT default network (eval, bf16 autocast), the frame
+    cut into the balanced tile plan for `world` ranks (one rank: the whole frame as one tile), every
+    rank computing its tiles and one all-reduce assembling the image: output megapixels / s over
+    the whole job (strong scaling: the frame is fixed).  Time = max over ranks, barriers both sides."""
+    import torch.distributed as dist
+    from visiontransformer_amd.models import DSWT_DEFAULT, dswt_from_config
+    from visiontransformer_amd.parallel import balanced_grid, plan_tiles, tiled_super_resolve
+    torch.manual_seed(0)
+    model = dswt_from_config(DSWT_DEFAULT).to(device).eval()
+    gen = torch.Generator(device=device).manual_seed(7)
+    lr = torch.rand(1, 3, *SR_LR, device=device, generator=gen)
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return tiled_super_resolve(model, lr, 4, tile="balanced", halo=32, rank=rank, world=world, reduce=world > 1)
+
+    out = run()
+    ok = bool(torch.isfinite(out).all())
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / iters
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    grid = balanced_grid(SR_LR[0], SR_LR[1], world)
+    return {"metric": "x4 SR output megapixels/sec (fwd)", "value": out.shape[2] * out.shape[3] / 1e6 / dt, "unit": "MP/s",
+            "n_gpus": world, "s_per_image": dt, "scaling": "strong", "dtype": "bf16", "data": "synthetic", "finite": ok,
+            "config": {"workload": "D: DSWT default (14.6 M params), 960x540 LR -> 3840x2160, %d tile(s) of %dx%d LR + 32 px halo "
+                                   "clipped at the frame border, tiles round-robin over %d rank(s), one all-reduce of the image"
+                                   % (len(plan_tiles(SR_LR[0], SR_LR[1], grid, 32, True)), grid[0], grid[1], world)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +307,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--pmc-target", action="store_true",
                     help="launch every kernel of the path twice at the bench shapes and exit (the "
                          "program rocprofv3 --pmc passes run; see tools/pmc_summary.py)")
@@ -316,6 +363,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_pass = pair.sdwa.last_selection.n if pair.sdwa.last_selection is not None else 0
+    # second half of the headline metric, outside the timed training region: all ranks take part
+    sr = None if args.no_inference else sr_inference(device, rank, world)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -345,6 +394,8 @@ def main():
                                 "traffic": pmc_traffic("win_attn_bwd_kernel<unsigned short, 16, 32, true, true>"),
                                 "us_per_launch": dom["us"]}
             line["kernels"] = ks
+        if sr is not None:
+            line["sr_inference"] = sr
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -120,6 +120,9 @@ def _worker(rank, world, port, q):
     out = parallel.tiled_super_resolve(model, lr, 2, tile=16, halo=4, rank=r, world=w)
     ref = parallel.tiled_super_resolve(model, lr, 2, tile=16, halo=4)
     ok_tiles = torch.allclose(out, ref, atol=1e-6)
+    # the balanced plan for this world size, halo clipped at the border: equal to whole-image inference
+    bal = parallel.tiled_super_resolve(model, lr, 2, tile="balanced", halo=4, rank=r, world=w)
+    ok_tiles = ok_tiles and torch.allclose(bal, model(lr), atol=1e-6)
     # (2) data parallel: per-rank batches, gradients averaged over the group
     net = parallel.data_parallel(_ToySR(), dev)
     gen2 = torch.Generator().manual_seed(100 + r)
