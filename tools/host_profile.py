@@ -1,41 +1,27 @@
 #!/usr/bin/env python3
-"""cProfile of the bench step's host side (where does the Python / launch time go)."""
-import cProfile, pstats, sys, os, io, time
+"""Host-side cost of one DSWT x4 inference forward on a small tile (where the launch rate, not the GPU,
+bounds the time): cProfile over a few forwards, top functions by own time."""
+import cProfile, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import bench
-
-dev = torch.device("cuda:0")
 from visiontransformer_amd import _lib
-_lib.load()
-model = bench.build_pair(dev)
-gen = torch.Generator(device=dev).manual_seed(100)
-x = torch.randn(bench.B_PER_GPU, bench.HW, bench.HW, bench.C, device=dev, generator=gen).requires_grad_()
-model.sdwa.gumbel_noise = -torch.empty(bench.B_PER_GPU, 16, device=dev).exponential_(generator=gen).log()
+from visiontransformer_amd.models import DSWT_DEFAULT, dswt_from_config
 
-def step():
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        y = model(x)
-    y.float().sum().backward()
-    model.zero_grad(set_to_none=True)
-    x.grad = None
+dev = torch.device("cuda:0"); _lib.load()
+torch.manual_seed(0)
+m = dswt_from_config(DSWT_DEFAULT).to(dev).eval()
+H, W = (int(a) for a in (sys.argv[1:3] if len(sys.argv) > 2 else (304, 272)))
+x = torch.rand(1, 3, H, W, device=dev)
 
-for _ in range(5):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(20):
-    step()
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print("host enqueue %.3f ms/step, with final sync %.3f ms/step" % ((t1 - t0) / 20 * 1e3, (t2 - t0) / 20 * 1e3))
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(20):
-    step()
-pr.disable()
-torch.cuda.synchronize()
-s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
-print(s.getvalue()[:6000])
+
+def run(n):
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for _ in range(n):
+            m(x)
+
+
+run(3); torch.cuda.synchronize()
+t0 = time.perf_counter(); run(5); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print("per forward: host %.2f ms, host+drain %.2f ms" % ((t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
+pr = cProfile.Profile(); pr.enable(); run(5); pr.disable(); torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(int(os.environ.get("ROWS", "45")))

@@ -4,6 +4,7 @@ Each Function allocates its outputs with torch (so memory stays in the caching a
 passes raw device pointers and the current HIP stream to the library, and saves for backward
 exactly what the backward kernels read.  Nothing here computes on the CPU.
 """
+import contextlib
 import ctypes
 import weakref
 from dataclasses import dataclass
@@ -15,6 +16,44 @@ from ._lib import call, dtype_code, ptr, stream
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
+
+
+class _NoGradCtx:
+    """Stand-in for the autograd context when gradients are disabled: nothing is saved, nothing needs a
+    gradient.  Calling Function.forward with it skips the dispatch cost of Function.apply, which at a few
+    hundred small launches per inference forward is a measurable part of the host time."""
+
+    class _Never:
+        def __getitem__(self, i):
+            return (False,) * 16 if isinstance(i, slice) else False
+
+        def __iter__(self):
+            return iter(())
+
+    needs_input_grad = _Never()
+
+    def __setattr__(self, name, value):
+        pass
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, flag):
+        pass
+
+
+_NO_GRAD = _NoGradCtx()
+_NULL_CTX = contextlib.nullcontext()
+
+
+def _run(fn, *args):
+    """fn.apply(*args); without autograd, fn.forward directly"""
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_NO_GRAD, *args)
 
 
 @dataclass
@@ -106,7 +145,7 @@ class _SelectFn(torch.autograd.Function):
 def select_windows(sd, sig, noise, tau, k, w, H, W):
     """Top-k + hard gate + compaction + corners (DSwinT_arch.py:201-237, :280-295).  sig =
     sd[:, 1:].sigmoid(), or None to have the kernels take the sigmoids themselves."""
-    out = _SelectFn.apply(sd, sig, noise, float(tau), int(k), int(w), int(H), int(W))
+    out = _run(_SelectFn, sd, sig, noise, float(tau), int(k), int(w), int(H), int(W))
     sdl, gdl, win_b, win_cell, win_h1, win_w1, cellmap, cand_idx, cand_pass, probs = out
     return Selection(n=win_b.numel(), win_b=win_b, win_cell=win_cell, win_h1=win_h1, win_w1=win_w1,
                      cellmap=cellmap, scores_delta=sdl, gates_delta=gdl, cand_idx=cand_idx,
@@ -217,7 +256,7 @@ def gather_windows(x, sel, w, out_dtype=None, sink=None, pad_out=False):
     """roi_align of the selected windows straight from NHWC to [n, w*w, C]
     (DSwinT_arch.py:259, :297, :303).  `sink`: see GradSink.  pad_out: the result is a view of the
     first C columns of rows padded (with zeros) to a multiple of 64 elements."""
-    return _GatherFn.apply(x, sel.win_b, sel.win_h1, sel.win_w1, sel.cellmap, int(w), out_dtype or x.dtype, sink,
+    return _run(_GatherFn, x, sel.win_b, sel.win_h1, sel.win_w1, sel.cellmap, int(w), out_dtype or x.dtype, sink,
                            bool(pad_out))
 
 
@@ -267,7 +306,7 @@ class _ScatterMeanFn(torch.autograd.Function):
 def scatter_mean_residual(x, after, sel, w, sink=None):
     """x + mean over covering windows of (after - roi_align(x)) * gates * scores
     (DSwinT_arch.py:308-315), NHWC in and out.  `sink`: see GradSink."""
-    return _ScatterMeanFn.apply(x, after, sel.gates_delta, sel.scores_delta, sel.cellmap, sel.win_b,
+    return _run(_ScatterMeanFn, x, after, sel.gates_delta, sel.scores_delta, sel.cellmap, sel.win_b,
                                 sel.win_h1, sel.win_w1, int(w), sink)
 
 
@@ -371,7 +410,7 @@ def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w
         n_img, H, W = qkv.shape[0], 0, 0
     else:
         n_img, H, W = grid
-    return _WinAttnFn.apply(qkv, table, lepe_w, lepe_b, int(layout), int(n_img), int(H), int(W), int(w),
+    return _run(_WinAttnFn, qkv, table, lepe_w, lepe_b, int(layout), int(n_img), int(H), int(W), int(w),
                             int(heads), float(scale), bool(pad_out))
 
 
@@ -416,7 +455,7 @@ class _UnshuffleLNFn(torch.autograd.Function):
 def unshuffle_nhwc_layernorm(x, gamma, beta, scale=1, eps=1e-5, out_dtype=None):
     """PixelUnshuffle(scale) + NCHW->NHWC + LayerNorm over channels in one pass
     (msft_arch.py:45-50; scale=1: :68-70 and :160-162).  x [B,c,H,W] -> [B,H/s,W/s,c*s*s]."""
-    return _UnshuffleLNFn.apply(x, gamma, beta, int(scale), float(eps), out_dtype or x.dtype)
+    return _run(_UnshuffleLNFn, x, gamma, beta, int(scale), float(eps), out_dtype or x.dtype)
 
 
 class _ShuffleFn(torch.autograd.Function):
@@ -454,12 +493,12 @@ class _UnshuffleFn(torch.autograd.Function):
 def shuffle_nchw(t, scale=1):
     """NHWC->NCHW + PixelShuffle(scale) in one pass (msft_arch.py:54, :74-76, :166).
     t [B,H,W,C] -> [B,C/s^2,H*s,W*s]."""
-    return _ShuffleFn.apply(t, int(scale))
+    return _run(_ShuffleFn, t, int(scale))
 
 
 def unshuffle_nhwc(x, scale=1):
     """PixelUnshuffle(scale) + NCHW->NHWC in one pass.  x [B,c,H,W] -> [B,H/s,W/s,c*s*s]."""
-    return _UnshuffleFn.apply(x, int(scale))
+    return _run(_UnshuffleFn, x, int(scale))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -503,7 +542,7 @@ def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None, identity_if_zero=None):
     is x itself (cast) when it holds 0 (inference only: the backward does not look at it)."""
     if identity_if_zero is not None and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
         raise RuntimeError("dwconv3x3_nhwc: identity_if_zero is for inference")
-    return _DWConvFn.apply(x, weight, bias, out_dtype or x.dtype, identity_if_zero)
+    return _run(_DWConvFn, x, weight, bias, out_dtype or x.dtype, identity_if_zero)
 
 
 class _SparseDiscFn(torch.autograd.Function):
@@ -597,7 +636,7 @@ def sparse_discriminator_nhwc(x, convs, w, out_dtype=None, sink=None):
     stride w + SiLU + conv 4->4 3x3 (DSwinT_arch.py:180-186, :266).  `convs` = the three Conv2d
     modules; returns sd [B,4,H/w,W/w]."""
     c0, c2, c4 = convs
-    return _SparseDiscFn.apply(x, c0.weight, c0.bias, c2.weight, c2.bias, c4.weight, c4.bias, int(w),
+    return _run(_SparseDiscFn, x, c0.weight, c0.bias, c2.weight, c2.bias, c4.weight, c4.bias, int(w),
                                out_dtype or x.dtype, sink)
 
 
@@ -760,15 +799,16 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act_dtype, pad_out):
         N, Kd = weight.shape
-        with torch.autocast("cuda", enabled=False):
-            x2 = x.reshape(-1, Kd)
-            T = x2.shape[0]
+        x2 = x.reshape(-1, Kd)
+        T = x2.shape[0]
+        mfma = (act_dtype == torch.bfloat16 and x2.is_cuda and T > 0 and N % 4 == 0 and weight.is_contiguous()
+                and weight.dtype in (torch.float32, torch.bfloat16) and weight.data_ptr() % 16 == 0)
+        # only the stock-GEMM branch calls ops that autocast would intercept
+        with (_NULL_CTX if mfma else torch.autocast("cuda", enabled=False)):
             xk = _padded_rows(x2, act_dtype)
             PAD_STATS["taken" if xk is not None else "copied"] += 1
             Np, Kp = _ceil_pad(N), _ceil_pad(Kd)
             Nout = Np if pad_out else N
-            mfma = (act_dtype == torch.bfloat16 and x2.is_cuda and T > 0 and N % 4 == 0 and weight.is_contiguous()
-                    and weight.dtype in (torch.float32, torch.bfloat16) and weight.data_ptr() % 16 == 0)
             if mfma:
                 b32 = None if bias is None else bias.detach().float().contiguous()
                 w_p, w_pt = _weight_operands(weight)
@@ -884,7 +924,7 @@ def linear(x, lin, pad_out=False):
     the result in rows padded to a multiple of 64 elements (returned as a view of the first
     out_features columns); for callers whose consumers accept such views."""
     act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-    return _LinearFn.apply(x, lin.weight, lin.bias, act, bool(pad_out))
+    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -952,7 +992,7 @@ def rms_norm(x, norm, for_projection=False, sink=None):
     eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
     act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
     to_act = for_projection and act == torch.bfloat16
-    return _RMSNormFn.apply(x, norm.weight, eps, act if to_act else torch.float32, to_act, sink)
+    return _run(_RMSNormFn, x, norm.weight, eps, act if to_act else torch.float32, to_act, sink)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -990,7 +1030,7 @@ def gated_silu(h, pad_out=False):
     H = h.shape[-1] // 2
     if not (h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[-1] == 2 * H and H % 4 == 0):
         return torch.nn.functional.silu(h[..., :H]) * h[..., H:]
-    return _GatedSiluFn.apply(h, H, bool(pad_out))
+    return _run(_GatedSiluFn, h, H, bool(pad_out))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1045,7 +1085,7 @@ def rezero_residual(x, r, branch, sink=None):
     if not ok:
         assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
         return torch.addcmul(x, r, branch)
-    return _RezeroFn.apply(x, r, branch, sink)
+    return _run(_RezeroFn, x, r, branch, sink)
 
 
 def prenorm_sink(x, norm, r):
@@ -1161,7 +1201,7 @@ def conv3x3_nhwc(x, conv):
           and B * H * W * max(_ceil_pad(Ci), _ceil_pad(conv.out_channels)) * 4 < 2 ** 31)
     if not ok:
         return None
-    return _Conv3x3Fn.apply(x.contiguous(), conv.weight, conv.bias, act)
+    return _run(_Conv3x3Fn, x.contiguous(), conv.weight, conv.bias, act)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1215,4 +1255,4 @@ def layer_norm(x, norm, for_projection=False):
         return norm(x)
     act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
     to_act = for_projection and act == torch.bfloat16
-    return _LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps, act if to_act else torch.float32, to_act)
+    return _run(_LayerNormFn, x, norm.weight, norm.bias, norm.eps, act if to_act else torch.float32, to_act)
