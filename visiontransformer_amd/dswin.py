@@ -191,7 +191,7 @@ class DeformableSparseWindowAttention(WindowedAttention):
         noise = self._noise(sd[:, 0].reshape(B, -1))
         if self.static_inference and not torch.is_grad_enabled() and not self.use_torch_convs:
             sel = K.select_windows_static(sd, noise, self.temperature, k, w, H, W)
-            self.last_selection = sel
+            self.last_selection = sel.detached()
             before = K.gather_windows(x, sel, w, out_dtype=act, pad_out=True)
             qkv = K.linear(before, self.in_proj, pad_out=True)
             z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
@@ -200,7 +200,7 @@ class DeformableSparseWindowAttention(WindowedAttention):
             # no window passed (DSwinT_arch.py:291-292: return x): the last kernel copies instead of convolving
             return K.dwconv3x3_nhwc(y, self.out_conv.weight, self.out_conv.bias, out_dtype=act, identity_if_zero=sel.n_dev)
         sel = K.select_windows(sd, None, noise, self.temperature, k, w, H, W)  # sigmoids taken in the kernels
-        self.last_selection = sel
+        self.last_selection = sel.detached()
         if sel.n == 0:  # DSwinT_arch.py:291-292
             if sink is not None:
                 sink.expected = 1  # only the sparse discriminator saw x

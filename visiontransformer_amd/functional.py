@@ -80,6 +80,11 @@ class Selection:
     probs: torch.Tensor
     n_dev: torch.Tensor = None   # static selection only: the number of passing windows, int32 [1] on the device
 
+    def detached(self):
+        """the same record without autograd history: what a module may keep as an attribute (a tensor with a
+        grad_fn there would pin the graph of the last forward and make copy.deepcopy of the module fail)"""
+        return Selection(**{k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in self.__dict__.items()})
+
 
 class _SelectFn(torch.autograd.Function):
     @staticmethod
