@@ -249,6 +249,17 @@ int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x, int x_dty
 int dsw_colsum_blocks(long long rows);
 int dsw_colsum(const void *x, int dtype, long long rows, int cols, float *out, float *partial, void *stream);
 
+/* Exponential moving average of a list of parameter tensors, in place:
+ *   ema[i][e] = ema[i][e] * beta + one_minus_beta * cur[i][e]
+ * replaces the per-parameter Python loop of toolkit/param_ema.py:9-17 (three elementwise launches per
+ * parameter) by one launch per 48 tensors, with the same rounding (both products rounded to the tensor
+ * dtype, then added): bit-identical to the reference's expression.
+ *   ema, cur, numel: HOST arrays of n device pointers / element counts (read during the call only);
+ *   every tensor dense, of the one dtype given; beta and one_minus_beta as the reference passes them
+ *   (one_minus_beta = the double 1 - beta rounded to float). */
+int dsw_ema_update(int n, void *const *ema, const void *const *cur, const long long *numel, int dtype, float beta,
+                   float one_minus_beta, void *stream);
+
 /* Row copy with dtype conversion between two row strides (in elements): dst[r][c] = src[r][c] for
  * c < cols; with zero_pad != 0 the columns cols..dst_ld-1 of every dst row are set to zero.  Used
  * around the projection GEMMs (the nn.Linear calls at DSwinT_arch.py:303,308,334,337 and

@@ -1,0 +1,84 @@
+"""Parameter EMA (toolkit/param_ema.py): the oracle and the host class against vectors written by the
+reference's own ParameterEMA (tests/golden/make_golden_ema.py), the fused kernel against the oracle."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ema_oracle
+from visiontransformer_amd.ema import ParameterEMA, ema_update_
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ema_reference.npz")
+
+
+def _golden():
+    z = np.load(GOLDEN, allow_pickle=False)
+    n = int(z["n_params"])
+    cur = [[torch.from_numpy(z["cur.%d.%d" % (s, i)]) for i in range(n)] for s in range(4)]
+    ema = [[torch.from_numpy(z["ema.%d.%d" % (s, i)]) for i in range(n)] for s in range(4)]
+    return cur, ema
+
+
+def _toy():
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Linear(7, 1031), torch.nn.Linear(1031, 3, bias=False),
+                               torch.nn.LayerNorm(9))
+
+
+def test_oracle_matches_the_reference_bit_for_bit():
+    cur, ema = _golden()
+    state = dict(step=0, start_step=1, beta=0.995)
+    e = [c + 1.0 for c in cur[0]]
+    for s in range(4):
+        e = ema_oracle.step_ema(state, e, cur[s])
+        for got, ref in zip(e, ema[s]):
+            assert torch.equal(got, ref)
+    assert not torch.equal(ema[1][1], cur[1][1])   # the later steps average, they do not copy
+
+
+def _drive(device):
+    cur, ema = _golden()
+    model, ema_model = _toy().to(device), _toy().to(device).eval().requires_grad_(False)
+    helper = ParameterEMA(start_step=1, beta=0.995)
+    for s in range(4):
+        with torch.no_grad():
+            for p, c in zip(model.parameters(), cur[s]):
+                p.copy_(c)
+        helper.step_ema(ema_model, model, new_ema=True)
+        for p, ref in zip(ema_model.parameters(), ema[s]):
+            assert torch.equal(p.detach().cpu(), ref), "step %d" % s
+    assert helper.step == 4
+
+
+def test_host_class_on_cpu_tensors():
+    _drive(torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_host_class_on_the_gpu_matches_the_reference_bit_for_bit(cuda0):
+    _drive(cuda0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_kernel_against_the_oracle(cuda0, dtype):
+    """more tensors than one launch takes, empty and ragged sizes, bases that are not 16-byte aligned"""
+    gen = torch.Generator().manual_seed(9)
+    sizes = [0, 1, 3, 4, 5, 4095, 4096, 4097, 70001] + [17 + 13 * i for i in range(60)]
+    ema_c, cur_c = [], []
+    for i, n in enumerate(sizes):
+        off = i % 3                      # element offsets 0, 1, 2 into a larger buffer
+        ema_c.append(torch.randn(n + off, generator=gen).to(dtype)[off:])
+        cur_c.append(torch.randn(n + off, generator=gen).to(dtype)[off:])
+    ref = [ema_oracle.update_average(e, c, 0.995) for e, c in zip(ema_c, cur_c)]
+    ema_g = [torch.empty(e.numel() + i % 3, dtype=dtype, device=cuda0)[i % 3:].copy_(e) for i, e in enumerate(ema_c)]
+    cur_g = [torch.empty(c.numel() + i % 3, dtype=dtype, device=cuda0)[i % 3:].copy_(c) for i, c in enumerate(cur_c)]
+    ema_update_(ema_g, cur_g, 0.995)
+    for i, (g, r) in enumerate(zip(ema_g, ref)):
+        assert torch.equal(g.cpu(), r), "tensor %d (%d elements)" % (i, r.numel())
+    # a second step on the result (in place), as training does
+    ref2 = [ema_oracle.update_average(r, c, 0.995) for r, c in zip(ref, cur_c)]
+    ema_update_(ema_g, cur_g, 0.995)
+    for g, r in zip(ema_g, ref2):
+        assert torch.equal(g.cpu(), r)

@@ -60,6 +60,8 @@ def test_training_step_under_whole_model_checkpointing(cuda0, kind):
             got[n] = p.grad.clone()
         grads.append(got)
     assert losses[0] == losses[1]
+    if kind == "dswt":   # the recomputation inside backward does not count as a second training step
+        assert int(model.current_iteration) == 1
     # two plain runs of the bf16 backward already differ by a few 1e-3 (the stock convolutions' backward is
     # not run-to-run reproducible): the checkpointed run has to stay within the bf16 bar of the plain one
     flat = lambda gs: torch.cat([gs[n].flatten() for n in sorted(gs)])
@@ -78,9 +80,14 @@ def test_training_step_under_whole_model_checkpointing(cuda0, kind):
     opt.zero_grad(set_to_none=True)
     moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in model.named_parameters())
     assert moved > 0.9 * len(before)
-    ema_model.load_state_dict(model.state_dict())      # ParameterEMA.set_parameters, toolkit/param_ema.py:26-27
+    from visiontransformer_amd.ema import ParameterEMA
+    ema = ParameterEMA(start_step=1, beta=0.995)
+    ema.step_ema(ema_model=ema_model, model=model)      # copies (toolkit/param_ema.py:20-23)
+    ema.step_ema(ema_model=ema_model, model=model)      # averages two equal models: the same values again
+    for (n, p), q in zip(model.named_parameters(), ema_model.parameters()):
+        assert rel_err(q, p) < 1e-6, n
     model.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         y_val = checkpoint(ema_model, lr, use_reentrant=False)
         y_ref = model(lr)
-    assert torch.isfinite(y_val).all() and rel_err(y_val, y_ref) < 1e-6
+    assert torch.isfinite(y_val).all() and rel_err(y_val, y_ref) < 2e-2

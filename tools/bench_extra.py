@@ -9,7 +9,10 @@
   C  MSFT (dim 192, levels 2, w 8), x4 training step (fwd + bwd, bf16 autocast) on 64x64 patches,
      batch 8: patches / s.
 
-  python tools/bench_extra.py [D] [E] [C]   -> one JSON line per workload
+  T  DSWT default network, x4 training step on 64x64 patches (T_BATCH, default 32): patches / s.
+  M  parameter EMA of the DSWT default network: fused multi-tensor kernel against the per-parameter loop.
+
+  python tools/bench_extra.py [D] [E] [C] [T] [M]   -> one JSON line per workload
 """
 import json
 import os
@@ -125,13 +128,46 @@ def workload_t(dev):
             "config": {"workload": "T: DSWT default (8 blocks x 3, dim 180, w 16), batch %d of 64x64 LR" % B}}
 
 
+def workload_m(dev):
+    """parameter EMA of the DSWT default network (14.6 M fp32 parameters in ~600 tensors): the fused
+    multi-tensor kernel against the reference's per-parameter loop (toolkit/param_ema.py:9-17)"""
+    import copy
+    from visiontransformer_amd.ema import ParameterEMA
+    from visiontransformer_amd.models import DSWT_DEFAULT, DSWTransformer
+    torch.manual_seed(0)
+    model = DSWTransformer(**DSWT_DEFAULT).to(dev)
+    ema_model = copy.deepcopy(model).eval().requires_grad_(False)
+    helper = ParameterEMA(start_step=0)
+    n_t = len(list(model.parameters()))
+    numel = sum(p.numel() for p in model.parameters())
+
+    def loop():   # the reference's expression, parameter by parameter
+        for c, e in zip(model.parameters(), ema_model.parameters()):
+            e.data = e.data * helper.beta + (1 - helper.beta) * c.data
+
+    t_fused = sync_time(lambda: helper.update_model_average(ema_model, model), 20, warm=3)
+    t_loop = sync_time(loop, 5, warm=2)
+    # device time of the fused launches alone (the host builds three pointer tables per call)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(10):
+        helper.update_model_average(ema_model, model)
+    ev1.record()
+    torch.cuda.synchronize()
+    gbs = 3 * numel * 4 / 1e9
+    return {"metric": "parameter EMA step", "tensors": n_t, "parameters": numel, "fused_ms": t_fused * 1e3, "reference_loop_ms": t_loop * 1e3,
+            "speedup": t_loop / t_fused, "algorithmic_GB": gbs, "GB/s_wall": gbs / t_fused,
+            "config": {"workload": "M: EMA of DSWT default, fp32, beta 0.995"}, "wall_ms_per_call_back_to_back": ev0.elapsed_time(ev1) / 10}
+
+
 def main():
     dev = torch.device("cuda:0")
     from visiontransformer_amd import _lib
     _lib.load()
     which = [a.upper() for a in sys.argv[1:]] or ["D", "E", "C"]
     for w in which:
-        print(json.dumps({"D": workload_d, "E": workload_e, "C": workload_c, "T": workload_t}[w](dev)), flush=True)
+        print(json.dumps({"D": workload_d, "E": workload_e, "C": workload_c, "T": workload_t, "M": workload_m}[w](dev)), flush=True)
 
 
 if __name__ == "__main__":

@@ -68,6 +68,7 @@ SIGNATURES = {
     "dsw_conv3x3_wgrad": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dsw_layernorm_fwd": (_I, [_P, _P, _P, _F, ctypes.c_longlong, _I, _P, _I, ctypes.c_longlong, _P, _P, _P]),
     "dsw_layernorm_bwd": (_I, [_P, _I, ctypes.c_longlong, _P, _P, _P, _P, ctypes.c_longlong, _I, _P, _P, _P]),
+    "dsw_ema_update": (_I, [_I, _P, _P, _P, _I, _F, _F, _P]),
     "dsw_colsum_blocks": (_I, [ctypes.c_longlong]),
     "dsw_colsum": (_I, [_P, _I, ctypes.c_longlong, _I, _P, _P, _P]),
     "dsw_dwconv3x3_bwd_blocks": (_I, [_I, _I, _I]),

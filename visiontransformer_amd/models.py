@@ -195,7 +195,9 @@ class DSWTransformer(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        if self.training:
+        # a forward that runs inside a backward pass is activation checkpointing recomputing this one
+        # (toolkit/model_helper2.py:115): the step has been counted already
+        if self.training and torch._C._current_graph_task_id() == -1:
             self.update_temperature()
         x = self.feature_extractor(self.padding(x))
         x = x.permute(0, 2, 3, 1).contiguous()
