@@ -252,7 +252,7 @@ int dsw_colsum(const void *x, int dtype, long long rows, int cols, float *out, f
 /* Exponential moving average of a list of parameter tensors, in place:
  *   ema[i][e] = ema[i][e] * beta + one_minus_beta * cur[i][e]
  * replaces the per-parameter Python loop of toolkit/param_ema.py:9-17 (three elementwise launches per
- * parameter) by one launch per 48 tensors, with the same rounding (both products rounded to the tensor
+ * parameter) by one launch per 128 tensors, with the same rounding (both products rounded to the tensor
  * dtype, then added): bit-identical to the reference's expression.
  *   ema, cur, numel: HOST arrays of n device pointers / element counts (read during the call only);
  *   every tensor dense, of the one dtype given; beta and one_minus_beta as the reference passes them

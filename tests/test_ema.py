@@ -65,7 +65,7 @@ def test_host_class_on_the_gpu_matches_the_reference_bit_for_bit(cuda0):
 def test_fused_kernel_against_the_oracle(cuda0, dtype):
     """more tensors than one launch takes, empty and ragged sizes, bases that are not 16-byte aligned"""
     gen = torch.Generator().manual_seed(9)
-    sizes = [0, 1, 3, 4, 5, 4095, 4096, 4097, 70001] + [17 + 13 * i for i in range(60)]
+    sizes = [0, 1, 3, 4, 5, 4095, 4096, 4097, 70001] + [17 + 13 * i for i in range(150)]
     ema_c, cur_c = [], []
     for i, n in enumerate(sizes):
         off = i % 3                      # element offsets 0, 1, 2 into a larger buffer
@@ -82,3 +82,15 @@ def test_fused_kernel_against_the_oracle(cuda0, dtype):
     ema_update_(ema_g, cur_g, 0.995)
     for g, r in zip(ema_g, ref2):
         assert torch.equal(g.cpu(), r)
+
+
+def test_parameter_lists_follow_replaced_parameters():
+    """the flat parameter lists are kept between steps; a Parameter object replaced in a module is seen"""
+    model, ema_model = _toy(), _toy().eval().requires_grad_(False)
+    helper = ParameterEMA(start_step=0, beta=0.5)
+    helper.step_ema(ema_model, model)
+    model[1].weight = torch.nn.Parameter(torch.full_like(model[1].weight, 3.0))
+    with torch.no_grad():
+        ema_model[1].weight.fill_(1.0)
+    helper.step_ema(ema_model, model)
+    assert torch.equal(ema_model[1].weight, torch.full_like(ema_model[1].weight, 2.0))

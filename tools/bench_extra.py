@@ -156,9 +156,20 @@ def workload_m(dev):
     ev1.record()
     torch.cuda.synchronize()
     gbs = 3 * numel * 4 / 1e9
+    # device time of the kernel launches of one call (the call itself is bound by the host's table building)
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(5):
+            helper.update_model_average(ema_model, model)
+        torch.cuda.synchronize()
+    dev_us = sum(e.self_device_time_total for e in prof.key_averages() if "ema_update_kernel" in e.key) / 5
+    launches = sum(e.count for e in prof.key_averages() if "ema_update_kernel" in e.key) // 5
     return {"metric": "parameter EMA step", "tensors": n_t, "parameters": numel, "fused_ms": t_fused * 1e3, "reference_loop_ms": t_loop * 1e3,
             "speedup": t_loop / t_fused, "algorithmic_GB": gbs, "GB/s_wall": gbs / t_fused,
-            "config": {"workload": "M: EMA of DSWT default, fp32, beta 0.995"}, "wall_ms_per_call_back_to_back": ev0.elapsed_time(ev1) / 10}
+            "config": {"workload": "M: EMA of DSWT default, fp32, beta 0.995"}, "wall_ms_per_call_back_to_back": ev0.elapsed_time(ev1) / 10,
+            "kernel_launches_per_call": launches, "kernel_us_per_call": dev_us,
+            "roofline": {"bound": "hbm", "achieved": gbs / (dev_us * 1e-6) if dev_us else None, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / (dev_us * 1e-6) / bench.HBM_PEAK_GBS if dev_us else None}}
 
 
 def main():

@@ -1,5 +1,5 @@
 // Exponential moving average of a model's parameters (toolkit/param_ema.py:9-17 of the reference:
-// a Python loop of three elementwise launches per parameter) as one launch per 48 parameters.
+// a Python loop of three elementwise launches per parameter) as one launch per 128 parameters.
 //   ema[i] = ema[i] * beta + (1 - beta) * cur[i]
 // with the reference's rounding: the two products are rounded to the parameter dtype separately and then
 // added (no fused multiply-add), so the result is bit-identical to the three torch ops.
@@ -10,9 +10,9 @@
 namespace dsw {
 namespace {
 
-constexpr int EMA_MAXT = 48;                // tensors per launch
+constexpr int EMA_MAXT = 128;               // tensors per launch (the argument block stays under 4 KB)
 constexpr int EMA_THREADS = 256;
-constexpr int EMA_CHUNK = EMA_THREADS * 16;  // elements per workgroup
+constexpr int EMA_CHUNK = EMA_THREADS * 8;   // elements per workgroup
 
 struct EmaBatch {
     void *ema[EMA_MAXT];
@@ -33,8 +33,12 @@ template <typename T> __device__ __forceinline__ float ema_value(float old, floa
 template <typename T>
 __global__ __launch_bounds__(EMA_THREADS) void ema_update_kernel(const EmaBatch batch, float beta, float omb) {
     // which tensor this workgroup belongs to (uniform over the workgroup)
-    int t = 0;
-    while (t + 1 < batch.n && (int)blockIdx.x >= batch.first_block[t + 1]) ++t;
+    int t = 0, hi = batch.n;   // first_block[t] <= blockIdx.x < first_block[t + 1]
+    while (hi - t > 1) {
+        const int mid = (t + hi) >> 1;
+        if ((int)blockIdx.x >= batch.first_block[mid]) t = mid;
+        else hi = mid;
+    }
     T *__restrict__ ema = static_cast<T *>(batch.ema[t]);
     const T *__restrict__ cur = static_cast<const T *>(batch.cur[t]);
     const long long numel = batch.numel[t];
