@@ -359,6 +359,15 @@ int dsw_rezero_fwd(const float *x, const void *branch, int b_dtype, long long ld
                    int C, float *y, void *stream);
 int dsw_rezero_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r, long long M,
                    int C, void *d_branch, long long ld_db, float *partial, void *stream);
+/* The same residual with the reference's dropout on the branch in between (`drop_path`, an nn.Dropout,
+ * DSwinT_arch.py:352, applied at :355-357): y = x + r * (branch * mask * keep_scale).  mask: dense bytes
+ * [M][C], 0 = dropped (the caller draws it, e.g. Bernoulli(1 - p) from torch's generator, so that activation
+ * checkpointing replays it); keep_scale = 1 / (1 - p).  Backward as above with dy masked and scaled. */
+int dsw_rezero_dropout_fwd(const float *x, const void *branch, int b_dtype, long long ldb, const float *r,
+                           const unsigned char *mask, float keep_scale, long long M, int C, float *y, void *stream);
+int dsw_rezero_dropout_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r,
+                           const unsigned char *mask, float keep_scale, long long M, int C, void *d_branch,
+                           long long ld_db, float *partial, void *stream);
 
 /* Dense 3x3 convolution, stride 1, zero padding 1, on an NHWC tensor (the LastChannelConv2D layers of the
  * reference's model assembly, DSwinT_arch.py:36-44, used at :372 and :420) on the matrix cores: the product kernel of dsw_linear with one k slab per tap, the rows of tap t read shifted by

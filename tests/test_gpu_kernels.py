@@ -556,6 +556,40 @@ def test_rezero_residual(cuda0, bdtype, padded):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bdtype,padded", [(torch.float32, False), (torch.bfloat16, True)])
+@pytest.mark.parametrize("p", [0.1, 0.6, 1.0])
+def test_rezero_residual_with_dropout(cuda0, bdtype, padded, p):
+    """x + r * dropout(branch) with the mask applied inside the residual kernel: the mask is the one torch's
+    generator gives for the same seed, values and the three gradients match the torch expression on it."""
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(11)
+    B, H, W, C = 2, 9, 11, 180
+    x = torch.randn(B, H, W, C, device=cuda0, requires_grad=True)
+    r = torch.nn.Parameter(torch.tensor([0.37], device=cuda0))
+    ld = 192 if padded else C
+    buf = torch.zeros(B * H * W, ld, device=cuda0, dtype=bdtype)
+    buf[:, :C] = torch.randn(B * H * W, C, device=cuda0).to(bdtype)
+    br = buf[:, :C].view(B, H, W, C).detach().requires_grad_()
+    dy = torch.randn(B, H, W, C, device=cuda0)
+    drop = torch.nn.Dropout(p).train()
+    torch.manual_seed(5)
+    mask = torch.empty(B * H * W, C, dtype=torch.uint8, device=cuda0).bernoulli_(1.0 - p).view(B, H, W, C)
+    keep = 1.0 / (1.0 - p) if p < 1.0 else 0.0
+    assert p == 1.0 or abs(float(mask.float().mean()) - (1 - p)) < 0.02
+    ref = x + r * (br.float() * mask * keep)
+    gx, gr, gb = torch.autograd.grad(ref, (x, r, br), dy)
+    torch.manual_seed(5)
+    got = K.rezero_residual(x, r, br, dropout=drop)
+    hx, hr, hb = torch.autograd.grad(got, (x, r, br), dy)
+    tol = 1e-5 if bdtype == torch.float32 else 1e-2
+    assert rel_err(got, ref) < 1e-6 and rel_err(hx, gx) < 1e-6
+    assert rel_err(hr, gr) < 1e-4 and rel_err(hb.float(), gb.float()) < tol
+    assert torch.equal(hb == 0, (mask == 0) | (dy == 0) if p < 1.0 else torch.ones_like(mask, dtype=torch.bool))
+    # evaluation mode: no mask, the plain residual
+    assert torch.equal(K.rezero_residual(x, r, br, dropout=drop.eval()), K.rezero_residual(x, r, br))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Ci,Co,xdtype", [(1, 5, 7, 12, 8, torch.float32), (2, 33, 20, 180, 180, torch.float32),
                                                 (1, 64, 64, 192, 64, torch.bfloat16), (3, 16, 16, 64, 256, torch.float32)])
 def test_conv3x3_nhwc(cuda0, B, H, W, Ci, Co, xdtype):

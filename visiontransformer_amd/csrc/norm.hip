@@ -242,25 +242,36 @@ extern "C" int dsw_gated_silu_bwd(const void *dout, int dout_dtype, long long ld
 namespace dsw {
 namespace {
 
+// inverted dropout on 4 consecutive elements: mask bytes (0 = dropped) of a dense [M][C] byte matrix
+__device__ __forceinline__ float4 drop4(float4 v, uint32_t m4, float keep) {
+    return make_float4((m4 & 0xffu) ? v.x * keep : 0.f, (m4 & 0xff00u) ? v.y * keep : 0.f, (m4 & 0xff0000u) ? v.z * keep : 0.f,
+                       (m4 & 0xff000000u) ? v.w * keep : 0.f);
+}
+
 template <typename TB>
 __global__ __launch_bounds__(256) void rezero_fwd_kernel(const float *__restrict__ x, const TB *__restrict__ b, long long ldb,
-                                                         const float *__restrict__ r, long long M, int C, float *__restrict__ y) {
+                                                         const float *__restrict__ r, const unsigned char *__restrict__ mask, float keep,
+                                                         long long M, int C, float *__restrict__ y) {
     const float rv = *r;
     const int per_row = C / 4;
     const long long items = M * per_row;
     for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
         const long long m = it / per_row;
         const int j = (int)(it - m * per_row) * 4;
-        const float4 xv = *reinterpret_cast<const float4 *>(x + m * C + j), bv = io<TB>::ld4(b + m * ldb + j);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + m * C + j);
+        float4 bv = io<TB>::ld4(b + m * ldb + j);
+        if (mask != nullptr) bv = drop4(bv, *reinterpret_cast<const uint32_t *>(mask + m * C + j), keep);
         *reinterpret_cast<float4 *>(y + m * C + j) = xv + bv * rv;
     }
 }
 
-// db = r * dy (rows of stride ld_db, padding columns zeroed), partial[block] = sum over its items of dy * b
+// db = r * dy (rows of stride ld_db, padding columns zeroed), partial[block] = sum over its items of dy * b;
+// with a dropout mask dy is masked and scaled first (the gradient of the dropped branch)
 template <typename TB>
 __global__ __launch_bounds__(256) void rezero_bwd_kernel(const float *__restrict__ dy, const TB *__restrict__ b, long long ldb,
-                                                         const float *__restrict__ r, long long M, int C, TB *__restrict__ db,
-                                                         long long ld_db, float *__restrict__ partial) {
+                                                         const float *__restrict__ r, const unsigned char *__restrict__ mask, float keep,
+                                                         long long M, int C, TB *__restrict__ db, long long ld_db,
+                                                         float *__restrict__ partial) {
     __shared__ float red[4];
     const float rv = *r;
     const int per_row = (int)(ld_db / 4), nv = C / 4;
@@ -271,7 +282,9 @@ __global__ __launch_bounds__(256) void rezero_bwd_kernel(const float *__restrict
         const int jv = (int)(it - m * per_row), j = jv * 4;
         float4 o = f4zero();
         if (jv < nv) {
-            const float4 g = *reinterpret_cast<const float4 *>(dy + m * C + j), bv = io<TB>::ld4(b + m * ldb + j);
+            float4 g = *reinterpret_cast<const float4 *>(dy + m * C + j);
+            const float4 bv = io<TB>::ld4(b + m * ldb + j);
+            if (mask != nullptr) g = drop4(g, *reinterpret_cast<const uint32_t *>(mask + m * C + j), keep);
             acc += g.x * bv.x + g.y * bv.y + g.z * bv.z + g.w * bv.w;
             o = g * rv;
         }
@@ -294,29 +307,55 @@ unsigned rz_blocks(long long items) { return (unsigned)((items + 255) / 256 < RZ
 
 extern "C" int dsw_rezero_blocks(long long M, long long ld) { return M > 0 && ld > 0 ? (int)rz_blocks(M * (ld / 4)) : 0; }
 
-extern "C" int dsw_rezero_fwd(const float *x, const void *branch, int b_dtype, long long ldb, const float *r, long long M, int C, float *y,
-                              void *stream) {
-    int rc = rz_check("dsw_rezero_fwd", M, C, ldb);
+static int rezero_fwd_impl(const char *who, const float *x, const void *branch, int b_dtype, long long ldb, const float *r,
+                           const unsigned char *mask, float keep, long long M, int C, float *y, void *stream) {
+    int rc = rz_check(who, M, C, ldb);
     if (rc) return rc;
-    DSW_REQUIRE(x && branch && r && y, "dsw_rezero_fwd: null pointer");
+    DSW_REQUIRE(x && branch && r && y, "%s: null pointer", who);
+    if ((uintptr_t)mask & 3) return fail(DSW_EUNSUPPORTED, "%s: the mask needs a 4-byte aligned base", who);
     DSW_DISPATCH_DTYPE(b_dtype, TB, {
         hipLaunchKernelGGL(rezero_fwd_kernel<TB>, dim3(rz_blocks(M * (C / 4))), dim3(256), 0, as_stream(stream), x, (const TB *)branch, ldb, r,
-                           M, C, y);
+                           mask, keep, M, C, y);
     });
     return check_launch("rezero_fwd_kernel");
 }
 
-extern "C" int dsw_rezero_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r, long long M, int C,
-                              void *d_branch, long long ld_db, float *partial, void *stream) {
-    int rc = rz_check("dsw_rezero_bwd", M, C, ldb);
+static int rezero_bwd_impl(const char *who, const float *dy, const void *branch, int b_dtype, long long ldb, const float *r,
+                           const unsigned char *mask, float keep, long long M, int C, void *d_branch, long long ld_db, float *partial,
+                           void *stream) {
+    int rc = rz_check(who, M, C, ldb);
     if (rc) return rc;
-    if (ld_db < C || ld_db % 4) return fail(DSW_EUNSUPPORTED, "dsw_rezero_bwd: gradient row stride %lld (a multiple of 4, >= C)", ld_db);
-    DSW_REQUIRE(dy && branch && r && d_branch && partial, "dsw_rezero_bwd: null pointer");
+    if (ld_db < C || ld_db % 4) return fail(DSW_EUNSUPPORTED, "%s: gradient row stride %lld (a multiple of 4, >= C)", who, ld_db);
+    DSW_REQUIRE(dy && branch && r && d_branch && partial, "%s: null pointer", who);
+    if ((uintptr_t)mask & 3) return fail(DSW_EUNSUPPORTED, "%s: the mask needs a 4-byte aligned base", who);
     DSW_DISPATCH_DTYPE(b_dtype, TB, {
         hipLaunchKernelGGL(rezero_bwd_kernel<TB>, dim3(rz_blocks(M * (ld_db / 4))), dim3(256), 0, as_stream(stream), dy, (const TB *)branch,
-                           ldb, r, M, C, (TB *)d_branch, ld_db, partial);
+                           ldb, r, mask, keep, M, C, (TB *)d_branch, ld_db, partial);
     });
     return check_launch("rezero_bwd_kernel");
+}
+
+extern "C" int dsw_rezero_fwd(const float *x, const void *branch, int b_dtype, long long ldb, const float *r, long long M, int C, float *y,
+                              void *stream) {
+    return rezero_fwd_impl("dsw_rezero_fwd", x, branch, b_dtype, ldb, r, nullptr, 1.f, M, C, y, stream);
+}
+
+extern "C" int dsw_rezero_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r, long long M, int C,
+                              void *d_branch, long long ld_db, float *partial, void *stream) {
+    return rezero_bwd_impl("dsw_rezero_bwd", dy, branch, b_dtype, ldb, r, nullptr, 1.f, M, C, d_branch, ld_db, partial, stream);
+}
+
+extern "C" int dsw_rezero_dropout_fwd(const float *x, const void *branch, int b_dtype, long long ldb, const float *r,
+                                      const unsigned char *mask, float keep_scale, long long M, int C, float *y, void *stream) {
+    DSW_REQUIRE(mask, "dsw_rezero_dropout_fwd: null mask");
+    return rezero_fwd_impl("dsw_rezero_dropout_fwd", x, branch, b_dtype, ldb, r, mask, keep_scale, M, C, y, stream);
+}
+
+extern "C" int dsw_rezero_dropout_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r,
+                                      const unsigned char *mask, float keep_scale, long long M, int C, void *d_branch, long long ld_db,
+                                      float *partial, void *stream) {
+    DSW_REQUIRE(mask, "dsw_rezero_dropout_bwd: null mask");
+    return rezero_bwd_impl("dsw_rezero_dropout_bwd", dy, branch, b_dtype, ldb, r, mask, keep_scale, M, C, d_branch, ld_db, partial, stream);
 }
 
 // ---- LayerNorm over channel rows (the nn.LayerNorm layers of msft's ViTBlock, msft_arch.py:152-153, applied

@@ -1043,22 +1043,28 @@ def gated_silu(h, pad_out=False):
 # ---------------------------------------------------------------------------------------------
 class _RezeroFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, branch, sink=None):
+    def forward(ctx, x, r, branch, sink=None, mask=None, keep=1.0):
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         b2, ldb = _row_view4(branch, C)
         M = x2.shape[0]
         r32 = r.detach().float().reshape(1).contiguous()
         y = torch.empty(M, C, dtype=torch.float32, device=x.device)
-        call("dsw_rezero_fwd", ptr(x2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(y), stream(x.device))
-        ctx.save_for_backward(b2, r32)
-        ctx.meta = (x.shape, branch.shape, ldb, r.shape, r.dtype, sink)
+        if mask is None:
+            call("dsw_rezero_fwd", ptr(x2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(y), stream(x.device))
+            ctx.save_for_backward(b2, r32)
+        else:
+            call("dsw_rezero_dropout_fwd", ptr(x2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), ptr(mask), float(keep), M, C,
+                 ptr(y), stream(x.device))
+            ctx.save_for_backward(b2, r32, mask)
+        ctx.meta = (x.shape, branch.shape, ldb, r.shape, r.dtype, sink, float(keep))
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        b2, r32 = ctx.saved_tensors
-        xshape, bshape, ldb, rshape, rdt, sink = ctx.meta
+        b2, r32, *rest = ctx.saved_tensors
+        mask = rest[0] if rest else None
+        xshape, bshape, ldb, rshape, rdt, sink, keep = ctx.meta
         M, C = b2.shape
         dy2 = dy.reshape(-1, C)
         if dy2.dtype != torch.float32 or not dy2.is_contiguous():
@@ -1068,29 +1074,40 @@ class _RezeroFn(torch.autograd.Function):
             ld_db = ldb if ldb > C else C     # padded rows stay padded on the way back
             dbuf = _mark_padded(torch.empty(M, ld_db, dtype=b2.dtype, device=b2.device))
             partial = torch.empty(_lib.load().dsw_rezero_blocks(M, ld_db), dtype=torch.float32, device=b2.device)
-            call("dsw_rezero_bwd", ptr(dy2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(dbuf), ld_db, ptr(partial),
-                 stream(b2.device))
+            if mask is None:
+                call("dsw_rezero_bwd", ptr(dy2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(dbuf), ld_db, ptr(partial),
+                     stream(b2.device))
+            else:
+                call("dsw_rezero_dropout_bwd", ptr(dy2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), ptr(mask), keep, M, C,
+                     ptr(dbuf), ld_db, ptr(partial), stream(b2.device))
             db = (dbuf[:, :C] if ld_db != C else dbuf).view(bshape)
             dr = partial.sum().reshape(rshape).to(rdt)
         if sink is None or not ctx.needs_input_grad[0]:
-            return dy, dr, db, None
+            return dy, dr, db, None, None, None
         # the residual's share of x's gradient is dy itself: the norm's backward reads it and writes the sum
         if sink.buf is not None:  # the norm's gradient came first: its buffer is ours to add into
             sink.buf.view(M, C).add_(dy2)
-            return sink.deliver(sink.buf), dr, db, None
-        return sink.deliver(dy2.view(xshape)), dr, db, None
+            return sink.deliver(sink.buf), dr, db, None, None, None
+        return sink.deliver(dy2.view(xshape)), dr, db, None, None, None
 
 
-def rezero_residual(x, r, branch, sink=None):
-    """x + r * branch for the fp32 stream x [..., C], a one-element parameter r and a branch of the same
-    shape in fp32 / bf16 (dense or a view of padded rows)."""
+def rezero_residual(x, r, branch, sink=None, dropout=None):
+    """x + r * dropout(branch) for the fp32 stream x [..., C], a one-element parameter r and a branch of the
+    same shape in fp32 / bf16 (dense or a view of padded rows).  dropout: the nn.Dropout the reference puts on
+    the branch (DSwinT_arch.py:352, :355-357) or None; in training its Bernoulli mask is drawn from torch's
+    generator as one byte per element and applied inside the residual kernel (forward and backward), in
+    place of a dropout pass, its mask pass and their backward over the branch."""
     C = x.shape[-1]
     ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and r.numel() == 1
           and branch.shape == x.shape and branch.dtype in (torch.float32, torch.bfloat16))
     if not ok:
         assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
-        return torch.addcmul(x, r, branch)
-    return _run(_RezeroFn, x, r, branch, sink)
+        return torch.addcmul(x, r, branch if dropout is None else dropout(branch))
+    if dropout is None or not dropout.training or dropout.p == 0:
+        return _run(_RezeroFn, x, r, branch, sink)
+    p = float(dropout.p)
+    mask = torch.empty(x.numel() // C, C, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p)
+    return _run(_RezeroFn, x, r, branch, sink, mask, 1.0 / (1.0 - p) if p < 1.0 else 0.0)
 
 
 def prenorm_sink(x, norm, r):

@@ -102,10 +102,10 @@ class DSWTViTBlock(nn.Module):
         for norm, rz, branch, proj in ((self.ln1, self.rezero1, self.wmsa, True), (self.ln3, self.rezero3, self.sdwa, False),
                                        (self.ln2, self.rezero2, self.mlp1, True)):
             sink = K.prenorm_sink(x, norm, rz)
-            b = self.drop_path(branch(K.rms_norm(x, norm, for_projection=proj, sink=sink)))
+            b = branch(K.rms_norm(x, norm, for_projection=proj, sink=sink))
             if sink is not None and not (b.shape == x.shape and b.dtype in (torch.float32, torch.bfloat16)):
                 raise RuntimeError("branch output of an unexpected form")
-            x = K.rezero_residual(x, rz, b, sink=sink)
+            x = K.rezero_residual(x, rz, b, sink=sink, dropout=self.drop_path)   # drop_path applied inside
         return x
 
 
