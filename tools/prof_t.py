@@ -21,3 +21,9 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=90))
+if os.environ.get("SHAPES"):
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof2:
+        step(); torch.cuda.synchronize()
+    for e in sorted(prof2.key_averages(group_by_input_shape=True), key=lambda e: -e.device_time_total):
+        if e.key in ("aten::mul", "aten::copy_", "aten::sum", "aten::add_", "aten::add", "aten::to", "aten::_to_copy", "aten::fill_", "aten::zero_"):
+            print("%-16s %5d calls %9.1f us  %s" % (e.key, e.count, e.device_time_total, str(e.input_shapes)[:140]))

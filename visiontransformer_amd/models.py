@@ -201,6 +201,11 @@ class DSWTransformer(nn.Module):
             self.update_temperature()
         x = self.feature_extractor(self.padding(x))
         x = x.permute(0, 2, 3, 1).contiguous()
+        if x.is_cuda and x.dtype == torch.bfloat16:
+            # under autocast the stem hands over bf16; the residual stream between the blocks is kept in
+            # fp32 (what it becomes after the first ReZero residual anyway, DSwinT_arch.py:355), so every
+            # norm and residual of every block runs in its kernel and no gradient is cast at a block boundary
+            x = x.float()
         x = self.feature_transition(self.layers(x)) + x
         x = self.img_reconstruction(x.permute(0, 3, 1, 2).contiguous())
         return x[:, :, :H * self.scale_factor, :W * self.scale_factor]
