@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""torch profiler view of one DSWT training step (batch 32 of 64x64 LR, bf16): top kernels / ops"""
+"""torch profiler view of one DSWT (or, MODEL=msft, MSFT) training step (batch 32 of 64x64 LR, bf16): top kernels / ops"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,14 @@ from visiontransformer_amd import _lib
 from visiontransformer_amd.models import DSWT_DEFAULT, DSWTransformer
 dev = torch.device("cuda:0"); _lib.load()
 torch.manual_seed(0)
-m = DSWTransformer(**DSWT_DEFAULT).to(dev).train()
+if os.environ.get("MODEL") == "msft":
+    from visiontransformer_amd.models import MSFT_CONFIG_C, MSFTransformer
+    m = MSFTransformer(**MSFT_CONFIG_C).to(dev).train()
+    for sub in m.modules():
+        if hasattr(sub, "attn_drop"):
+            sub.attn_drop = 0.0
+else:
+    m = DSWTransformer(**DSWT_DEFAULT).to(dev).train()
 B = int(os.environ.get("T_BATCH", "32"))
 x = torch.rand(B, 3, 64, 64, device=dev); tgt = torch.rand(B, 3, 256, 256, device=dev)
 def step():
