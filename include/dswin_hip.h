@@ -294,6 +294,13 @@ int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w_p, void *w
 int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
                int ldw, const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols,
                int accumulate, void *a_copy, long long lda_copy, void *stream);
+/* The projection that closes a branch of the reference's ViTBlock together with the ReZero residual around it
+ * (DSwinT_arch.py:337 or :69 with :355-357, inference): out = resid + scale[0] * (A W^T + bias), fp32 [M][ncols]
+ * with row stride ldo, resid fp32 with row stride ld_resid (it may be out itself), scale one fp32 value on the
+ * device.  Operands as for dsw_linear.  Saves the bf16 round trip of the branch and the residual pass. */
+int dsw_linear_residual(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
+                        int ldw, const float *bias, int N, const float *resid, long long ld_resid, const float *scale,
+                        float *out, long long ldo, int ncols, void *stream);
 
 /* Weight and bias gradient of those projections (torch.nn.Linear backward behind the same call
  * sites): dw[n][k] = sum_m dy[m][n] x[m][k], db[n] = sum_m dy[m][n], fp32, summed in a fixed order.

@@ -334,3 +334,45 @@ def test_dsmsa_static_inference(cuda0, gates):
     if gates == "mixed":
         assert 0 < n_dyn < 9
     assert rel_err(outs[1], outs[0]) < (1e-6 if gates == "mixed" else 1e-2)   # closed: bf16 copy of x against x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,padded", [(1000, 180, 180, True), (4099, 360, 180, True), (300, 96, 64, False)])
+def test_linear_residual(cuda0, M, K, N, padded):
+    """resid + r * (a W^T + b) in the projection kernel against torch on the same bf16-rounded operands"""
+    from visiontransformer_amd import functional as K_
+    torch.manual_seed(M)
+    lin = torch.nn.Linear(K, N).to(cuda0)
+    r = torch.nn.Parameter(torch.tensor([0.7], device=cuda0))
+    resid = torch.randn(M, N, device=cuda0)
+    ld = -(-K // 64) * 64 if padded else K
+    buf = torch.zeros(M, ld, device=cuda0, dtype=torch.bfloat16)
+    buf[:, :K] = torch.randn(M, K, device=cuda0).to(torch.bfloat16)
+    a = K_._mark_padded(buf)[:, :K] if padded else buf
+    ref = resid + r.detach() * (a.float() @ lin.weight.detach().to(torch.bfloat16).float().t() + lin.bias.detach())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        got = K_.linear_residual(a, lin, resid, r)
+    assert got is not None and got.dtype == torch.float32 and got.shape == resid.shape
+    assert rel_err(got, ref) < 1e-5
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert K_.linear_residual(a, lin, resid, r) is None      # autograd on: the caller composes the two ops
+
+
+@pytest.mark.gpu
+def test_vitblock_inference_fuses_the_residual_into_the_projections(cuda0):
+    """eval + no_grad + bf16 autocast: WindowedMSA's out_proj and the MLP's fc2 add the ReZero residual in their
+    own kernel; same values as the composed path (which rounds the branch to bf16 first) within the bf16 bar."""
+    from visiontransformer_amd import models
+    torch.manual_seed(3)
+    blk = models.DSWTViTBlock(16, 180, n_heads=6).to(cuda0).eval()
+    with torch.no_grad():
+        for p in (blk.rezero1, blk.rezero2, blk.rezero3):
+            p.fill_(0.8)
+    x = torch.randn(2, 32, 48, 180, device=cuda0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        composed = blk(x.clone().requires_grad_()).detach()        # autograd on: rezero_residual kernels
+        with torch.no_grad():
+            fused = blk(x)
+    assert fused.dtype == torch.float32 and fused.shape == x.shape
+    assert rel_err(fused, composed) < 5e-3
+    assert rel_err(fused - x, composed - x) < 2e-2

@@ -112,7 +112,8 @@ template <typename TA, typename TC, int KS, bool PERSIST>
 __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
-    long long lda_copy, int chunks_per_block, int accumulate, int convH, int convW) {
+    long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
+    int convH, int convW) {
     using cfg = LnCfg<KS>;
     constexpr int LS = cfg::LS, NKS = cfg::NKS;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -121,6 +122,8 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     float *biasl = reinterpret_cast<float *>(Bs + LN_CN * LS);  // bias of this block's columns, zero where there is none
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    // fp32 results only: C = resid + rs * (A W^T + bias); resid == C is plain accumulation
+    const float rs = rscale != nullptr ? *rscale : 1.f;
     const int m0 = blockIdx.x * LN_BM;
     const int rows = min(M - m0, LN_BM);
     const bool half16 = sizeof(TA) == 2 && (((lda | K) & 7) != 0 || (reinterpret_cast<uintptr_t>(A) & 15) != 0);
@@ -186,6 +189,19 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
             for (int g = 0; g < 4; ++g) bv[t][g] = *reinterpret_cast<const float4 *>(biasl + chunk * LN_CN + 4 * hh + t * 32 + 8 * g);
 #pragma unroll
         for (int ps = 0; ps < 2 / TPP; ++ps) {
+            // the residual's values are asked for before the tile goes through LDS, so that their latency
+            // overlaps the staging
+            float4 ro[4];
+            if constexpr (sizeof(TC) == 4) {
+                if (resid != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = m0 + wave * 32 + i * 8 + (lane >> 3), col = nb + ps * SW + (lane & 7) * PC;
+                        ro[i] = (m < M && col + PC <= ncols) ? *reinterpret_cast<const float4 *>(resid + (size_t)m * ld_resid + col)
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
 #pragma unroll
             for (int tt = 0; tt < TPP; ++tt) {
                 const int t = ps * TPP + tt;
@@ -205,10 +221,10 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 TC *dst = C + (size_t)m * ldc + col;
                 if (m < M) {
                     if constexpr (sizeof(TC) == 4) {
-                        if (accumulate && col + PC <= ncols) {
-                            const float4 o = *reinterpret_cast<const float4 *>(dst);
-                            v = make_uint4(__float_as_uint(__uint_as_float(v.x) + o.x), __float_as_uint(__uint_as_float(v.y) + o.y),
-                                           __float_as_uint(__uint_as_float(v.z) + o.z), __float_as_uint(__uint_as_float(v.w) + o.w));
+                        if (resid != nullptr && col + PC <= ncols) {
+                            const float4 o = ro[i];
+                            v = make_uint4(__float_as_uint(o.x + rs * __uint_as_float(v.x)), __float_as_uint(o.y + rs * __uint_as_float(v.y)),
+                                           __float_as_uint(o.z + rs * __uint_as_float(v.z)), __float_as_uint(o.w + rs * __uint_as_float(v.w)));
                         }
                     }
                     if (col + PC <= ncols) *reinterpret_cast<uint4 *>(dst) = v;
@@ -489,8 +505,8 @@ int set_lds(const void *kern, size_t lds, const char *who) {
 
 template <typename TA, typename TC, int KS>
 int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
-                  void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, int accumulate, int convH, int convW,
-                  hipStream_t st) {
+                  void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, const float *resid, long long ld_resid,
+                  const float *rscale, int convH, int convW, hipStream_t st) {
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
@@ -510,12 +526,12 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
         auto kern = linear_nt_kernel<TA, TC, KS, true>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, accumulate, convH, convW);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW);
     } else {
         auto kern = linear_nt_kernel<TA, TC, KS, false>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, accumulate, convH, convW);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW);
     }
     return check_launch("linear_nt_kernel");
 }
@@ -536,9 +552,9 @@ extern "C" int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w
     return check_launch("weight_prep_kernel");
 }
 
-extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
-                          const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
-                          long long lda_copy, void *stream) {
+static int linear_impl(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                       const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
+                       long long lda_copy, const float *resid, long long ld_resid, const float *rscale, void *stream) {
     if (M <= 0 || M > 0x7fffff00LL || K <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
     DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
@@ -555,20 +571,42 @@ extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M
         return fail(DSW_EUNSUPPORTED, "dsw_linear: bias needs N %% 4 == 0, N <= ncols, a 16-byte aligned base (N=%d ncols=%d)", N, ncols);
     if (a_copy != nullptr && (lda_copy < Kp || lda_copy % 8 || ((uintptr_t)a_copy & 15)))
         return fail(DSW_EUNSUPPORTED, "dsw_linear: the bf16 copy of A needs rows of >= %d elements, a multiple of 8 (lda_copy=%lld)", Kp, lda_copy);
-    if (accumulate && c_dtype != DSW_F32) return fail(DSW_EUNSUPPORTED, "dsw_linear: accumulation needs an fp32 result");
+    if ((accumulate || resid != nullptr) && c_dtype != DSW_F32) return fail(DSW_EUNSUPPORTED, "dsw_linear: accumulation needs an fp32 result");
+    if (accumulate) {
+        resid = static_cast<const float *>(c);
+        ld_resid = ldc;
+        rscale = nullptr;
+    } else if (resid != nullptr && (ld_resid < ncols || ld_resid % 4 || ((uintptr_t)resid & 15)))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear_residual: the residual needs a row stride >= ncols, a multiple of 4, and a 16-byte aligned base "
+                                      "(ld_resid=%lld)", ld_resid);
     const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 ? 128 : 64);
     const int nslab = Kp / KS;
     hipStream_t st = as_stream(stream);
     int rc = DSW_OK;
 #define DSW_LINEAR_KS(KSV)                                                                                                     \
     DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
-        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, accumulate, 0, 0, st); \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, st); \
     }))
     if (KS == 192) DSW_LINEAR_KS(192);
     else if (KS == 128) DSW_LINEAR_KS(128);
     else DSW_LINEAR_KS(64);
 #undef DSW_LINEAR_KS
     return rc;
+}
+
+extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                          const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
+                          long long lda_copy, void *stream) {
+    return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, N, c, c_dtype, ldc, ncols, accumulate, a_copy, lda_copy, nullptr, 0,
+                       nullptr, stream);
+}
+
+extern "C" int dsw_linear_residual(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                                   const float *bias, int N, const float *resid, long long ld_resid, const float *scale, float *out,
+                                   long long ldo, int ncols, void *stream) {
+    DSW_REQUIRE(resid && scale, "dsw_linear_residual: null pointer");
+    return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, N, out, DSW_F32, ldo, ncols, 0, nullptr, 0, resid, ld_resid, scale,
+                       stream);
 }
 
 extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,
@@ -598,7 +636,7 @@ extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B
     int rc = DSW_OK;
 #define DSW_CONV_KS(KSV)                                                                                                          \
     DSW_DISPATCH_DTYPE(x_dtype, TA, DSW_DISPATCH_DTYPE(out_dtype, TC, {                                                           \
-        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, 0, H, W, st); \
+        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, nullptr, 0, nullptr, H, W, st); \
     }))
     if (KS == 192) DSW_CONV_KS(192);
     else if (KS == 128) DSW_CONV_KS(128);

@@ -110,12 +110,17 @@ class WindowedMSA(WindowedAttention):
         # the tensor is not contiguous.  False: always return a contiguous tensor.
         self.padded_output = True
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual = (stream, r), inference only: returns stream + r * attention(x) with the residual taken
+        inside out_proj's kernel (the caller's ReZero residual, DSwinT_arch.py:355), instead of attention(x)."""
         B, H, W, C = x.shape
         _check_no_attn_dropout(self.attn_drop, self.training)
         qkv = K.linear(x, self.qkv, pad_out=True)
         z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W),
                                pad_out=True)
+        if residual is not None:
+            y = K.linear_residual(z, self.out_proj, *residual)
+            return y if y is not None else K.rezero_residual(residual[0], residual[1], K.linear(z, self.out_proj, pad_out=True))
         return K.linear(z, self.out_proj, pad_out=self.padded_output)
 
 

@@ -932,6 +932,39 @@ def linear(x, lin, pad_out=False):
     return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out))
 
 
+def linear_residual(a, lin, resid, r):
+    """resid + r * lin(a) as fp32, in one kernel (dsw_linear_residual): the projection that closes a branch of
+    the reference's ViTBlock fused with the ReZero residual around it (DSwinT_arch.py:337 / :69 with
+    :355-357).  Inference under bf16 autocast only; returns None when the call is not one the kernel takes
+    (autograd on, other dtypes or layouts), and the caller then composes linear() and rezero_residual()."""
+    if torch.is_grad_enabled() or not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return None
+    weight, bias = lin.weight, lin.bias
+    N, Kd = weight.shape
+    if not (a.is_cuda and resid.is_cuda and resid.dtype == torch.float32 and resid.is_contiguous() and resid.shape[-1] == N
+            and N % 4 == 0 and r.numel() == 1 and a.shape[:-1] == resid.shape[:-1] and weight.is_contiguous()
+            and weight.dtype in (torch.float32, torch.bfloat16) and weight.data_ptr() % 16 == 0 and resid.data_ptr() % 16 == 0):
+        return None
+    a2 = a.reshape(-1, Kd)
+    T = a2.shape[0]
+    if T == 0:
+        return None
+    xk = _padded_rows(a2, torch.bfloat16)
+    if xk is not None:
+        a2, K_ = xk, _ceil_pad(Kd)
+    elif _mfma_operand(a2) is not None:
+        K_ = Kd
+    else:
+        return None
+    w_p, _ = _weight_operands(weight)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    r32 = r.detach().float().reshape(1).contiguous()
+    out = torch.empty(T, N, dtype=torch.float32, device=a.device)
+    call("dsw_linear_residual", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K_, ptr(w_p),
+         w_p.shape[0], w_p.shape[1], None if b32 is None else ptr(b32), N, ptr(resid), N, ptr(r32), ptr(out), N, N, stream(a.device))
+    return out.view(resid.shape)
+
+
 # ---------------------------------------------------------------------------------------------
 # RMSNorm in front of the attention modules / the MLP (DSwinT_arch.py:343-345, :355-357)
 # ---------------------------------------------------------------------------------------------

@@ -67,7 +67,13 @@ class GatedMLP(nn.Module):
             object.__setattr__(self, "_kept_fc1", kept)
         return kept[1]
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual = (stream, r), inference only: returns stream + r * mlp(x), the residual taken inside fc2's
+        kernel (the caller's ReZero residual, DSwinT_arch.py:357)."""
+        if residual is not None:
+            h = K.gated_silu(K.linear(x, self._stacked(), pad_out=True), pad_out=True)
+            y = K.linear_residual(h, self.fc2, *residual)
+            return y if y is not None else K.rezero_residual(residual[0], residual[1], K.linear(h, self.fc2))
         if not x.is_cuda:
             return self.drop(self.fc2(self.act(self.fc1_gate(x)) * self.fc1_content(x)))
         # gate and content share their input: one projection onto both (the rows of the two weights
@@ -99,8 +105,16 @@ class DSWTViTBlock(nn.Module):
     def forward(self, x):
         # x + rezero * branch(norm(x)): one pass over the fp32 stream for the residual, the branch read where
         # it lies, and the two gradients of x meeting in one buffer (K.prenorm_sink)
+        fuse = (not torch.is_grad_enabled() and not self.training and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+                and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and isinstance(self.mlp1.act, nn.SiLU) and self.mlp1.drop.p == 0)
         for norm, rz, branch, proj in ((self.ln1, self.rezero1, self.wmsa, True), (self.ln3, self.rezero3, self.sdwa, False),
                                        (self.ln2, self.rezero2, self.mlp1, True)):
+            if fuse and proj:
+                # inference: the branch's closing projection adds the residual itself (no bf16 round trip of the
+                # branch, no residual pass)
+                x = branch(K.rms_norm(x, norm, for_projection=True), residual=(x, rz))
+                continue
             sink = K.prenorm_sink(x, norm, rz)
             b = branch(K.rms_norm(x, norm, for_projection=proj, sink=sink))
             if sink is not None and not (b.shape == x.shape and b.dtype in (torch.float32, torch.bfloat16)):
