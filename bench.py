@@ -364,7 +364,12 @@ def main():
         dt = float(t.item())
     n_pass = pair.sdwa.last_selection.n if pair.sdwa.last_selection is not None else 0
     # second half of the headline metric, outside the timed training region: all ranks take part
-    sr = None if args.no_inference else sr_inference(device, rank, world)
+    sr = None
+    if not args.no_inference:
+        try:
+            sr = sr_inference(device, rank, world)
+        except Exception as e:  # the training line above stays valid; the failure is reported in its place
+            sr = {"metric": "x4 SR output megapixels/sec (fwd)", "value": None, "error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
