@@ -5,7 +5,7 @@ import torch
 
 def run(device):
     from oracle import dswin_oracle as D
-    from .dswin import DeformableSparseWindowAttention, WindowedMSA
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention, WindowedMSA
 
     torch.manual_seed(0)
     w, C, heads = 8, 24, 2

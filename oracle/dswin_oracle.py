@@ -179,12 +179,15 @@ def gumbel_noise(shape, generator=None, dtype=torch.float32):
     return -torch.empty(shape, dtype=dtype).exponential_(generator=generator).log()
 
 
-def candidate_indexes(scores, num_win_selected, temperature, training, noise=None):
+def candidate_indexes(scores, num_win_selected, temperature, training, noise=None, forced_idx=None):
     """Top-k window candidates + straight-through value (DSwinT_arch.py:201-225).
 
     scores [B,1,Hw,Ww]; ``noise`` is the explicit Gumbel draw [B,Hw*Ww] used
     when ``training`` (the reference lets F.gumbel_softmax draw it).  Returns
-    b_idx, h_idx, w_idx, scores_delta (all flat [B*k]) and the soft probs."""
+    b_idx, h_idx, w_idx, scores_delta (all flat [B*k]) and the soft probs.
+    ``forced_idx`` [B,k] (tests of reduced-precision runs): take these cells as
+    the top-k instead of ranking, so that values can be compared on the same
+    windows when a rounding difference swaps two near-equal candidates."""
     B, _, Hw, Ww = scores.shape
     k = int((Hw * Ww) * num_win_selected)
     flat = scores.view(B, -1)
@@ -194,7 +197,11 @@ def candidate_indexes(scores, num_win_selected, temperature, training, noise=Non
         probs = ((flat + noise) / temperature).float().softmax(dim=-1)    # gumbel_softmax, hard=False
     else:
         probs = F.softmax((flat / temperature).float(), dim=-1)
-    top_p, top_i = torch.topk(probs, k, dim=1)
+    if forced_idx is None:
+        top_p, top_i = torch.topk(probs, k, dim=1)
+    else:
+        top_i = forced_idx.long().view(B, k)
+        top_p = probs.gather(1, top_i)
     scores_delta = (torch.ones_like(top_p) - top_p).detach() + top_p
     b_idx = torch.arange(B).view(-1, 1).expand(-1, k).reshape(-1)
     h_idx = (top_i // Ww).reshape(-1)
@@ -236,25 +243,31 @@ def sparse_discriminator(P, x_nchw, w, prefix="sparse_discriminator."):
 
 
 def dsmsa_forward(P, x, w, num_heads, training=False, noise=None, temperature=1.0,
-                  num_win_selected=0.25, aux=None):
+                  num_win_selected=0.25, aux=None, forced=None):
     """DeformableSparseWindowAttention.forward (DSwinT_arch.py:255-317).
 
     x [B,H,W,C] -> [B,H,W,C].  ``aux`` (a dict) receives the integer
-    decisions: candidate (b,h,w), pass mask, passing (b,h,w), h1, w1."""
+    decisions: candidate (b,h,w), pass mask, passing (b,h,w), h1, w1.
+    ``forced`` (a dict, tests of reduced-precision runs only): integer decisions
+    to take over instead of deriving them - "cand_idx" [B,k] flat cells,
+    "pass_mask" [B*k] bool, "h1"/"w1" [n] corners of the passing windows."""
     x = x.permute(0, 3, 1, 2).contiguous()
     B, C, H, W = x.shape
     sd = sparse_discriminator(P, x, w)
     scores = sd[:, :1]
     gates = sd[:, 1:2].sigmoid()
     offsets = sd[:, 2:].sigmoid()
+    forced = forced or {}
     cb, ch, cw, scores_delta, probs = candidate_indexes(scores, num_win_selected, temperature,
-                                                        training, noise)
+                                                        training, noise, forced.get("cand_idx"))
     if aux is not None:
         aux.update(sd=sd.detach(), cand_b=cb, cand_h=ch, cand_w=cw, probs=probs.detach())
     if cb.numel() == 0:
         return x.permute(0, 2, 3, 1).contiguous()
     cand_gates = gates[cb, 0, ch, cw]
     hard = (cand_gates > 0.5).float()
+    if "pass_mask" in forced:
+        hard = forced["pass_mask"].float()
     gates_delta = (hard - cand_gates).detach() + cand_gates
     keep = hard.bool()
     b_idx, h_idx, w_idx = cb[keep], ch[keep], cw[keep]
@@ -264,6 +277,8 @@ def dsmsa_forward(P, x, w, num_heads, training=False, noise=None, temperature=1.
     if b_idx.numel() == 0:
         return x.permute(0, 2, 3, 1).contiguous()
     h1, w1, h2, w2 = cords(b_idx, h_idx, w_idx, offsets, w, H, W)
+    if "h1" in forced:
+        h1, w1 = forced["h1"].long(), forced["w1"].long()
     if aux is not None:
         aux.update(h1=h1, w1=w1)
     before = gather_windows(x, b_idx, h1, w1, w)                   # roi_align, DSwinT_arch.py:297

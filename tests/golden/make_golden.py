@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
 
 from oracle import dswin_oracle  # noqa: E402
 
@@ -201,6 +202,35 @@ def dswt_model(D, name, seed, H, W):
     _save(name, arrays, dict(kind="dswt_model", cfg=cfg, H=H, W=W, num_win_selected=0.5))
 
 
+def dswt_model_default(D, name, seed, H, W):
+    """The default-width DSWT network (configs/config.yaml: 8 x 3 blocks, dim 180, 6 heads, w 16; 14.6 M
+    parameters) on one 64x64 LR patch, eval mode: the reference's CPU-runnable case.  The parameters are drawn
+    per name by seeded_params.fill_parameters, so only x and y are stored."""
+    from seeded_params import fill_parameters
+    cfg = dict(block_type="default", n_blocks=8, n_sub_blocks=3, levels=1, window_size=16, dim=180, level_dim=96,
+               n_heads=6, n_heads_fuse=4, feature_dim=64, scale_factor=4)
+    mod = D.MSFTransformer(**cfg)
+    fill_parameters(mod, seed)
+    mod.eval()
+    gen = torch.Generator().manual_seed(seed)
+    x = (torch.randn(1, 3, H, W, generator=gen) * 0.5).clamp(-1, 1)
+    picked = []
+    for m in mod.modules():
+        if isinstance(m, D.DeformableSparseWindowAttention):
+            orig = m.cords
+
+            def crd(b, h, ww, offsets, HH, WW, orig=orig):
+                out = orig(b, h, ww, offsets, HH, WW)
+                picked.append(torch.stack([b, h, ww, out[0], out[1]], 1))
+                return out
+            m.cords = crd
+    with torch.no_grad():
+        y = mod(x)
+    n_win = torch.tensor([p.shape[0] for p in picked])
+    _save(name, {"x": x, "y": y, "aux.n_win": n_win, "aux.windows": torch.cat(picked)},
+          dict(kind="dswt_model_default", cfg=cfg, H=H, W=W, seed=seed, n_dsmsa_calls=len(picked)))
+
+
 def msft_model(M, name, seed, H, W):
     gen = torch.Generator().manual_seed(seed)
     cfg = dict(block_type="default", n_blocks=1, n_sub_blocks=1, levels=2, window_size=8, dim=32, level_dim=16,
@@ -224,6 +254,9 @@ def msft_model(M, name, seed, H, W):
 def main():
     torch.set_num_threads(4)
     D, M = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "default-width":   # only the newest vector (the others are unchanged)
+        dswt_model_default(D, "model_dswt_default", seed=33, H=64, W=64)
+        return
     # DSWT WindowedMSA: w=8 and w=16, head_dim 6 / 8 / 30 (the default config's d)
     dswt_wmsa(D, "dswt_wmsa_w8", B=2, H=16, W=24, C=12, heads=2, w=8, seed=1)
     dswt_wmsa(D, "dswt_wmsa_w16", B=1, H=32, W=32, C=24, heads=3, w=16, seed=2)
@@ -249,6 +282,7 @@ def main():
     # whole networks (the callers of the path), small configs, H/W that need reflect padding
     dswt_model(D, "model_dswt", seed=31, H=20, W=28)
     msft_model(M, "model_msft", seed=32, H=28, W=20)
+    dswt_model_default(D, "model_dswt_default", seed=33, H=64, W=64)
 
 
 if __name__ == "__main__":

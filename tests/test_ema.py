@@ -94,3 +94,42 @@ def test_parameter_lists_follow_replaced_parameters():
         ema_model[1].weight.fill_(1.0)
     helper.step_ema(ema_model, model)
     assert torch.equal(ema_model[1].weight, torch.full_like(ema_model[1].weight, 2.0))
+
+
+@pytest.mark.gpu
+def test_ema_update_is_seen_by_the_prepared_weight_caches(cuda0):
+    """Without autograd the projections, 3x3 convolutions and the stacked fc1 keep their prepared bf16 operands
+    per parameter until the parameter's version counter moves.  The fused update writes through raw pointers:
+    it has to move that counter, or a second evaluation of the EMA model (toolkit/model_helper2.py sample_model,
+    use_ema_model=True) would run on the weights of the first."""
+    from visiontransformer_amd import models
+    torch.manual_seed(0)
+    cfg = dict(models.DSWT_DEFAULT)
+    cfg.update(n_blocks=1, n_sub_blocks=1, dim=48, n_heads=2, window_size=8, feature_dim=16)
+    model = models.DSWTransformer(**cfg)
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "rezero" in n:
+                p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=gen))
+    model = model.to(cuda0)
+    ema_model = copy.deepcopy(model).eval().requires_grad_(False)
+    x = torch.rand(1, 3, 32, 32, device=cuda0, generator=torch.Generator(device=cuda0).manual_seed(1)) * 2 - 1
+    helper = ParameterEMA(start_step=0, beta=0.5)
+
+    def evaluate(m):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return m(x).float()
+
+    y0 = evaluate(ema_model)                      # fills the caches
+    versions = [p._version for p in ema_model.parameters()]
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn(p.shape, device=cuda0, generator=torch.Generator(device=cuda0).manual_seed(2)) * 0.05)
+    helper.step_ema(ema_model, model)             # step 0 >= start_step: averages through the kernel
+    assert all(p._version > v for p, v in zip(ema_model.parameters(), versions))
+    y1 = evaluate(ema_model)
+    cold = copy.deepcopy(ema_model)               # new Parameter objects: nothing cached for them
+    y_cold = evaluate(cold)
+    assert not torch.equal(y1, y0)
+    assert torch.equal(y1, y_cold)

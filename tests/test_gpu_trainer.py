@@ -63,11 +63,17 @@ def test_training_step_under_whole_model_checkpointing(cuda0, kind):
     if kind == "dswt":   # the recomputation inside backward does not count as a second training step
         assert int(model.current_iteration) == 1
     # two plain runs of the bf16 backward already differ by a few 1e-3 (the stock convolutions' backward is
-    # not run-to-run reproducible): the checkpointed run has to stay within the bf16 bar of the plain one
+    # not run-to-run reproducible): the checkpointed run has to stay within the bf16 bar of the plain one.
+    # Per tensor the bound is relative to the tensor's own norm plus a floor tied to the whole gradient: a
+    # one-element gradient (a ReZero gate) is a cancelling sum of ~4e5 bf16-rounded terms whose value is a few
+    # 1e-3 of the sum of their magnitudes, so run-to-run noise of the terms shows up as several percent of it.
     flat = lambda gs: torch.cat([gs[n].flatten() for n in sorted(gs)])
-    assert rel_err(flat(grads[1]), flat(grads[0])) < 1e-2
+    f0, f1 = flat(grads[0]).double(), flat(grads[1]).double()
+    assert rel_err(f1, f0) < 1e-2
+    rms = float(f0.norm()) / f0.numel() ** 0.5
     for n, g in grads[0].items():
-        assert rel_err(grads[1][n], g) < 5e-2, n
+        d = float((grads[1][n].double() - g.double()).norm())
+        assert d <= 5e-2 * float(g.double().norm()) + 5e-2 * rms * g.numel() ** 0.5, n
 
     # the rest of toolkit/model_helper2.py:122-127 on the checkpointed run, then a validation call (:174-177)
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.99))

@@ -173,10 +173,8 @@ class DeformableSparseWindowAttention(WindowedAttention):
     def forward(self, x):
         B, H, W, C = x.shape
         w = self.w
-        x = x.contiguous()
-        act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-        if act not in (torch.float32, torch.bfloat16):
-            act = x.dtype
+        x = K.supported_input(x).contiguous()
+        act = K.autocast_dtype(x.dtype)
         # the three readers of x meet in one gradient buffer (only when all three are certain to run
         # in the backward pass: the early returns below leave the sparse discriminator alone)
         Hw0, Ww0 = H // w, W // w

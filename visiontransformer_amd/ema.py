@@ -21,6 +21,9 @@ def _launch(pairs, dev, dtype, beta):
     with torch.cuda.device(dev):
         _lib.call("dsw_ema_update", n, ctypes.cast(ema_p, ctypes.c_void_p), ctypes.cast(cur_p, ctypes.c_void_p),
                   ctypes.cast(numel, ctypes.c_void_p), _lib.dtype_code(dtype), float(beta), float(1 - beta), _lib.stream(dev))
+    # the kernel wrote through raw pointers: tell torch, so that everything keyed on a tensor's version counter
+    # (autograd's saved-tensor checks, the prepared-weight caches of functional.py / models.py) sees the change
+    torch.autograd.graph.increment_version([e for e, _ in pairs])
 
 
 def ema_update_(ema_tensors, cur_tensors, beta):

@@ -49,6 +49,36 @@ _NO_GRAD = _NoGradCtx()
 _NULL_CTX = contextlib.nullcontext()
 
 
+_FP16_WARNED = [False]
+
+
+def autocast_dtype(fallback):
+    """The 16-bit type the kernels compute in under the caller's CUDA autocast, else `fallback`.
+
+    The kernels are built for fp32 and bf16.  Under fp16 autocast (torch's default for autocast("cuda"), the
+    mode of the reference's trainer, toolkit/model_helper2.py:35,120) the modules compute in bf16 instead -
+    the same storage width with fp32's exponent range, so GradScaler's scaled losses and gradients pass
+    through unharmed - and say so once."""
+    if not torch.is_autocast_enabled("cuda"):
+        return fallback
+    act = torch.get_autocast_dtype("cuda")
+    if act == torch.float16:
+        if not _FP16_WARNED[0]:
+            _FP16_WARNED[0] = True
+            import warnings
+            warnings.warn("visiontransformer_amd: fp16 autocast requested; the HIP kernels are built for bf16 and "
+                          "fp32, so the attention modules compute in bf16 under this autocast (use "
+                          "torch.autocast('cuda', dtype=torch.bfloat16) to make that explicit)", stacklevel=3)
+        return torch.bfloat16
+    return act
+
+
+def supported_input(x):
+    """fp16 tensors (what stock ops hand over under fp16 autocast) widened to fp32 - lossless, and a type the
+    kernels read; everything else as it is"""
+    return x.float() if x.dtype == torch.float16 else x
+
+
 def _run(fn, *args):
     """fn.apply(*args); without autograd, fn.forward directly"""
     if torch.is_grad_enabled():
@@ -928,7 +958,7 @@ def linear(x, lin, pad_out=False):
     """`lin(x)` for an nn.Linear `lin`, honouring CUDA autocast like F.linear does.  pad_out: leave
     the result in rows padded to a multiple of 64 elements (returned as a view of the first
     out_features columns); for callers whose consumers accept such views."""
-    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    act = autocast_dtype(x.dtype)
     return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out))
 
 
@@ -937,7 +967,7 @@ def linear_residual(a, lin, resid, r):
     the reference's ViTBlock fused with the ReZero residual around it (DSwinT_arch.py:337 / :69 with
     :355-357).  Inference under bf16 autocast only; returns None when the call is not one the kernel takes
     (autograd on, other dtypes or layouts), and the caller then composes linear() and rezero_residual()."""
-    if torch.is_grad_enabled() or not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+    if torch.is_grad_enabled() or autocast_dtype(None) != torch.bfloat16:
         return None
     weight, bias = lin.weight, lin.bias
     N, Kd = weight.shape
@@ -1028,7 +1058,7 @@ def rms_norm(x, norm, for_projection=False, sink=None):
         assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
         return norm(x)
     eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
-    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    act = autocast_dtype(x.dtype)
     to_act = for_projection and act == torch.bfloat16
     return _run(_RMSNormFn, x, norm.weight, eps, act if to_act else torch.float32, to_act, sink)
 
@@ -1248,7 +1278,7 @@ def conv3x3_nhwc(x, conv):
     """`conv` (an nn.Conv2d with a 3x3 kernel, stride 1, padding 1, one group) applied to the NHWC tensor
     x [B, H, W, Ci] -> [B, H, W, Co], or None when this call is not one the kernels take (not bf16
     autocast, other geometry): the caller then uses the stock convolution."""
-    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    act = autocast_dtype(x.dtype)
     B, H, W, Ci = x.shape
     ok = (x.is_cuda and act == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)
           and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
@@ -1308,6 +1338,6 @@ def layer_norm(x, norm, for_projection=False):
           and norm.weight is not None and tuple(norm.normalized_shape) == (C,))
     if not ok:
         return norm(x)
-    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    act = autocast_dtype(x.dtype)
     to_act = for_projection and act == torch.bfloat16
     return _run(_LayerNormFn, x, norm.weight, norm.bias, norm.eps, act if to_act else torch.float32, to_act)

@@ -106,7 +106,7 @@ class DSWTViTBlock(nn.Module):
         # x + rezero * branch(norm(x)): one pass over the fp32 stream for the residual, the branch read where
         # it lies, and the two gradients of x meeting in one buffer (K.prenorm_sink)
         fuse = (not torch.is_grad_enabled() and not self.training and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-                and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and K.autocast_dtype(None) == torch.bfloat16
                 and isinstance(self.mlp1.act, nn.SiLU) and self.mlp1.drop.p == 0)
         for norm, rz, branch, proj in ((self.ln1, self.rezero1, self.wmsa, True), (self.ln3, self.rezero3, self.sdwa, False),
                                        (self.ln2, self.rezero2, self.mlp1, True)):
@@ -215,7 +215,7 @@ class DSWTransformer(nn.Module):
             self.update_temperature()
         x = self.feature_extractor(self.padding(x))
         x = x.permute(0, 2, 3, 1).contiguous()
-        if x.is_cuda and x.dtype == torch.bfloat16:
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16):
             # under autocast the stem hands over bf16; the residual stream between the blocks is kept in
             # fp32 (what it becomes after the first ReZero residual anyway, DSwinT_arch.py:355), so every
             # norm and residual of every block runs in its kernel and no gradient is cast at a block boundary

@@ -27,6 +27,7 @@ class PatchMerging(nn.Module):
         self.linear = nn.Linear(dim, dim, bias=False)
 
     def forward(self, x):
+        x = K.supported_input(x)
         t = K.unshuffle_nhwc_layernorm(x, self.norm.weight, self.norm.bias, self.scale, self.norm.eps,
                                        out_dtype=_ln_out_dtype(x))
         return K.shuffle_nchw(K.linear(t, self.linear) if t.is_cuda else self.linear(t), 1)
@@ -43,6 +44,7 @@ class PatchUnMerging(nn.Module):
         self.linear = nn.Linear(dim, dim, bias=False)
 
     def forward(self, x):
+        x = K.supported_input(x)
         t = K.unshuffle_nhwc_layernorm(x, self.norm.weight, self.norm.bias, 1, self.norm.eps,
                                        out_dtype=_ln_out_dtype(x))
         return K.shuffle_nchw(K.linear(t, self.linear) if t.is_cuda else self.linear(t), self.scale)
@@ -109,7 +111,7 @@ class ViTBlock(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        t = K.unshuffle_nhwc(x, 1).view(B, H * W, C)
+        t = K.unshuffle_nhwc(K.supported_input(x), 1).view(B, H * W, C)
         # both LayerNorms feed projections: under bf16 autocast they write bf16 padded rows directly
         n1 = K.layer_norm(t, self.ln1, for_projection=True)
         t = self.drop_path(self.msa(n1, H, W)) + t
