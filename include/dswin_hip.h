@@ -249,6 +249,17 @@ int dsw_sparse_disc_bwd(const void *dsd, int dsd_dtype, const void *x, int x_dty
 int dsw_colsum_blocks(long long rows);
 int dsw_colsum(const void *x, int dtype, long long rows, int cols, float *out, float *partial, void *stream);
 
+/* dsw_colsum without the caller scratch.  No counterpart in the reference: it exists for callers that cannot
+ * allocate device memory around a call - code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  The per-block partial sums live in a static device array inside the library
+ * (dsw_colsum_static_max_floats() floats = 4 MiB, held by every GPU the library runs on until the process
+ * ends); the call allocates and frees nothing.  dsw_colsum_blocks(rows) * cols must not exceed that size
+ * (DSW_EUNSUPPORTED otherwise, nothing launched).  The device the buffers live on must be the current device.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU race; calls in stream order do
+ * not.  Same kernels and summation order as dsw_colsum, so the same bits. */
+size_t dsw_colsum_static_max_floats(void);
+int dsw_colsum_static(const void *x, int dtype, long long rows, int cols, float *out, void *stream);
+
 /* Exponential moving average of a list of parameter tensors, in place:
  *   ema[i][e] = ema[i][e] * beta + one_minus_beta * cur[i][e]
  * replaces the per-parameter Python loop of toolkit/param_ema.py:9-17 (three elementwise launches per

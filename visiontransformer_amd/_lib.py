@@ -74,6 +74,8 @@ SIGNATURES = {
     "dsw_ema_update": (_I, [_I, _P, _P, _P, _I, _F, _F, _P]),
     "dsw_colsum_blocks": (_I, [ctypes.c_longlong]),
     "dsw_colsum": (_I, [_P, _I, ctypes.c_longlong, _I, _P, _P, _P]),
+    "dsw_colsum_static_max_floats": (_Z, []),
+    "dsw_colsum_static": (_I, [_P, _I, ctypes.c_longlong, _I, _P, _P]),
     "dsw_dwconv3x3_bwd_blocks": (_I, [_I, _I, _I]),
     "dsw_dwconv3x3_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "dsw_sparse_disc_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),

@@ -6,6 +6,8 @@
 // All are bandwidth-bound: every kernel streams the activation once, 4 channels per lane, with the
 // small weight sets in LDS.  Parameter gradients use per-block partial sums reduced in a fixed
 // order (no atomics, bitwise reproducible).
+#include <mutex>
+
 #include "common.hpp"
 
 namespace dsw {
@@ -904,6 +906,53 @@ extern "C" int dsw_colsum(const void *x, int dtype, long long rows, int cols, fl
     if (rc) return rc;
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + PR_COLS - 1) / PR_COLS), dim3(256), 0, st, partial, nblk, cols, out);
     return check_launch("partial_reduce_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// dsw_colsum for callers that cannot allocate (code under HIP graph capture, tight serving loops):
+// the per-block partial sums live in a file-scope device array instead of a caller buffer.
+// Every GPU the library runs on holds its own copy of the array (4 MiB) at its own address; host
+// code must never pass the array's name to a kernel - it uses the per-device address obtained once
+// from hipGetSymbolAddress.  All calls on one GPU share that GPU's array: calls that overlap on one
+// GPU (two streams, two host threads) race.  Nothing in it has to start at zero: every block of
+// colsum_kernel writes all of its partial sums before partial_reduce_kernel reads them.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t CS_STATIC_FLOATS = (size_t)1 << 20;
+static __device__ __align__(256) float scratch[CS_STATIC_FLOATS];
+
+constexpr int CS_MAX_DEVICES = 64;
+static float *g_scratch_ptr[CS_MAX_DEVICES];   // per device, filled on the first call there
+static std::mutex g_scratch_mutex;
+
+static int static_scratch_for_current_device(float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(DSW_ELAUNCH, "dsw_colsum_static: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= CS_MAX_DEVICES) return fail(DSW_EUNSUPPORTED, "dsw_colsum_static: device index %d", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));   // the copy of the array on the current device
+        if (e != hipSuccess || p == nullptr)
+            return fail(DSW_ELAUNCH, "dsw_colsum_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<float *>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return DSW_OK;
+}
+
+extern "C" size_t dsw_colsum_static_max_floats(void) { return CS_STATIC_FLOATS; }
+
+extern "C" int dsw_colsum_static(const void *x, int dtype, long long rows, int cols, float *out, void *stream) {
+    if (rows <= 0 || cols <= 0) return fail(DSW_EINVAL, "dsw_colsum_static: bad sizes rows=%lld cols=%d", rows, cols);
+    const size_t need = (size_t)dsw_colsum_blocks(rows) * (size_t)cols;
+    if (need > CS_STATIC_FLOATS)
+        return fail(DSW_EUNSUPPORTED, "dsw_colsum_static: rows=%lld cols=%d needs %zu floats of scratch, the static buffer holds %zu "
+                    "(use dsw_colsum with a caller buffer)", rows, cols, need, CS_STATIC_FLOATS);
+    float *ptr = nullptr;
+    const int rc = static_scratch_for_current_device(&ptr);   // the device the caller made current (the stream's device)
+    if (rc) return rc;
+    return dsw_colsum(x, dtype, rows, cols, out, ptr, stream);
 }
 
 extern "C" int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, int dst_dtype, long long dst_ld,
