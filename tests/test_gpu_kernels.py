@@ -198,6 +198,8 @@ ATTN_CASES = [
     (16, 48, 3, "chunked", 2),      # head dim 16
     (8, 108, 2, "chunked", (1, 16, 8)),  # head dim 54 -> padded to 64
     (16, 21, 3, "interleaved", 2),  # odd head dim 7
+    (16, 108, 2, "chunked", 2),     # 16x16 windows with head dim 54 -> padded to 64
+    (16, 96, 3, "interleaved", (1, 16, 32)),  # head dim 32: no padding column left for the row constants
 ]
 
 
@@ -207,6 +209,8 @@ ATTN_CASES = [
 def test_window_attention(cuda0, dtype, bias, w, C, heads, layout, grid):
     K = _K()
     from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
+    if dtype == torch.float32 and w == 16 and C // heads > 32:
+        pytest.skip("fp32 operands of 16x16 windows at head dims above 32 do not fit a CU's LDS (DSW_EUNSUPPORTED)")
     gen = torch.Generator().manual_seed(C + w)
     L = w * w
     shape = (grid[0], grid[1], grid[2], 3 * C) if isinstance(grid, tuple) else (grid, L, 3 * C)
@@ -238,6 +242,42 @@ def test_window_attention(cuda0, dtype, bias, w, C, heads, layout, grid):
     assert torch.equal(out2, out) and torch.equal(q2.grad, q_g.grad)
     if bias:
         assert torch.equal(t2.grad, t_g.grad)
+
+
+@pytest.mark.parametrize("bias", [True, False])
+@pytest.mark.parametrize("C,heads,layout,grid", [(180, 6, "interleaved", (2, 32, 48)), (180, 6, "chunked", 7), (48, 3, "chunked", 3),
+                                                 (108, 2, "interleaved", (1, 32, 16))])
+def test_window_attention_backward_kernels_agree(cuda0, monkeypatch, bias, C, heads, layout, grid):
+    """16x16 windows in bf16 have two backward kernels: the two-phase one (no dS exchange between waves) and the
+    general one (DSW_ATTN_BWD_GENERAL=1).  Same gradients within bf16 rounding of the P / dS operands, and each
+    against the fp32 oracle."""
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
+    w = 16
+    gen = torch.Generator().manual_seed(C + len(layout))
+    shape = (grid[0], grid[1], grid[2], 3 * C) if isinstance(grid, tuple) else (grid, w * w, 3 * C)
+    qkv = torch.randn(shape, generator=gen).to(torch.bfloat16)
+    table = (torch.randn((2 * w - 1) ** 2, heads, generator=gen) * 0.5) if bias else None
+    r = torch.randn(shape[:-1] + (C,), generator=gen)
+    q_ref = qkv.float().clone().requires_grad_()
+    t_ref = None if table is None else table.clone().requires_grad_()
+    ref = D.window_attention_core(q_ref, t_ref, w, heads, layout, grid=grid if isinstance(grid, tuple) else None).reshape(r.shape)
+    (ref * r).sum().backward()
+    res = []
+    for general in ("0", "1"):
+        monkeypatch.setenv("DSW_ATTN_BWD_GENERAL", general)
+        q_g = qkv.to(cuda0).requires_grad_()
+        t_g = None if table is None else table.to(cuda0).requires_grad_()
+        out = K.window_attention(q_g, t_g, w, heads, QKV_CHUNKED if layout == "chunked" else QKV_INTERLEAVED,
+                                 grid=grid if isinstance(grid, tuple) else None)
+        (out.float() * r.to(cuda0)).sum().backward()
+        assert rel_err(q_g.grad, q_ref.grad) < TOL[torch.bfloat16]
+        if bias:
+            assert rel_err(t_g.grad, t_ref.grad) < TOL[torch.bfloat16]
+        res.append((q_g.grad, None if t_g is None else t_g.grad))
+    assert rel_err(res[0][0], res[1][0]) < 1e-2
+    if bias:
+        assert rel_err(res[0][1], res[1][1]) < 1e-2
 
 
 def test_window_attention_large_logits(cuda0):

@@ -15,6 +15,7 @@
 // registers along the table's diagonals and added into one private LDS table per wave (program
 // order inside a wave => bitwise reproducible), summed in wave order and written as a
 // per-(window, head) partial that a second kernel reduces over windows in a fixed order.
+#include <stdlib.h>
 #include <utility>
 
 #include "attn_common.hpp"
@@ -23,7 +24,6 @@
 
 namespace dsw {
 
-constexpr int BGW_STRIDE = 32, BGW_ROWS = 17;  // per-wave bias-gradient table (w = 16): [qi - kip + 1][dj + 15]
 
 template <typename T, int WS, int DP> struct BwdCfg {
     static constexpr bool BF = sizeof(T) == 2;
@@ -54,23 +54,6 @@ template <typename T, int WS, int DP> struct BwdCfg {
     static constexpr int MIN_WAVES = (WS == 16 && BF && DP == 32) ? 4 : (WS == 16 ? 2 : 2);
 };
 
-// 8 consecutive bf16 (or DP/2 floats handled by the caller) of a global row, zero past d
-__device__ __forceinline__ uint4 load_bf16x8_masked(const bf16_t *row, int e0, int d) {
-    uint32_t v[4];
-    if ((d & 1) == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (e0 + 2 * i < d) ? *reinterpret_cast<const uint32_t *>(row + e0 + 2 * i) : 0u;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t lo = (e0 + 2 * i < d) ? row[e0 + 2 * i] : 0u;
-            const uint32_t hi = (e0 + 2 * i + 1 < d) ? row[e0 + 2 * i + 1] : 0u;
-            v[i] = lo | (hi << 16);
-        }
-    }
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
 // ---- d(bias table) for 16 x 16 windows: diagonal sums in registers ---------------------------------
 // In a dS tile (query = row = register, key = column = lane) the table entry of an element is
 // (di, dj) = (qi - ki, qj - kj).  Rotating each register's 16-lane rows left by its qj puts every
@@ -92,24 +75,6 @@ __device__ __forceinline__ void diag_sums(std::integer_sequence<int, R...>, cons
                                           float (&all)[2], float (&wrapped)[2]) {
     (diag_step<R>(ds, wrap, all, wrapped), ...);
 }
-// lanes 32-63: rotate the 16-lane rows left by 4 more; lanes 0-31 unchanged
-__device__ __forceinline__ float upper_rows_rot4(float x) {
-    const int xi = __float_as_int(x);
-    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x120 + 12, 0xC, 0xF, false));
-}
-// lanes 0-15 receive the value of lane + 16, lanes 32-47 that of lane + 16 (v_permlane16_swap)
-__device__ __forceinline__ float rows_odd_to_even(float x) {
-    const unsigned xi = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
-    return __uint_as_float(r[1]);
-}
-// lanes 0-31 receive the value of lane + 32 (v_permlane32_swap); lanes 32-63 are unspecified
-__device__ __forceinline__ float upper_half_to_lower(float x) {
-    const unsigned xi = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
-    return __uint_as_float(r[1]);
-}
-
 template <typename T, int WS, int DP, bool BIAS, bool PAIR>
 __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::MIN_WAVES)) void win_attn_bwd_kernel(
     AttnGeom g, const T *__restrict__ qkv, const T *__restrict__ out, const T *__restrict__ dout,
@@ -662,25 +627,35 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
     }
 }
 
-// d_table[t][h] = sum over windows of ws[(win*heads + h)*T + t], in a fixed order: 16 window
-// groups (window index mod 16) summed by 16 threads each, then the 16 partials in group order.
+// d_table[t][h] = sum over windows of ws[(win*heads + h)*T + t], in a fixed order: 64 window groups (window
+// index mod 64) each summed by one thread with four loads in flight, then the 64 partials in group order.
 // A block takes 16 consecutive entries t of one head: each read instruction covers 64-byte runs of ws.
-__global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int heads, int T,
-                                                               float *__restrict__ d_table) {
-    __shared__ float part[16][17];
+__global__ __launch_bounds__(1024) void bias_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int heads, int T,
+                                                                float *__restrict__ d_table) {
+    constexpr int GROUPS = 64;
+    __shared__ float part[GROUPS][17];
     const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int chunks = (T + 15) / 16;
     const int h = blockIdx.x / chunks, t = (blockIdx.x - h * chunks) * 16 + e;
-    float acc = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (t < T) {
-        for (int wdx = grp; wdx < n_win; wdx += 16) acc += ws[((size_t)wdx * heads + h) * T + t];
+        const float *p = ws + (size_t)h * T + t;
+        const size_t step = (size_t)heads * T;
+        int wdx = grp;
+        for (; wdx + 3 * GROUPS < n_win; wdx += 4 * GROUPS) {
+            a0 += p[(size_t)wdx * step];
+            a1 += p[(size_t)(wdx + GROUPS) * step];
+            a2 += p[(size_t)(wdx + 2 * GROUPS) * step];
+            a3 += p[(size_t)(wdx + 3 * GROUPS) * step];
+        }
+        for (; wdx < n_win; wdx += GROUPS) a0 += p[(size_t)wdx * step];
     }
-    part[grp][e] = acc;
+    part[grp][e] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (grp == 0 && t < T) {
         float tot = 0.f;
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) tot += part[k2][e];
+#pragma unroll 8
+        for (int k2 = 0; k2 < GROUPS; ++k2) tot += part[k2][e];
         d_table[(size_t)t * heads + h] = tot;
     }
 }
@@ -790,6 +765,12 @@ __global__ __launch_bounds__(256) void lepe_grad_reduce_kernel(const float *__re
     else d_b[c] = acc;
 }
 
+// DSW_ATTN_BWD_GENERAL=1 in the environment sends every shape to the general kernel (tests compare the two)
+static bool force_general_bwd() {
+    const char *e = getenv("DSW_ATTN_BWD_GENERAL");
+    return e != nullptr && e[0] == '1';
+}
+
 template <typename T, int WS, int DP>
 static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const void *dout, const float *table,
                       float scale, const float *lepe_w, const float *lepe_b, const float *lse, void *dqkv,
@@ -826,7 +807,16 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
     } while (0)
     constexpr bool BF16 = sizeof(T) == 2;
     const bool pair = BF16 && (g.d % 2 == 0);
-    if constexpr (BF16) {
+    bool launched = false;
+    if constexpr (BF16 && WS == 16) {
+        if (!lepe && !force_general_bwd()) {  // the two-phase kernel (attn_bwd_w16.hip) takes even head dims <= DP - 2
+            const int r2 = launch_bwd_w16_two_phase(g, qkv, out, dout, table, scale, lse, dqkv, ws_table, st);
+            if (r2 > 0) return r2;
+            launched = r2 == DSW_OK;
+        }
+    }
+    if (launched) {
+    } else if constexpr (BF16) {
         if (bias && pair) DSW_BWD_LAUNCH(true, true);
         else if (bias) DSW_BWD_LAUNCH(true, false);
         else if (pair) DSW_BWD_LAUNCH(false, true);
@@ -840,7 +830,7 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
     if (rc) return rc;
     if (bias) {
         const int T2 = (2 * WS - 1) * (2 * WS - 1);
-        hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(g.heads * ((T2 + 15) / 16)), dim3(256), 0, st, ws_table,
+        hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(g.heads * ((T2 + 15) / 16)), dim3(1024), 0, st, ws_table,
                            g.n_win, g.heads, T2, d_table);
         rc = check_launch("bias_grad_reduce_kernel");
         if (rc) return rc;

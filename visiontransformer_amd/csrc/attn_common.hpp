@@ -88,4 +88,48 @@ template <int WS> struct bias_lds {
     static constexpr int FLOATS = ROWS * TS;
 };
 
+
+constexpr int BGW_STRIDE = 32, BGW_ROWS = 17;  // per-wave bias-gradient table (w = 16): [qi - kip + 1][dj + 15]
+
+// 8 consecutive bf16 (or DP/2 floats handled by the caller) of a global row, zero past d
+__device__ __forceinline__ uint4 load_bf16x8_masked(const bf16_t *row, int e0, int d) {
+    uint32_t v[4];
+    if ((d & 1) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (e0 + 2 * i < d) ? *reinterpret_cast<const uint32_t *>(row + e0 + 2 * i) : 0u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = (e0 + 2 * i < d) ? row[e0 + 2 * i] : 0u;
+            const uint32_t hi = (e0 + 2 * i + 1 < d) ? row[e0 + 2 * i + 1] : 0u;
+            v[i] = lo | (hi << 16);
+        }
+    }
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// lanes 32-63: rotate the 16-lane rows left by 4 more; lanes 0-31 unchanged
+__device__ __forceinline__ float upper_rows_rot4(float x) {
+    const int xi = __float_as_int(x);
+    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x120 + 12, 0xC, 0xF, false));
+}
+// lanes 0-15 receive the value of lane + 16, lanes 32-47 that of lane + 16 (v_permlane16_swap)
+__device__ __forceinline__ float rows_odd_to_even(float x) {
+    const unsigned xi = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    return __uint_as_float(r[1]);
+}
+// lanes 0-31 receive the value of lane + 32 (v_permlane32_swap); lanes 32-63 are unspecified
+__device__ __forceinline__ float upper_half_to_lower(float x) {
+    const unsigned xi = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    return __uint_as_float(r[1]);
+}
+
+// backward for 16 x 16 windows in bf16 without any exchange of dS between waves (attn_bwd_w16.hip); returns
+// DSW_OK after launching, or a negative value when the shape is not one it takes (the caller then uses
+// the general kernel)
+int launch_bwd_w16_two_phase(const AttnGeom &g, const void *qkv, const void *out, const void *dout, const float *table,
+                             float scale, const float *lse, void *dqkv, float *ws_table, hipStream_t st);
+
 }  // namespace dsw
