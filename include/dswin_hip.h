@@ -73,11 +73,13 @@ int dsw_select_fwd(const void *sd, const void *sig, int sd_dtype, const float *n
  * fp32 are the incoming gradients of the two straight-through values; d_scores [B,Hw*Ww] fp32
  * receives the softmax-Jacobian product (probs*(dp - sum(probs*dp)))/tau, d_gate [B,Hw*Ww]
  * fp32 the gradient of sig channel 0 (zero for windows that did not pass).  The offsets get no
- * gradient, as in the reference (.long() at DSwinT_arch.py:232-233).  n_win is read on the
- * host side by the caller (it sizes the saved tensors). */
+ * gradient, as in the reference (.long() at DSwinT_arch.py:232-233).  n_win is the number of window
+ * slots handed over: the pass count read on the host, or all B*k slots with n_live (may be NULL) = the
+ * device counter n_pass of dsw_select_fwd - slots from *n_live on are ignored, so a caller that never
+ * reads the count on the host (DSwinT_arch.py:291 does, through numel()) gets the same gradients. */
 int dsw_select_bwd(const float *probs, const float *d_scores_delta, const float *d_gates_delta,
                    const int *win_b, const int *win_cell, int n_win, float tau,
-                   int B, int Hw, int Ww, float *d_scores, float *d_gate, void *stream);
+                   int B, int Hw, int Ww, float *d_scores, float *d_gate, const int *n_live, void *stream);
 
 /* dsw_select_fwd accepts sig = NULL: the three sigmoids of sd[:, 1:] (DSwinT_arch.py:269-270, :280)
  * are then taken inside the kernels, rounded to the activation dtype like the tensor op.
@@ -86,7 +88,7 @@ int dsw_select_bwd(const float *probs, const float *d_scores_delta, const float 
  * channels 2,3: zero - the offsets get no gradient, DSwinT_arch.py:232-233). */
 int dsw_select_bwd_sd(const float *probs, const float *d_scores_delta, const float *d_gates_delta,
                       const int *win_b, const int *win_cell, int n_win, float tau, int B, int Hw,
-                      int Ww, const void *sd, int sd_dtype, void *d_sd, void *stream);
+                      int Ww, const void *sd, int sd_dtype, void *d_sd, const int *n_live, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (2) Bilinear window gather.  Replaces the NHWC->NCHW copy (DSwinT_arch.py:259),
@@ -128,7 +130,9 @@ int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int afte
 /* Backward of (4).  dy [B,H,W,C] -> dx [B,H,W,C] (identity path + the -roi_align path),
  * d_after [n_win, w*w, C], d_gates_delta / d_scores_delta [n_win] fp32.
  * partial: caller-provided scratch of 2*n_win*w floats (per window-row partial sums, reduced
- * in a fixed order).  accumulate_dx != 0: dx is added into the buffer passed instead of written. */
+ * in a fixed order).  accumulate_dx != 0: dx is added into the buffer passed instead of written.
+ * n_live (may be NULL): device counter of the passing windows when n_win counts all B*k slots (see
+ * dsw_select_bwd); the slots from *n_live on get zero d_after rows and zero d_gates / d_scores. */
 int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype,
                          const void *after, int after_dtype, const float *gates_delta,
                          const float *scores_delta, const int *cellmap, const int *win_b,
@@ -136,7 +140,7 @@ int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtyp
                          int B, int H, int W, int C, int w, int ld_after,
                          void *dx, int dx_dtype, int accumulate_dx, void *d_after, int d_after_dtype,
                          int ld_d_after, float *d_gates_delta, float *d_scores_delta, float *partial,
-                         void *stream);
+                         const int *n_live, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (3)+(5) Fused window attention on MFMA: softmax(q k^T * scale + bias) v per (window, head),
@@ -213,7 +217,8 @@ int dsw_unshuffle_nhwc_fwd(const void *x, int dtype, int B, int c, int H, int W,
  * (DSwinT_arch.py:259, :317) disappears.  Weights and their gradients are fp32.
  *
  * identity_if_zero (forward, may be NULL): a device counter, e.g. dsw_select_fwd's n_pass; when it holds 0
- * the kernel copies x to y instead (the early return of DSwinT_arch.py:291-292 without a host read).
+ * the kernel copies x to y instead (the early return of DSwinT_arch.py:291-292 without a host read); the
+ * backward then passes dy through as dx and gives zero d_weight / d_bias.
  * dsw_dwconv3x3_fwd/bwd: depthwise 3x3, stride 1, zero padding 1 (out_conv, DSwinT_arch.py:198,
  *   :317).  weight [C,9], bias [C] or NULL.  bwd writes dx, d_weight [C,9], d_bias [C];
  *   partial: caller scratch of (dsw_dwconv3x3_bwd_blocks(B,H,W) + 1) * C * 10 floats.
@@ -229,7 +234,7 @@ int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const flo
 int dsw_dwconv3x3_bwd_blocks(int B, int H, int W);
 int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype, const float *weight,
                       int B, int H, int W, int C, void *dx, int dx_dtype, float *d_weight,
-                      float *d_bias, float *partial, void *stream);
+                      float *d_bias, float *partial, const int *identity_if_zero, void *stream);
 int dsw_sparse_disc_fwd(const void *x, int x_dtype, const float *w0, const float *b0,
                         const float *w2, const float *b2, const float *w4, const float *b4, int B,
                         int H, int W, int C, int w, float *t0, float *u, void *sd, int sd_dtype,

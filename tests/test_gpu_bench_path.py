@@ -101,10 +101,12 @@ def test_dsmsa_bf16_autocast_against_the_oracle(cuda0, training):
     assert cand.shape == (B, k) and all(len(set(row.tolist())) == k for row in cand)
     top = sel.probs.cpu().gather(1, cand)
     assert (top[:, 1:] <= top[:, :-1]).all()
-    assert 0 < sel.n < B * k, "the parameters above put gates on both sides of 0.5"
+    n_pass = int(sel.n_dev.item())    # the module itself never reads it on the host
+    assert sel.n == B * k and 0 < n_pass < B * k, "the parameters above put gates on both sides of 0.5"
     assert int(sel.win_h1.min()) >= 0 and int(sel.win_h1.max()) <= H - w and int(sel.win_w1.max()) <= W - w
 
-    forced = dict(cand_idx=cand, pass_mask=sel.cand_pass.cpu().reshape(-1).bool(), h1=sel.win_h1.cpu(), w1=sel.win_w1.cpu())
+    forced = dict(cand_idx=cand, pass_mask=sel.cand_pass.cpu().reshape(-1).bool(), h1=sel.win_h1.cpu()[:n_pass],
+                  w1=sel.win_w1.cpu()[:n_pass])
     P = {kk: v.detach().clone().requires_grad_(v.is_floating_point()) for kk, v in mod.state_dict().items()}
     x_ref = x.clone().requires_grad_()
     aux = {}

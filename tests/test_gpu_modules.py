@@ -41,6 +41,28 @@ def test_dswt_wmsa_golden(cuda0, name):
 
 
 @pytest.mark.parametrize("name", golden_names("dswt_dsmsa"))
+def test_dswt_dsmsa_golden_with_the_host_read(cuda0, name):
+    """static_training = False: the pass count is read on the host and only the passing windows are processed"""
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    g, m = load_golden(name)
+    mod = _load_into(DeformableSparseWindowAttention(m["w"], m["C"], m["heads"]), g, cuda0)
+    mod.static_training = False
+    mod.num_win_selected = m["num_win_selected"]
+    mod.temperature = m["temperature"]
+    mod.train(m["training"])
+    mod.gumbel_noise = g["noise"].to(cuda0)
+    x = g["x"].to(cuda0).requires_grad_()
+    y = mod(x)
+    sel = mod.last_selection
+    if m["n_candidates"]:
+        assert sel.n == m["n_pass"] and sel.n_dev is None
+        if sel.n:
+            assert torch.equal(sel.win_h1.cpu().long(), g["aux.h1"]) and torch.equal(sel.win_w1.cpu().long(), g["aux.w1"])
+    assert rel_err(y, g["y"]) < TOL
+    _check_grads(mod, g, x, y, cuda0)
+
+
+@pytest.mark.parametrize("name", golden_names("dswt_dsmsa"))
 def test_dswt_dsmsa_golden(cuda0, name):
     from visiontransformer_amd.dswin import DeformableSparseWindowAttention
     g, m = load_golden(name)
@@ -59,12 +81,15 @@ def test_dswt_dsmsa_golden(cuda0, name):
         cand = sel.cand_idx.cpu().long().reshape(-1)
         assert torch.equal(cand // Ww, g["aux.cand_h"])
         assert torch.equal(cand % Ww, g["aux.cand_w"])
-        assert sel.n == m["n_pass"]
-        if sel.n:
-            assert torch.equal(sel.win_b.cpu().long(), g["aux.b_idx"])
-            assert torch.equal(sel.win_cell.cpu().long(), g["aux.h_idx"] * Ww + g["aux.w_idx"])
-            assert torch.equal(sel.win_h1.cpu().long(), g["aux.h1"])
-            assert torch.equal(sel.win_w1.cpu().long(), g["aux.w1"])
+        # the default path never reads the pass count on the host: all B*k slots, count on the device
+        assert sel.n == m["n_candidates"] and sel.n_dev is not None
+        n = int(sel.n_dev.item())
+        assert n == m["n_pass"]
+        if n:
+            assert torch.equal(sel.win_b.cpu().long()[:n], g["aux.b_idx"])
+            assert torch.equal(sel.win_cell.cpu().long()[:n], g["aux.h_idx"] * Ww + g["aux.w_idx"])
+            assert torch.equal(sel.win_h1.cpu().long()[:n], g["aux.h1"])
+            assert torch.equal(sel.win_w1.cpu().long()[:n], g["aux.w1"])
     assert rel_err(y, g["y"]) < TOL
     _check_grads(mod, g, x, y, cuda0)
 
@@ -92,7 +117,7 @@ def test_dsmsa_fused_input_gradient(cuda0, autocast):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
             y = x + mod(x)
         (y.float() * dy).sum().backward()
-        assert mod.last_selection.n > 0
+        assert int(mod.last_selection.n_dev.item()) > 0
         got = {"x": x.grad.clone(), **{k: p.grad.clone() for k, p in mod.named_parameters()}}
         if not fuse:
             res = got
@@ -124,31 +149,49 @@ def test_padded_rows_travel_between_kernels_and_projections(cuda0):
         assert mod(x).is_contiguous()
 
 
-def test_dsmsa_bf16_autocast_against_fp32(cuda0):
-    """the trainer's mode: bf16 autocast.  Same module, same weights: selection must be a valid
-    selection (k candidates per image, distinct cells) and values within 2e-2 of the fp32 run
-    whenever both runs picked the same windows."""
+@pytest.mark.parametrize("gates", ["mixed", "closed"])
+@pytest.mark.parametrize("autocast", [False, True])
+def test_dsmsa_training_without_the_host_read(cuda0, gates, autocast):
+    """static_training (the default): no host read of the pass count in forward or backward.  Same output and
+    gradients as the path that reads it; with every gate closed the module returns its input (DSwinT_arch.py:
+    291-292), the gradient passes through to x, and every parameter still receives a (zero) gradient - which is
+    what lets DistributedDataParallel run without find_unused_parameters."""
     from visiontransformer_amd.dswin import DeformableSparseWindowAttention
-    torch.manual_seed(0)
-    mod = DeformableSparseWindowAttention(16, 180, 6).to(cuda0)
+    torch.manual_seed(7)
+    mod = DeformableSparseWindowAttention(16, 180, 6).to(cuda0).train()
     with torch.no_grad():
         mod.sparse_discriminator[4].weight.mul_(8.0)
-        mod.sparse_discriminator[4].bias[1] += 1.0
+        mod.sparse_discriminator[4].bias[1] += -30.0 if gates == "closed" else 0.3
         mod.pe.relative_position_bias_table.normal_(0, 0.5)
-    mod.train()
-    x = torch.randn(4, 64, 64, 180, device=cuda0)
-    mod.gumbel_noise = -torch.empty(4, 16, device=cuda0).exponential_().log()
-    y32 = mod(x)
-    s32 = mod.last_selection
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        y16 = mod(x)
-    s16 = mod.last_selection
-    assert s16.cand_idx.shape == (4, 4)
-    assert all(len(set(r.tolist())) == 4 for r in s16.cand_idx.cpu())
-    assert y16.dtype == torch.bfloat16
-    if s32.n == s16.n and torch.equal(s32.win_cell, s16.win_cell) and torch.equal(s32.win_h1, s16.win_h1) \
-            and torch.equal(s32.win_w1, s16.win_w1):
-        assert rel_err(y16, y32) < 2e-2
+    x = torch.randn(3, 64, 48, 180, device=cuda0, requires_grad=True)
+    mod.gumbel_noise = -torch.empty(3, 12, device=cuda0).exponential_().log()
+    dy = torch.randn(3, 64, 48, 180, device=cuda0)
+    res = {}
+    for static in (False, True):
+        mod.static_training = static
+        mod.zero_grad(set_to_none=True)
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            y = mod(x)
+        (y.float() * dy).sum().backward()
+        sel = mod.last_selection
+        n = sel.n if sel.n_dev is None else int(sel.n_dev.item())
+        res[static] = dict(y=y.detach().float(), x=x.grad.clone(), n=n,
+                           p={k: (None if p.grad is None else p.grad.clone()) for k, p in mod.named_parameters()})
+    assert res[True]["n"] == res[False]["n"] and (res[True]["n"] == 0) == (gates == "closed")
+    tol = 2e-2 if autocast else 1e-5
+    assert rel_err(res[True]["y"], res[False]["y"]) < tol
+    assert rel_err(res[True]["x"], res[False]["x"]) < tol
+    for k, g_static in res[True]["p"].items():
+        assert g_static is not None and torch.isfinite(g_static).all(), k
+        g_dyn = res[False]["p"][k]
+        if g_dyn is None or float(g_dyn.abs().max()) == 0.0:     # unused on the host-read path (early return / offsets)
+            assert float(g_static.abs().max()) == 0.0, k
+        else:
+            assert rel_err(g_static, g_dyn) < tol, k
+    if gates == "closed":
+        assert torch.equal(res[True]["y"], x.detach().to(y.dtype).float())
+        assert rel_err(res[True]["x"], dy) < (1e-2 if autocast else 1e-6)
 
 
 # ----------------------------------------------------------------------------------------------

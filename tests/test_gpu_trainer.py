@@ -103,3 +103,35 @@ def test_training_step_under_whole_model_checkpointing(cuda0, kind, deterministi
         y_val = checkpoint(ema_model, lr, use_reentrant=False)
         y_ref = model(lr)
     assert torch.isfinite(y_val).all() and rel_err(y_val, y_ref) < 2e-2
+
+
+def test_ddp_without_unused_parameter_search_when_no_window_passes(cuda0, tmp_path):
+    """DistributedDataParallel with find_unused_parameters=False (what toolkit/init.py:131 constructs) around a
+    DSWT block whose DS-MSA gates are all closed, under whole-model non-reentrant checkpointing
+    (toolkit/model_helper2.py:115), two steps in a row: the reducer raises on the second forward if any parameter
+    was left without a gradient in the first.  One-rank group (gloo) - the reducer's bookkeeping is the same."""
+    import torch.distributed as dist
+    from visiontransformer_amd import models
+    assert not dist.is_initialized()
+    dist.init_process_group("gloo", init_method="file://%s" % (tmp_path / "pg"), rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        blk = models.DSWTViTBlock(16, 48, n_heads=2).to(cuda0).train()
+        with torch.no_grad():
+            blk.sdwa.sparse_discriminator[4].weight.zero_()
+            blk.sdwa.sparse_discriminator[4].bias[1] = -30.0        # every gate closed
+            for r in (blk.rezero1, blk.rezero2, blk.rezero3):
+                r.fill_(0.5)
+        ddp = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[cuda0.index], find_unused_parameters=False)
+        x = torch.randn(2, 32, 32, 48, device=cuda0)
+        for step in range(2):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = checkpoint(ddp, x, use_reentrant=False)
+            y.float().square().mean().backward()
+            assert int(blk.sdwa.last_selection.n_dev.item()) == 0
+            for n, p in blk.named_parameters():
+                assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            assert float(blk.sdwa.in_proj.weight.grad.abs().max()) == 0.0
+            ddp.zero_grad(set_to_none=True)
+    finally:
+        dist.destroy_process_group()

@@ -27,13 +27,13 @@ SIGNATURES = {
     "dswin_version": (_I, []),
     "dswin_last_error_string": (ctypes.c_char_p, []),
     "dsw_select_fwd": (_I, [_P, _P, _I, _P, _F] + [_I] * 7 + [_P] * 12 + [_P]),
-    "dsw_select_bwd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
-    "dsw_select_bwd_sd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _I, _P, _P]),
+    "dsw_select_bwd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
+    "dsw_select_bwd_sd": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _I, _P, _P, _P]),
     "dsw_gather_fwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 6 + [_P, _I, _I, _P]),
     "dsw_gather_bwd": (_I, [_P, _I, _P, _P, _P] + [_I] * 7 + [_P, _I, _I, _P]),
     "dsw_scatter_mean_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 7 + [_P, _I, _P]),
     "dsw_scatter_mean_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 7 +
-                             [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
+                             [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "dsw_win_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "dsw_win_attn_bwd_workspace": (_Z, [_I] * 8),
     "dsw_win_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P,
@@ -77,7 +77,7 @@ SIGNATURES = {
     "dsw_colsum_static_max_floats": (_Z, []),
     "dsw_colsum_static": (_I, [_P, _I, ctypes.c_longlong, _I, _P, _P]),
     "dsw_dwconv3x3_bwd_blocks": (_I, [_I, _I, _I]),
-    "dsw_dwconv3x3_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "dsw_dwconv3x3_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     "dsw_sparse_disc_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "dsw_sparse_disc_bwd_blocks": (_I, [_I, _I]),
     "dsw_sparse_disc_bwd_scratch": (_Z, [_I, _I, _I, _I, _I]),

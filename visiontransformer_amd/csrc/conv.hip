@@ -616,12 +616,15 @@ __global__ __launch_bounds__(WG_THREADS) void sd_bwd_w0_kernel(const float *__re
 }
 
 // packed [C][10] -> d_weight [C][9], d_bias [C]
-__global__ void split10_kernel(const float *__restrict__ packed, int C, float *__restrict__ dw, float *__restrict__ db) {
+// zero_if_zero: a device counter; when it holds 0 the gradients are zero (the forward was the identity)
+__global__ void split10_kernel(const float *__restrict__ packed, int C, float *__restrict__ dw, float *__restrict__ db,
+                               const int *__restrict__ zero_if_zero) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * 10) return;
     const int c = i / 10, k = i - c * 10;
-    if (k < 9) dw[c * 9 + k] = packed[i];
-    else db[c] = packed[i];
+    const float v = (zero_if_zero != nullptr && *zero_if_zero == 0) ? 0.f : packed[i];
+    if (k < 9) dw[c * 9 + k] = v;
+    else db[c] = v;
 }
 // packed [n0 + n1] -> a [n0], b [n1]
 __global__ void copy2_kernel(const float *__restrict__ packed, int n0, int n1, float *__restrict__ a, float *__restrict__ b) {
@@ -717,7 +720,7 @@ extern "C" int dsw_dwconv3x3_bwd_blocks(int B, int H, int W) {
 
 extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype, const float *weight, int B,
                                  int H, int W, int C, void *dx, int dx_dtype, float *d_weight, float *d_bias,
-                                 float *partial, void *stream) {
+                                 float *partial, const int *identity_if_zero, void *stream) {
     int rc = check_conv("dsw_dwconv3x3_bwd", B, H, W, C);
     if (rc) return rc;
     DSW_REQUIRE(dy && x && weight && dx && d_weight && d_bias && partial, "dsw_dwconv3x3_bwd: null pointer");
@@ -726,7 +729,7 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
     const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
         hipLaunchKernelGGL((dwconv_stream_kernel<TG, TO, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds, st,
-                           (const TG *)dy, weight, (const float *)nullptr, H, W, C, segs, (TO *)dx, (const int *)nullptr);
+                           (const TG *)dy, weight, (const float *)nullptr, H, W, C, segs, (TO *)dx, identity_if_zero);
     }));
     rc = check_launch("dwconv_stream_kernel<flip>");
     if (rc) return rc;
@@ -748,7 +751,7 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((C * 10 + PR_COLS - 1) / PR_COLS), dim3(256), 0, st, partial, nblocks, C * 10, packed);
     rc = check_launch("partial_reduce_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(split10_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, packed, C, d_weight, d_bias);
+    hipLaunchKernelGGL(split10_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, packed, C, d_weight, d_bias, identity_if_zero);
     return check_launch("split10_kernel");
 }
 

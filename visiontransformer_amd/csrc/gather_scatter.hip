@@ -256,11 +256,22 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_win_kernel(
     const float *__restrict__ gates_delta, const float *__restrict__ scores_delta,
     const int *__restrict__ cellmap, const int *__restrict__ win_b, const int *__restrict__ win_h1,
     const int *__restrict__ win_w1, int H, int W, int C, int w, int lda, int ldd, TO *__restrict__ d_after,
-    float *__restrict__ partial) {
+    float *__restrict__ partial, const int *__restrict__ n_live) {
     __shared__ float inv_cnt[64];
     __shared__ float red[GS_THREADS / 64];
     const int Hw = H / w, Ww = W / w;
     const int n = blockIdx.x / w, i = blockIdx.x - n * w;
+    if (n_live != nullptr && n >= *n_live) {
+        // a window slot behind the passing ones (callers that never read the count on the host hand over all
+        // B*k slots): nothing was written back from it, so its gradients are zero
+        for (int it = threadIdx.x; it < w * (ldd >> 2); it += GS_THREADS)
+            io<TO>::st4(d_after + ((size_t)n * w * w + (size_t)i * w) * ldd + ((size_t)it << 2), f4zero());
+        if (threadIdx.x == 0) {
+            partial[((size_t)n * w + i) * 2 + 0] = 0.f;
+            partial[((size_t)n * w + i) * 2 + 1] = 0.f;
+        }
+        return;
+    }
     const int b = win_b[n], y = win_h1[n] + i, x0 = win_w1[n];
     if (threadIdx.x < w) {
         const Cover cv = find_cover(cellmap, win_h1, win_w1, b, y, x0 + threadIdx.x, Hw, Ww, w);
@@ -393,7 +404,7 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
                                     const int *win_h1, const int *win_w1, int n_win, int B, int H, int W,
                                     int C, int w, int ld_after, void *dx, int dx_dtype, int accumulate_dx,
                                     void *d_after, int d_after_dtype, int ld_d_after, float *d_gates_delta,
-                                    float *d_scores_delta, float *partial, void *stream) {
+                                    float *d_scores_delta, float *partial, const int *n_live, void *stream) {
     int rc = check_geometry("dsw_scatter_mean_bwd", B, H, W, C, w);
     if (rc) return rc;
     if (!ld_after) ld_after = C;
@@ -427,11 +438,11 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
         if (d_after_dtype == DSW_F32) {
             hipLaunchKernelGGL((scatter_bwd_win_kernel<TG, TX, TA, float>), dim3(n_win * w), dim3(GS_THREADS), 0, st,
                                (const TG *)dy, (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
-                               win_b, win_h1, win_w1, H, W, C, w, ld_after, ld_d_after, (float *)d_after, partial);
+                               win_b, win_h1, win_w1, H, W, C, w, ld_after, ld_d_after, (float *)d_after, partial, n_live);
         } else if (d_after_dtype == DSW_BF16) {
             hipLaunchKernelGGL((scatter_bwd_win_kernel<TG, TX, TA, bf16_t>), dim3(n_win * w), dim3(GS_THREADS), 0, st,
                                (const TG *)dy, (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
-                               win_b, win_h1, win_w1, H, W, C, w, ld_after, ld_d_after, (bf16_t *)d_after, partial);
+                               win_b, win_h1, win_w1, H, W, C, w, ld_after, ld_d_after, (bf16_t *)d_after, partial, n_live);
         } else {
             return fail(DSW_EUNSUPPORTED, "dsw_scatter_mean_bwd: d_after dtype %d", d_after_dtype);
         }

@@ -141,9 +141,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_bwd_kernel(
     const float *__restrict__ probs, const float *__restrict__ d_scores_delta,
     const float *__restrict__ d_gates_delta, const int *__restrict__ win_b,
     const int *__restrict__ win_cell, int n_win, float tau, int n, float *__restrict__ d_scores,
-    float *__restrict__ d_gate) {
+    float *__restrict__ d_gate, const int *__restrict__ n_live) {
     extern __shared__ __attribute__((aligned(16))) float dp[];
     float *red = dp + n;
+    if (n_live != nullptr) n_win = min(n_win, *n_live);  // the slots behind the passing windows hold nothing
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int j = tid; j < n; j += SEL_THREADS) {
         dp[j] = 0.f;
@@ -172,9 +173,11 @@ template <typename T>
 __global__ __launch_bounds__(SEL_THREADS) void select_bwd_sd_kernel(
     const float *__restrict__ probs, const float *__restrict__ d_scores_delta,
     const float *__restrict__ d_gates_delta, const int *__restrict__ win_b,
-    const int *__restrict__ win_cell, int n_win, float tau, int n, const T *__restrict__ sd, T *__restrict__ d_sd) {
+    const int *__restrict__ win_cell, int n_win, float tau, int n, const T *__restrict__ sd, T *__restrict__ d_sd,
+    const int *__restrict__ n_live) {
     extern __shared__ __attribute__((aligned(16))) float dp[];  // [n] d(p), [n] d(gate), reduction scratch
     float *dg = dp + n, *red = dg + n;
+    if (n_live != nullptr) n_win = min(n_win, *n_live);  // the slots behind the passing windows hold nothing
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int j = tid; j < n; j += SEL_THREADS) {
         dp[j] = 0.f;
@@ -245,7 +248,7 @@ extern "C" int dsw_select_fwd(const void *sd, const void *sig, int sd_dtype, con
 extern "C" int dsw_select_bwd(const float *probs, const float *d_scores_delta,
                               const float *d_gates_delta, const int *win_b, const int *win_cell,
                               int n_win, float tau, int B, int Hw, int Ww, float *d_scores,
-                              float *d_gate, void *stream) {
+                              float *d_gate, const int *n_live, void *stream) {
     DSW_REQUIRE(probs && d_scores && d_gate, "dsw_select_bwd: null pointer");
     DSW_REQUIRE(n_win == 0 || (d_scores_delta && d_gates_delta && win_b && win_cell), "dsw_select_bwd: null window arrays");
     DSW_REQUIRE(B > 0 && Hw > 0 && Ww > 0 && n_win >= 0 && tau > 0.f, "dsw_select_bwd: bad sizes");
@@ -257,13 +260,13 @@ extern "C" int dsw_select_bwd(const float *probs, const float *d_scores_delta,
         if (e != hipSuccess) return fail(DSW_ELAUNCH, "select_bwd: LDS attribute: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(select_bwd_kernel, dim3(B), dim3(SEL_THREADS), lds, as_stream(stream), probs, d_scores_delta,
-                       d_gates_delta, win_b, win_cell, n_win, tau, n, d_scores, d_gate);
+                       d_gates_delta, win_b, win_cell, n_win, tau, n, d_scores, d_gate, n_live);
     return check_launch("select_bwd_kernel");
 }
 
 extern "C" int dsw_select_bwd_sd(const float *probs, const float *d_scores_delta, const float *d_gates_delta,
                                  const int *win_b, const int *win_cell, int n_win, float tau, int B, int Hw, int Ww,
-                                 const void *sd, int sd_dtype, void *d_sd, void *stream) {
+                                 const void *sd, int sd_dtype, void *d_sd, const int *n_live, void *stream) {
     DSW_REQUIRE(probs && sd && d_sd, "dsw_select_bwd_sd: null pointer");
     DSW_REQUIRE(n_win == 0 || (d_scores_delta && d_gates_delta && win_b && win_cell), "dsw_select_bwd_sd: null window arrays");
     DSW_REQUIRE(B > 0 && Hw > 0 && Ww > 0 && n_win >= 0 && tau > 0.f, "dsw_select_bwd_sd: bad sizes");
@@ -277,7 +280,7 @@ extern "C" int dsw_select_bwd_sd(const float *probs, const float *d_scores_delta
             if (e != hipSuccess) return fail(DSW_ELAUNCH, "select_bwd_sd: LDS attribute: %s", hipGetErrorString(e));
         }
         hipLaunchKernelGGL(kern, dim3(B), dim3(SEL_THREADS), lds, as_stream(stream), probs, d_scores_delta, d_gates_delta,
-                           win_b, win_cell, n_win, tau, n, (const T *)sd, (T *)d_sd);
+                           win_b, win_cell, n_win, tau, n, (const T *)sd, (T *)d_sd, n_live);
     });
     return check_launch("select_bwd_sd_kernel");
 }

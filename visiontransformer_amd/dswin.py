@@ -158,10 +158,14 @@ class DeformableSparseWindowAttention(WindowedAttention):
         # True: the gradients of the three readers of x (sparse discriminator, gather, scatter
         # residual) are accumulated in one buffer inside the kernels instead of being added by autograd
         self.fuse_input_grads = True
-        # True: without autograd (inference) the number of windows that passed the gate is never read on the
-        # host: all candidates get a window slot, only the passing ones are written back.  Same values; the
-        # call does not stall the host, last_selection.n is then the slot count and .n_dev the pass count.
-        self.static_inference = True
+        # True: the number of windows that passed the gate is never read on the host (the reference reads it
+        # twice per call, DSwinT_arch.py:273, :291): all B*k candidates get a window slot, only the passing
+        # ones are written back, and in the backward the other slots receive and contribute exactly zero.
+        # Same values and gradients; the call does not stall the host, every parameter gets a gradient on
+        # every step (zeros when no window passed), last_selection.n is the slot count and .n_dev the pass
+        # count on the device.  False restores the host read and processes only the passing windows.
+        self.static_inference = True   # without autograd
+        self.static_training = True    # with autograd
 
     def _noise(self, scores_flat):
         if not self.training:
@@ -192,14 +196,15 @@ class DeformableSparseWindowAttention(WindowedAttention):
         if k == 0:  # DSwinT_arch.py:273-274
             return x
         noise = self._noise(sd[:, 0].reshape(B, -1))
-        if self.static_inference and not torch.is_grad_enabled() and not self.use_torch_convs:
+        static = self.static_training if torch.is_grad_enabled() else self.static_inference
+        if static and not self.use_torch_convs:
             sel = K.select_windows_static(sd, noise, self.temperature, k, w, H, W)
             self.last_selection = sel.detached()
-            before = K.gather_windows(x, sel, w, out_dtype=act, pad_out=True)
+            before = K.gather_windows(x, sel, w, out_dtype=act, sink=sink, pad_out=True)
             qkv = K.linear(before, self.in_proj, pad_out=True)
             z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
             after = K.linear(z, self.out_proj, pad_out=True)
-            y = K.scatter_mean_residual(x, after, sel, w)
+            y = K.scatter_mean_residual(x, after, sel, w, sink=sink)
             # no window passed (DSwinT_arch.py:291-292: return x): the last kernel copies instead of convolving
             return K.dwconv3x3_nhwc(y, self.out_conv.weight, self.out_conv.bias, out_dtype=act, identity_if_zero=sel.n_dev)
         sel = K.select_windows(sd, None, noise, self.temperature, k, w, H, W)  # sigmoids taken in the kernels

@@ -165,11 +165,11 @@ class _SelectFn(torch.autograd.Function):
         if sd is not None:  # the sigmoids were taken inside the forward kernels: one kernel, gradient of sd itself
             d_sd = torch.empty(B, 4, Hw, Ww, dtype=dt, device=dev)
             call("dsw_select_bwd_sd", ptr(probs), ptr(dsd), ptr(dgd), ptr(win_b), ptr(win_cell), npass, _c_float(tau),
-                 B, Hw, Ww, ptr(sd), dtype_code(dt), ptr(d_sd), stream(dev))
+                 B, Hw, Ww, ptr(sd), dtype_code(dt), ptr(d_sd), None, stream(dev))
             return d_sd, None, None, None, None, None, None, None
         grads = torch.empty(2, B, n, dtype=torch.float32, device=dev)
         call("dsw_select_bwd", ptr(probs), ptr(dsd), ptr(dgd), ptr(win_b), ptr(win_cell), npass, _c_float(tau),
-             B, Hw, Ww, ptr(grads[0]), ptr(grads[1]), stream(dev))
+             B, Hw, Ww, ptr(grads[0]), ptr(grads[1]), None, stream(dev))
         d_sd = torch.zeros(B, 4, Hw, Ww, dtype=dt, device=dev)
         d_sd[:, 0] = grads[0].view(B, Hw, Ww).to(dt)
         d_sig = torch.zeros(B, 3, Hw, Ww, dtype=dt, device=dev)  # offsets (channels 1, 2) get no gradient
@@ -187,35 +187,65 @@ def select_windows(sd, sig, noise, tau, k, w, H, W):
                      cand_pass=cand_pass, probs=probs)
 
 
+class _SelectStaticFn(torch.autograd.Function):
+    """dsw_select_fwd on all B * k window slots, the pass count staying on the device (see select_windows_static)"""
+
+    @staticmethod
+    def forward(ctx, sd, noise, tau, k, w, H, W):
+        _lib.require_cuda(sd, noise)
+        B, four, Hw, Ww = sd.shape
+        assert four == 4
+        sd = sd.contiguous()
+        n = Hw * Ww
+        dev = sd.device
+        if noise is not None:
+            noise = noise.to(torch.float32).contiguous()
+            assert noise.shape == (B, n)
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        probs = torch.empty(B, n, **f32)
+        cand_idx = torch.empty(B, k, **i32)
+        cand_p = torch.empty(B, k, **f32)
+        cand_pass = torch.empty(B, k, **i32)
+        n_pass = torch.empty(1, **i32)
+        win = torch.zeros(4, B * k, **i32)
+        deltas = torch.zeros(2, B * k, **f32)
+        cellmap = torch.empty(B, Hw, Ww, **i32)
+        call("dsw_select_fwd", ptr(sd), None, dtype_code(sd.dtype), ptr(noise), _c_float(tau), B, Hw, Ww, k, w, H, W, ptr(probs),
+             ptr(cand_idx), ptr(cand_p), ptr(cand_pass), ptr(n_pass), ptr(win[0]), ptr(win[1]), ptr(win[2]), ptr(win[3]),
+             ptr(deltas[0]), ptr(deltas[1]), ptr(cellmap), stream(dev))
+        ctx.save_for_backward(probs, win, sd, n_pass)
+        ctx.meta = (tau, B, Hw, Ww, k)
+        ctx.mark_non_differentiable(win, cellmap, cand_idx, cand_pass, probs, n_pass)
+        ctx.set_materialize_grads(False)
+        return deltas[0], deltas[1], win, cellmap, cand_idx, cand_pass, probs, n_pass
+
+    @staticmethod
+    def backward(ctx, d_scores_delta, d_gates_delta, *unused):
+        probs, win, sd, n_pass = ctx.saved_tensors
+        tau, B, Hw, Ww, k = ctx.meta
+        dev = probs.device
+        zero = lambda: torch.zeros(B * k, dtype=torch.float32, device=dev)
+        dsd = zero() if d_scores_delta is None else d_scores_delta.to(torch.float32).contiguous()
+        dgd = zero() if d_gates_delta is None else d_gates_delta.to(torch.float32).contiguous()
+        d_sd = torch.empty(B, 4, Hw, Ww, dtype=sd.dtype, device=dev)
+        call("dsw_select_bwd_sd", ptr(probs), ptr(dsd), ptr(dgd), ptr(win[0]), ptr(win[1]), B * k, _c_float(tau),
+             B, Hw, Ww, ptr(sd), dtype_code(sd.dtype), ptr(d_sd), ptr(n_pass), stream(dev))
+        return d_sd, None, None, None, None, None, None
+
+
 def select_windows_static(sd, noise, tau, k, w, H, W):
-    """select_windows without the host read of the number of passing windows, for inference: every
-    candidate gets a window slot (B * k of them); the slots behind the passing ones hold a harmless
-    window (image 0, corner 0,0) that the cell map never points to, so the gather / attention /
-    projections run on all slots and the scatter writes back only the passing ones.  Selection.n_dev is
-    the pass count on the device."""
-    _lib.require_cuda(sd, noise)
-    B, four, Hw, Ww = sd.shape
-    assert four == 4
-    sd = sd.contiguous()
-    n = Hw * Ww
-    dev = sd.device
-    if noise is not None:
-        noise = noise.to(torch.float32).contiguous()
-    i32 = dict(dtype=torch.int32, device=dev)
-    f32 = dict(dtype=torch.float32, device=dev)
-    probs = torch.empty(B, n, **f32)
-    cand_idx = torch.empty(B, k, **i32)
-    cand_p = torch.empty(B, k, **f32)
-    cand_pass = torch.empty(B, k, **i32)
-    n_pass = torch.empty(1, **i32)
-    win = torch.zeros(4, B * k, **i32)
-    deltas = torch.zeros(2, B * k, **f32)
-    cellmap = torch.empty(B, Hw, Ww, **i32)
-    call("dsw_select_fwd", ptr(sd), None, dtype_code(sd.dtype), ptr(noise), _c_float(tau), B, Hw, Ww, k, w, H, W, ptr(probs),
-         ptr(cand_idx), ptr(cand_p), ptr(cand_pass), ptr(n_pass), ptr(win[0]), ptr(win[1]), ptr(win[2]), ptr(win[3]),
-         ptr(deltas[0]), ptr(deltas[1]), ptr(cellmap), stream(dev))
-    return Selection(n=B * k, win_b=win[0], win_cell=win[1], win_h1=win[2], win_w1=win[3], cellmap=cellmap,
-                     scores_delta=deltas[0], gates_delta=deltas[1], cand_idx=cand_idx, cand_pass=cand_pass, probs=probs,
+    """select_windows without the host read of the number of passing windows (the reference has two such reads
+    per call, DSwinT_arch.py:273, :291): every candidate gets a window slot (B * k of them); the slots behind
+    the passing ones hold a harmless window (image 0, corner 0,0) with zero straight-through values that the
+    cell map never points to, so the gather / attention / projections run on all slots, the scatter writes
+    back only the passing ones, and in the backward the dead slots receive and contribute exactly zero.
+    Selection.n_dev is the pass count on the device.  The sigmoids of sd[:, 1:] are taken inside the kernels."""
+    out = _run(_SelectStaticFn, sd, noise, float(tau), int(k), int(w), int(H), int(W))
+    sdl, gdl, win, cellmap, cand_idx, cand_pass, probs, n_pass = out
+    B = sd.shape[0]
+    return Selection(n=B * int(k), win_b=win[0], win_cell=win[1], win_h1=win[2], win_w1=win[3], cellmap=cellmap,
+                     scores_delta=sdl, gates_delta=gdl, cand_idx=cand_idx, cand_pass=cand_pass, probs=probs,
                      n_dev=n_pass)
 
 
@@ -297,7 +327,7 @@ def gather_windows(x, sel, w, out_dtype=None, sink=None, pad_out=False):
 
 class _ScatterMeanFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, w, sink):
+    def forward(ctx, x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, w, sink, n_live=None):
         _lib.require_cuda(x, after)
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -310,7 +340,7 @@ class _ScatterMeanFn(torch.autograd.Function):
         call("dsw_scatter_mean_fwd", ptr(x), dtype_code(x.dtype), _dptr(after), dtype_code(after.dtype),
              ptr(gates_delta), ptr(scores_delta), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
              B, H, W, C, w, lda, ptr(y), dtype_code(y.dtype), stream(x.device))
-        ctx.save_for_backward(x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1)
+        ctx.save_for_backward(x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, n_live)
         ctx.w = w
         ctx.sink = sink
         ctx.after_meta = (after_shape, lda)
@@ -318,7 +348,7 @@ class _ScatterMeanFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1 = ctx.saved_tensors
+        x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, n_live = ctx.saved_tensors
         w = ctx.w
         B, H, W, C = x.shape
         n = win_b.numel()
@@ -334,15 +364,16 @@ class _ScatterMeanFn(torch.autograd.Function):
         call("dsw_scatter_mean_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype),
              _dptr(after), dtype_code(after.dtype), ptr(gates_delta), ptr(scores_delta), ptr(cellmap),
              ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, lda, ptr(dx), dtype_code(dx.dtype), acc,
-             ptr(d_after), dtype_code(d_after.dtype), lda, ptr(dg[0]), ptr(dg[1]), ptr(partial), stream(dev))
-        return _dx_deliver(sink, dx), d_after[:, :C].view(after_shape), dg[0], dg[1], None, None, None, None, None, None
+             ptr(d_after), dtype_code(d_after.dtype), lda, ptr(dg[0]), ptr(dg[1]), ptr(partial),
+             None if n_live is None else ptr(n_live), stream(dev))
+        return _dx_deliver(sink, dx), d_after[:, :C].view(after_shape), dg[0], dg[1], None, None, None, None, None, None, None
 
 
 def scatter_mean_residual(x, after, sel, w, sink=None):
     """x + mean over covering windows of (after - roi_align(x)) * gates * scores
     (DSwinT_arch.py:308-315), NHWC in and out.  `sink`: see GradSink."""
     return _run(_ScatterMeanFn, x, after, sel.gates_delta, sel.scores_delta, sel.cellmap, sel.win_b,
-                                sel.win_h1, sel.win_w1, int(w), sink)
+                                sel.win_h1, sel.win_w1, int(w), sink, sel.n_dev)
 
 
 def _row_view(t, n):
@@ -550,13 +581,13 @@ class _DWConvFn(torch.autograd.Function):
         y = torch.empty(B, H, W, C, dtype=out_dtype, device=x.device)
         call("dsw_dwconv3x3_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(y),
              dtype_code(out_dtype), None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
-        ctx.save_for_backward(x, w32)
+        ctx.save_for_backward(x, w32, identity_if_zero)
         ctx.meta = (weight.shape, weight.dtype, None if bias is None else bias.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w32 = ctx.saved_tensors
+        x, w32, ident = ctx.saved_tensors
         wshape, wdt, bdt = ctx.meta
         B, H, W, C = x.shape
         dev = x.device
@@ -567,16 +598,14 @@ class _DWConvFn(torch.autograd.Function):
         nblk = _lib.load().dsw_dwconv3x3_bwd_blocks(B, H, W)
         partial = torch.empty((nblk + 1) * C * 10, dtype=torch.float32, device=dev)
         call("dsw_dwconv3x3_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype), ptr(w32), B, H, W, C,
-             ptr(dx), dtype_code(dx.dtype), ptr(dw), ptr(db), ptr(partial), stream(dev))
+             ptr(dx), dtype_code(dx.dtype), ptr(dw), ptr(db), ptr(partial), None if ident is None else ptr(ident), stream(dev))
         return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), None, None
 
 
 def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None, identity_if_zero=None):
     """Depthwise 3x3 conv, stride 1, zero padding 1, on an NHWC tensor (out_conv of DS-MSA,
     DSwinT_arch.py:198, :317).  weight [C,1,3,3].  identity_if_zero: an int32 device counter; the result
-    is x itself (cast) when it holds 0 (inference only: the backward does not look at it)."""
-    if identity_if_zero is not None and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        raise RuntimeError("dwconv3x3_nhwc: identity_if_zero is for inference")
+    is x itself (cast) when it holds 0, and the backward then passes the gradient through to x alone."""
     return _run(_DWConvFn, x, weight, bias, out_dtype or x.dtype, identity_if_zero)
 
 

@@ -40,15 +40,18 @@ def init_distributed(backend=None):
     return rank, world, device
 
 
-def data_parallel(model, device):
-    """Wrap for data-parallel training when a process group exists (gradient all-reduce in
-    buckets, overlapped with backward).  Every path of the kernel-backed modules returns
-    gradients for all parameters it used, and the early-return paths of DS-MSA leave the
-    attention parameters unused, hence find_unused_parameters."""
+def data_parallel(model, device, find_unused_parameters=False):
+    """Wrap for data-parallel training when a process group exists (gradient all-reduce in buckets,
+    overlapped with backward).  The kernel-backed modules give every parameter a gradient on every
+    step: DS-MSA's default path (static_training) never returns early - when no window passes the gate
+    its attention parameters receive zeros - so the reducer needs no search for unused parameters
+    (the reference's DDP call, toolkit/init.py:131, does not ask for one either).  Only a map with fewer
+    than 1 / num_win_selected windows (k == 0, DSwinT_arch.py:273) or static_training = False leaves
+    parameters without a gradient: pass find_unused_parameters=True for those."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
     ids = [device.index] if device.type == "cuda" else None
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=True)
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters)
 
 
 @dataclass
