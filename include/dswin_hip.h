@@ -159,12 +159,20 @@ int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtyp
  * ld_qkv, ld_out: row strides in elements of qkv (>= 3C) and out (>= C), even; 0 = dense rows.
  *        With ld_out > C the columns C..ld_out-1 of every out row are set to zero (rows padded
  *        to the widths the GEMM library is fast at go to the next projection as they are).
+ * dropout_p, dropout_seed: attention dropout on the softmax probabilities (DSwinT_arch.py:172: F.dropout in
+ *        training; msft_arch.py:136: SDPA's dropout_p, applied in eval() too).  No mask tensor: the keep
+ *        decision of element (window, head, query q, key k) is a hash of the seed and the element's position
+ *        that forward and backward both evaluate - pair index ((window*heads + head)*L + q)*L/2 + k/2 mod
+ *        2^32, x = (pair + seed_lo) ^ seed_hi put through the murmur3 finaliser (x ^= x>>16; x *= 0x85EBCA6B;
+ *        x ^= x>>13; x *= 0xC2B2AE35; x ^= x>>16); key k takes bits 0-15 (k even) or 16-31 (k odd) and is kept
+ *        when they are >= round(p * 65536); kept probabilities are scaled by 1/(1-p).  p in [0,1); 0 = none.
+ *        The backward must be given the p and seed of its forward.
  * Supported: w in {8,16}; head dim C/heads <= 64; dtype f32 (exact f32 MFMA) or bf16.
  */
 int dsw_win_attn_fwd(const void *qkv, int dtype, int layout, int n_img, int H, int W, int w,
                      int C, int heads, int ld_qkv, int ld_out, const float *bias_table,
                      float scale, const float *lepe_w, const float *lepe_b, void *out,
-                     float *lse, void *stream);
+                     float *lse, float dropout_p, unsigned long long dropout_seed, void *stream);
 
 /* bytes of scratch dsw_win_attn_bwd needs (per-(window,head) partial bias-table and LePE
  * weight gradients, reduced in a fixed order by a second kernel inside the call). */
@@ -181,7 +189,7 @@ int dsw_win_attn_bwd(const void *qkv, const void *out, const void *dout, int dty
                      int ld_dout, const float *bias_table, float scale, const float *lepe_w,
                      const float *lepe_b, const float *lse, void *dqkv, float *d_bias_table,
                      float *d_lepe_w, float *d_lepe_b, void *workspace, size_t workspace_bytes,
-                     void *stream);
+                     float dropout_p, unsigned long long dropout_seed, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (5) MSFT multi-scale reshapes, one pass each, no intermediate copies.

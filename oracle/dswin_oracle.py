@@ -73,10 +73,39 @@ def deheadify(x):
     return x.permute(0, 2, 1, 3).contiguous().view(N, L, -1)
 
 
-def attention(q, k, v, C, num_heads, attn_drop=0.0, pe=0, training=False):
-    """softmax(q k^T * (C//h)^-0.5 + pe) v  (DSwinT_arch.py:171-172)."""
+def dropout_keep_mask(n_win, num_heads, L, p, seed):
+    """The keep decisions of the build's in-kernel attention dropout, [n_win, h, L, L] bool, from the rule
+    include/dswin_hip.h states for dsw_win_attn_fwd (torch's own dropout draws cannot be reproduced across
+    devices, so - like the Gumbel noise - the randomness is made explicit): element (window, head, q, k) has pair
+    index ((window*h + head)*L + q)*L/2 + k/2 mod 2^32; x = (pair + seed_lo) ^ seed_hi goes through the murmur3
+    finaliser; key k takes bits 0-15 (k even) or 16-31 (k odd) of x and is kept when they are >= round(p*65536)."""
+    import numpy as np
+    thr = min(int(round(p * 65536.0)), 65535)
+    seed_lo, seed_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    rows = np.arange(n_win * num_heads * L, dtype=np.uint64).reshape(-1, 1)
+    pair = ((rows * np.uint64(L // 2) + np.arange(L // 2, dtype=np.uint64).reshape(1, -1)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = (pair + seed_lo) ^ seed_hi
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x85EBCA6B)
+        x ^= x >> np.uint32(13)
+        x *= np.uint32(0xC2B2AE35)
+        x ^= x >> np.uint32(16)
+    keep = np.empty((rows.shape[0], L), dtype=bool)
+    keep[:, 0::2] = (x & np.uint32(0xFFFF)) >= thr
+    keep[:, 1::2] = (x >> np.uint32(16)) >= thr
+    return torch.from_numpy(keep).view(n_win, num_heads, L, L)
+
+
+def attention(q, k, v, C, num_heads, attn_drop=0.0, pe=0, training=False, keep=None):
+    """softmax(q k^T * (C//h)^-0.5 + pe) v  (DSwinT_arch.py:171-172).  ``keep`` [N,h,L,L] bool makes the
+    dropout draw explicit: probabilities are multiplied by keep / (1 - attn_drop), what F.dropout does
+    with its own draw."""
     logits = (q @ k.transpose(-2, -1)) * (C // num_heads) ** -0.5 + pe
-    return F.dropout(logits.softmax(dim=-1), p=attn_drop, training=training) @ v
+    probs = logits.softmax(dim=-1)
+    if keep is not None:
+        return (probs * keep.to(probs.dtype) / (1.0 - attn_drop)) @ v
+    return F.dropout(probs, p=attn_drop, training=training) @ v
 
 
 # --------------------------------------------------------------------------- #
@@ -296,7 +325,7 @@ def dsmsa_forward(P, x, w, num_heads, training=False, noise=None, temperature=1.
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-def wmsa_forward(P, x, w, num_heads, attn_drop=0.0, training=False):
+def wmsa_forward(P, x, w, num_heads, attn_drop=0.0, training=False, keep=None):
     """DSWT WindowedMSA.forward (DSwinT_arch.py:331-338).  The 3C projection is
     headified first and then split per head: head h owns channels
     [h*3d, (h+1)*3d) and q,k,v are the thirds of that slice."""
@@ -305,7 +334,7 @@ def wmsa_forward(P, x, w, num_heads, attn_drop=0.0, training=False):
     qkv = F.linear(z, P["qkv.weight"], P["qkv.bias"])
     q, k, v = headify(qkv, num_heads).chunk(3, dim=-1)
     pe = rpe_bias(P["pe.relative_position_bias_table"], P["pe.relative_position_index"])
-    z = attention(q, k, v, C, num_heads, attn_drop=attn_drop, pe=pe, training=training)
+    z = attention(q, k, v, C, num_heads, attn_drop=attn_drop, pe=pe, training=training, keep=keep)
     z = F.linear(deheadify(z), P["out_proj.weight"], P["out_proj.bias"])
     return reverse_window_partition(z, w, H, W)
 
@@ -313,7 +342,7 @@ def wmsa_forward(P, x, w, num_heads, attn_drop=0.0, training=False):
 # --------------------------------------------------------------------------- #
 # Pieces the HIP kernels are compared against one by one
 # --------------------------------------------------------------------------- #
-def window_attention_core(qkv, table, w, num_heads, layout, grid=None):
+def window_attention_core(qkv, table, w, num_heads, layout, grid=None, attn_drop=0.0, keep=None):
     """Attention core on a packed 3C projection, output de-headified.
 
     layout "chunked": channels are q|k|v thirds, each split into heads
@@ -331,7 +360,7 @@ def window_attention_core(qkv, table, w, num_heads, layout, grid=None):
     else:
         q, k, v = headify(qkv, num_heads).chunk(3, dim=-1)
     pe = 0 if table is None else rpe_bias(table, relative_position_index(w).to(table.device))
-    out = deheadify(attention(q, k, v, C, num_heads, pe=pe))
+    out = deheadify(attention(q, k, v, C, num_heads, attn_drop=attn_drop, pe=pe, keep=keep))
     if grid is not None:
         out = reverse_window_partition(out, w, H, W)
     return out

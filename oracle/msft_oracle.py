@@ -38,7 +38,16 @@ def locally_enhanced_pe(v, H, W, win, num_heads, conv_w, conv_b):
     return vh, lepe
 
 
-def wmsa_forward(P, x, H, W, win, num_heads, attn_drop=0.0):
+def _sdpa(q, k, v, attn_drop, keep):
+    """F.scaled_dot_product_attention(q, k, v, dropout_p) (msft_arch.py:136); with ``keep`` [N,h,L,L] bool the
+    dropout draw is explicit (probabilities times keep / (1 - p), SDPA's own rule)."""
+    if keep is None:
+        return F.scaled_dot_product_attention(q, k, v, dropout_p=attn_drop)
+    probs = ((q @ k.transpose(-2, -1)) * q.shape[-1] ** -0.5).softmax(dim=-1)
+    return (probs * keep.to(probs.dtype) / (1.0 - attn_drop)) @ v
+
+
+def wmsa_forward(P, x, H, W, win, num_heads, attn_drop=0.0, keep=None):
     """msft WindowedMSA.forward (msft_arch.py:127-143): qkv Linear, q|k|v
     thirds, SDPA (scale d^-0.5, no bias, no mask) + LePE, out_proj."""
     qkv = F.linear(x, P["qkv.weight"], P["qkv.bias"])
@@ -46,7 +55,7 @@ def wmsa_forward(P, x, H, W, win, num_heads, attn_drop=0.0):
     q = window_partition(q, H, W, win, num_heads)
     k = window_partition(k, H, W, win, num_heads)
     v, lepe = locally_enhanced_pe(v, H, W, win, num_heads, P["pe_encoder.weight"], P["pe_encoder.bias"])
-    z = F.scaled_dot_product_attention(q, k, v, dropout_p=attn_drop) + lepe
+    z = _sdpa(q, k, v, attn_drop, keep) + lepe
     z = reverse_window_partition(z, H, W, win)
     return F.linear(z, P["out_proj.weight"], P["out_proj.bias"])
 

@@ -280,6 +280,53 @@ def test_window_attention_backward_kernels_agree(cuda0, monkeypatch, bias, C, he
         assert rel_err(res[0][1], res[1][1]) < 1e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("w,C,heads,layout,grid,bias,p", [
+    (8, 96, 6, "chunked", (2, 16, 24), False, 0.1),      # msft level block: head dim 16, SDPA's dropout_p
+    (8, 108, 2, "chunked", 3, False, 0.3),               # head dim 54
+    (16, 180, 6, "interleaved", (1, 32, 32), True, 0.2), # DSWT WindowedMSA shape with its bias table
+    (16, 48, 3, "chunked", 2, True, 0.5),
+])
+def test_window_attention_dropout(cuda0, dtype, w, C, heads, layout, grid, bias, p):
+    """Attention dropout inside the kernels (DSwinT_arch.py:172, msft_arch.py:136) against the oracle given the
+    SAME keep mask (oracle.dropout_keep_mask restates the rule of include/dswin_hip.h): output, dqkv and the
+    bias-table gradient; a different seed gives a different result; p = 0 is the plain kernel."""
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
+    gen = torch.Generator().manual_seed(C + w + int(100 * p))
+    L = w * w
+    shape = (grid[0], grid[1], grid[2], 3 * C) if isinstance(grid, tuple) else (grid, L, 3 * C)
+    n_win = grid[0] * (grid[1] // w) * (grid[2] // w) if isinstance(grid, tuple) else grid
+    qkv = torch.randn(shape, generator=gen).to(dtype)
+    table = (torch.randn((2 * w - 1) ** 2, heads, generator=gen) * 0.5) if bias else None
+    r = torch.randn(shape[:-1] + (C,), generator=gen)
+    seed = 0x0123456789ABCDEF + w
+    keep = D.dropout_keep_mask(n_win, heads, L, p, seed)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+    q_ref = qkv.float().clone().requires_grad_()
+    t_ref = None if table is None else table.clone().requires_grad_()
+    g_ = grid if isinstance(grid, tuple) else None
+    ref = D.window_attention_core(q_ref, t_ref, w, heads, layout, grid=g_, attn_drop=p, keep=keep).reshape(r.shape)
+    (ref * r).sum().backward()
+    lay = QKV_CHUNKED if layout == "chunked" else QKV_INTERLEAVED
+    q_g = qkv.to(cuda0).requires_grad_()
+    t_g = None if table is None else table.to(cuda0).requires_grad_()
+    out = K.window_attention(q_g, t_g, w, heads, lay, grid=g_, dropout_p=p, dropout_seed=seed)
+    (out.float() * r.to(cuda0)).sum().backward()
+    tol = TOL[dtype]
+    assert rel_err(out, ref) < tol
+    assert rel_err(q_g.grad, q_ref.grad) < tol
+    if bias:
+        assert rel_err(t_g.grad, t_ref.grad) < tol
+    with torch.no_grad():
+        other = K.window_attention(qkv.to(cuda0), None if table is None else table.to(cuda0), w, heads, lay, grid=g_,
+                                   dropout_p=p, dropout_seed=seed + 1)
+        same = K.window_attention(qkv.to(cuda0), None if table is None else table.to(cuda0), w, heads, lay, grid=g_,
+                                  dropout_p=p, dropout_seed=seed)
+        plain = K.window_attention(qkv.to(cuda0), None if table is None else table.to(cuda0), w, heads, lay, grid=g_)
+    assert torch.equal(same, out.detach()) and rel_err(other, out) > 0.05 and rel_err(plain, out) > 0.05
+
+
 def test_window_attention_large_logits(cuda0):
     """softmax stability: logits of a few hundred must not overflow (row max is subtracted)."""
     K = _K()

@@ -225,10 +225,69 @@ def test_msft_vitblock_golden(cuda0):
     from visiontransformer_amd.msft import ViTBlock
     g, m = load_golden("msft_vitblock")
     mod = _load_into(ViTBlock(m["w"], m["C"], n_heads=m["heads"]), g, cuda0).eval()
+    mod.msa.attn_drop = 0.0   # as the vector was made (the reference's 0.1 is random even in eval())
     x = g["x"].to(cuda0).requires_grad_()
     y = mod(x)
     assert rel_err(y, g["y"]) < TOL
     _check_grads(mod, g, x, y, cuda0)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_msft_wmsa_default_constructor_with_attention_dropout(cuda0, training):
+    """msft WindowedMSA(window, dim) as the reference constructs it: attn_drop = 0.1 handed to SDPA in training AND
+    in eval() (msft_arch.py:81, :136).  With the dropout draw made explicit (module.dropout_seed -> the oracle's keep
+    mask) output and every gradient match the oracle; without a seed two calls differ, as the reference's do."""
+    from oracle import dswin_oracle as D, msft_oracle as M
+    from visiontransformer_amd.msft import WindowedMSA
+    torch.manual_seed(5)
+    w, C, heads, B, H, W = 8, 96, 6, 2, 16, 24
+    mod = WindowedMSA(w, C, heads)
+    assert mod.attn_drop == 0.1
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn_like(p) * (p[0].numel() ** -0.5 if p.dim() >= 2 else 0.1))
+    x = torch.randn(B, H * W, C)
+    r = torch.randn(B, H * W, C)
+    seed = 991
+    keep = D.dropout_keep_mask(B * (H // w) * (W // w), heads, w * w, 0.1, seed)
+    P = {k: v.detach().clone().requires_grad_() for k, v in mod.state_dict().items()}
+    x_ref = x.clone().requires_grad_()
+    y_ref = M.wmsa_forward(P, x_ref, H, W, w, heads, attn_drop=0.1, keep=keep)
+    (y_ref * r).sum().backward()
+    mod = mod.to(cuda0).train(training)
+    mod.dropout_seed = seed
+    xg = x.to(cuda0).requires_grad_()
+    y = mod(xg, H, W)
+    (y * r.to(cuda0)).sum().backward()
+    assert rel_err(y, y_ref) < TOL and rel_err(xg.grad, x_ref.grad) < TOL
+    for n, p in mod.named_parameters():
+        assert rel_err(p.grad, P[n].grad) < TOL, n
+    mod.dropout_seed = None
+    with torch.no_grad():
+        a, b = mod(xg, H, W), mod(xg, H, W)
+    assert not torch.equal(a, b)
+
+
+def test_dswt_wmsa_attention_dropout_follows_training_mode(cuda0):
+    """DSWT WindowedMSA(attn_drop=p): F.dropout(..., training=self.training) - on in train(), off in eval()"""
+    from oracle import dswin_oracle as D
+    from visiontransformer_amd.dswin import WindowedMSA
+    torch.manual_seed(6)
+    w, C, heads = 16, 48, 3
+    mod = WindowedMSA(w, C, heads, attn_drop=0.25)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn_like(p) * (p[0].numel() ** -0.5 if p.dim() >= 2 else 0.1))
+    x = torch.randn(2, 32, 16, C)
+    P = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    keep = D.dropout_keep_mask(2 * 2 * 1, heads, w * w, 0.25, 4242)
+    mod = mod.to(cuda0)
+    mod.dropout_seed = 4242
+    with torch.no_grad():
+        y_train = mod.train()(x.to(cuda0))
+        y_eval = mod.eval()(x.to(cuda0))
+    assert rel_err(y_train, D.wmsa_forward(P, x, w, heads, attn_drop=0.25, keep=keep)) < TOL
+    assert rel_err(y_eval, D.wmsa_forward(P, x, w, heads)) < TOL
 
 
 def test_msft_wmsa_bf16(cuda0):
@@ -284,6 +343,9 @@ def test_msft_model_golden(cuda0):
     from visiontransformer_amd import models
     g, m = load_golden("model_msft")
     mod = _load_into(models.MSFTransformer(**m["cfg"]), g, cuda0).eval()
+    for sub in mod.modules():
+        if hasattr(sub, "attn_drop"):
+            sub.attn_drop = 0.0   # as the vector was made
     x = g["x"].to(cuda0).requires_grad_()
     y = mod(x)
     assert y.shape == g["y"].shape

@@ -24,10 +24,7 @@ def _build(kind, dev):
     else:
         cfg = dict(models.MSFT_CONFIG_C)
         cfg.update(n_blocks=1, n_sub_blocks=1)
-        m = models.MSFTransformer(**cfg)
-        for sub in m.modules():
-            if hasattr(sub, "attn_drop"):
-                sub.attn_drop = 0.0
+        m = models.MSFTransformer(**cfg)   # attention dropout 0.1 as the reference constructs it (msft_arch.py:81,149)
     gen = torch.Generator().manual_seed(3)
     with torch.no_grad():
         for n, p in m.named_parameters():

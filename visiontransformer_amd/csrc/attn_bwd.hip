@@ -75,11 +75,11 @@ __device__ __forceinline__ void diag_sums(std::integer_sequence<int, R...>, cons
                                           float (&all)[2], float (&wrapped)[2]) {
     (diag_step<R>(ds, wrap, all, wrapped), ...);
 }
-template <typename T, int WS, int DP, bool BIAS, bool PAIR>
+template <typename T, int WS, int DP, bool BIAS, bool PAIR, bool DROP>
 __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::MIN_WAVES)) void win_attn_bwd_kernel(
     AttnGeom g, const T *__restrict__ qkv, const T *__restrict__ out, const T *__restrict__ dout,
     const float *__restrict__ table, float scale, const float *__restrict__ lse, T *__restrict__ dqkv,
-    float *__restrict__ ws_table, const float *__restrict__ delta_in) {
+    float *__restrict__ ws_table, const float *__restrict__ delta_in, DropArgs drop) {
     using Cfg = BwdCfg<T, WS, DP>;
     constexpr bool BF = Cfg::BF;
     static_assert(BF || !PAIR, "the pair path moves two bf16 per lane");
@@ -365,9 +365,21 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(sacc[r]);
-            const float ds = p * pacc[r];
-            sacc[r] = p;
-            pacc[r] = ds;
+            if constexpr (DROP) {
+                // the forward thinned P after normalising it: O = (keep * P / (1-p)) V.  With m = keep / (1-p):
+                // dV takes m * P; dP = m * dO V^T, and pacc holds dO V^T - delta, so dS = P (m (pacc + delta) - delta)
+                const int qrow = qb * 32 + rho(r) + 4 * hh;
+                const float ndl = ndelta_s[qrow];
+                const uint32_t h = drop_hash((((uint32_t)win * g.heads + head) * L + qrow) * (L / 2) + (key >> 1), drop.seed_lo, drop.seed_hi);
+                const bool keep = ((key & 1) ? (h >> 16) : (h & 0xffffu)) >= drop.thr;
+                const float dp = keep ? (pacc[r] - ndl) * drop.inv_keep : 0.f;
+                sacc[r] = keep ? p * drop.inv_keep : 0.f;
+                pacc[r] = p * (dp + ndl);
+            } else {
+                const float ds = p * pacc[r];
+                sacc[r] = p;
+                pacc[r] = ds;
+            }
         }
         // ---- d(bias table), w = 16 ------------------------------------------------------------------------
         if constexpr (BIAS && WS == 16) {
@@ -775,7 +787,7 @@ template <typename T, int WS, int DP>
 static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const void *dout, const float *table,
                       float scale, const float *lepe_w, const float *lepe_b, const float *lse, void *dqkv,
                       float *d_table, float *d_lepe_w, float *d_lepe_b, float *ws_table, float *ws_lepe,
-                      float *ws_delta, hipStream_t st) {
+                      float *ws_delta, const DropArgs &drop, hipStream_t st) {
     using Cfg = BwdCfg<T, WS, DP>;
     const bool bias = table != nullptr, lepe = lepe_w != nullptr;
     const size_t lds = Cfg::lds_bytes(bias);
@@ -795,21 +807,26 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
         rc = check_launch("lepe_bwd_pre_kernel");
         if (rc) return rc;
     }
-#define DSW_BWD_LAUNCH(B_, P_)                                                                                   \
+#define DSW_BWD_LAUNCH2(B_, P_, D_)                                                                              \
     do {                                                                                                         \
-        auto kern = win_attn_bwd_kernel<T, WS, DP, B_, P_>;                                                      \
+        auto kern = win_attn_bwd_kernel<T, WS, DP, B_, P_, D_>;                                                  \
         if (lds > 48 * 1024) {                                                                                   \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); \
         }                                                                                                        \
         hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const T *)qkv, (const T *)out, (const T *)dout, table, \
-                           scale, lse, (T *)dqkv, ws_table, lepe ? ws_delta : (const float *)nullptr);          \
+                           scale, lse, (T *)dqkv, ws_table, lepe ? ws_delta : (const float *)nullptr, drop);    \
+    } while (0)
+#define DSW_BWD_LAUNCH(B_, P_)                       \
+    do {                                             \
+        if (drop.thr) DSW_BWD_LAUNCH2(B_, P_, true); \
+        else DSW_BWD_LAUNCH2(B_, P_, false);         \
     } while (0)
     constexpr bool BF16 = sizeof(T) == 2;
     const bool pair = BF16 && (g.d % 2 == 0);
     bool launched = false;
     if constexpr (BF16 && WS == 16) {
-        if (!lepe && !force_general_bwd()) {  // the two-phase kernel (attn_bwd_w16.hip) takes even head dims <= DP - 2
+        if (!lepe && !drop.thr && !force_general_bwd()) {  // the two-phase kernel (attn_bwd_w16.hip) takes even head dims <= DP - 2
             const int r2 = launch_bwd_w16_two_phase(g, qkv, out, dout, table, scale, lse, dqkv, ws_table, st);
             if (r2 > 0) return r2;
             launched = r2 == DSW_OK;
@@ -826,6 +843,7 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
         else DSW_BWD_LAUNCH(false, false);
     }
 #undef DSW_BWD_LAUNCH
+#undef DSW_BWD_LAUNCH2
     rc = check_launch("win_attn_bwd_kernel");
     if (rc) return rc;
     if (bias) {
@@ -845,6 +863,7 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
 
 int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads, int layout, int ld_qkv, int ld_out,
               int ld_dout, AttnGeom &g);
+int make_drop(const char *who, float p, unsigned long long seed, DropArgs &d);
 
 }  // namespace dsw
 
@@ -868,9 +887,13 @@ extern "C" int dsw_win_attn_bwd(const void *qkv, const void *out, const void *do
                                 int n_img, int H, int W, int w, int C, int heads, int ld_qkv, int ld_out, int ld_dout,
                                 const float *bias_table, float scale, const float *lepe_w, const float *lepe_b, const float *lse,
                                 void *dqkv, float *d_bias_table, float *d_lepe_w, float *d_lepe_b,
-                                void *workspace, size_t workspace_bytes, void *stream) {
+                                void *workspace, size_t workspace_bytes, float dropout_p, unsigned long long dropout_seed,
+                                void *stream) {
     AttnGeom g;
     int rc = make_geom("dsw_win_attn_bwd", n_img, H, W, w, C, heads, layout, ld_qkv, ld_out, ld_dout, g);
+    if (rc) return rc;
+    DropArgs drop;
+    rc = make_drop("dsw_win_attn_bwd", dropout_p, dropout_seed, drop);
     if (rc) return rc;
     DSW_REQUIRE(qkv && out && dout && lse && dqkv, "dsw_win_attn_bwd: null pointer");
     DSW_REQUIRE((bias_table == nullptr) == (d_bias_table == nullptr), "dsw_win_attn_bwd: bias_table and d_bias_table go together");
@@ -885,10 +908,10 @@ extern "C" int dsw_win_attn_bwd(const void *qkv, const void *out, const void *do
     hipStream_t st = as_stream(stream);
     const bool big = g.d > 32;
     DSW_DISPATCH_DTYPE(dtype, T, {
-        if (w == 16) return big ? launch_bwd<T, 16, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, st)
-                                : launch_bwd<T, 16, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, st);
-        return big ? launch_bwd<T, 8, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, st)
-                   : launch_bwd<T, 8, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, st);
+        if (w == 16) return big ? launch_bwd<T, 16, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, drop, st)
+                                : launch_bwd<T, 16, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, drop, st);
+        return big ? launch_bwd<T, 8, 64>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, drop, st)
+                   : launch_bwd<T, 8, 32>(g, qkv, out, dout, bias_table, scale, lepe_w, lepe_b, lse, dqkv, d_bias_table, d_lepe_w, d_lepe_b, ws_table, ws_lepe, ws_delta, drop, st);
     });
     return DSW_OK;
 }

@@ -21,6 +21,27 @@ struct AttnGeom {
     int ldq, ldo, ldg;  // row strides in elements: qkv / dqkv (>= 3C), out (>= C), dout (>= C)
 };
 
+// Attention dropout (DSwinT_arch.py:172, msft_arch.py:136) without a mask tensor: the keep decision of score
+// element (window, head, query q, key k) is a function of a 64-bit seed and the element's position that the
+// forward and the backward kernels both evaluate (and that a CPU check can evaluate too).  One 32-bit hash
+// serves the two adjacent keys 2j, 2j+1 of a query row: pair index = ((window * heads + head) * L + q) * L/2 + j
+// (mod 2^32); the even key takes the hash's low 16 bits, the odd key the high 16 bits, and an element is kept
+// when its 16 bits are >= thr = round(p * 65536).  Kept probabilities are scaled by 1 / (1 - p).
+struct DropArgs {
+    uint32_t thr;      // 0: no dropout
+    uint32_t seed_lo, seed_hi;
+    float inv_keep;    // 1 / (1 - p)
+};
+__device__ __forceinline__ uint32_t drop_hash(uint32_t pair_idx, uint32_t seed_lo, uint32_t seed_hi) {
+    uint32_t x = (pair_idx + seed_lo) ^ seed_hi;  // then the murmur3 finaliser
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+
 // Row of the C layout of a 32x32 MFMA result held in register r by lane half hh.
 __device__ __forceinline__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
@@ -129,6 +150,7 @@ __device__ __forceinline__ float upper_half_to_lower(float x) {
 // backward for 16 x 16 windows in bf16 without any exchange of dS between waves (attn_bwd_w16.hip); returns
 // DSW_OK after launching, or a negative value when the shape is not one it takes (the caller then uses
 // the general kernel)
+// (it has no dropout: the caller sends calls with dropout to the general kernel)
 int launch_bwd_w16_two_phase(const AttnGeom &g, const void *qkv, const void *out, const void *dout, const float *table,
                              float scale, const float *lse, void *dqkv, float *ws_table, hipStream_t st);
 

@@ -12,6 +12,8 @@
 // then, as they stand in the accumulators, the B operand of O^T = V^T P^T (rows of the
 // accumulator = the summed key index), so P never touches LDS; 1/sum is applied to O^T per lane.
 // bf16 inputs use v_mfma_f32_32x32x16_bf16, f32 inputs the exact-f32 v_mfma_f32_32x32x2_f32.
+#include <math.h>
+
 #include "attn_common.hpp"
 
 #pragma clang fp contract(fast)
@@ -35,11 +37,11 @@ template <typename T, int WS, int DP> struct FwdCfg {
     }
 };
 
-template <typename T, int WS, int DP, bool BIAS, bool LEPE>
+template <typename T, int WS, int DP, bool BIAS, bool LEPE, bool DROP>
 __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::MIN_WAVES)) void win_attn_fwd_kernel(
     AttnGeom g, const T *__restrict__ qkv, const float *__restrict__ table, float scale,
     const float *__restrict__ lepe_w, const float *__restrict__ lepe_b, T *__restrict__ out,
-    float *__restrict__ lse) {
+    float *__restrict__ lse, DropArgs drop) {
     using Cfg = FwdCfg<T, WS, DP>;
     constexpr int L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, THREADS = Cfg::THREADS, QS = Cfg::QS, VS = Cfg::VS;
     constexpr int TS = bias_lds<WS>::TS, TMAX = (2 * WS - 2) * (TS + 1);
@@ -250,9 +252,20 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
                     sacc[tt][r] = __builtin_amdgcn_exp2f(sh.x);
                     sacc[tt][r + 1] = __builtin_amdgcn_exp2f(sh.y);
                 }
-                if (!ones_row) {
+                if (!ones_row || DROP) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sum += sacc[tt][r];
+                }
+                if constexpr (DROP) {
+                    // the denominator above is of the full row; what goes on to the product with V is thinned.
+                    // Registers r, r+1 (r even) are the adjacent keys 32t + rho(r) + 4hh (+1): one hash per pair.
+                    const uint32_t row_pairs = (((uint32_t)win * g.heads + head) * L + q) * (L / 2) + ((32 * t + 4 * hh) >> 1);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const uint32_t h = drop_hash(row_pairs + (rho(r) >> 1), drop.seed_lo, drop.seed_hi);
+                        sacc[tt][r] = (h & 0xffffu) >= drop.thr ? sacc[tt][r] : 0.f;
+                        sacc[tt][r + 1] = (h >> 16) >= drop.thr ? sacc[tt][r + 1] : 0.f;
+                    }
                 }
                 if constexpr (BF) {
 #pragma unroll
@@ -289,14 +302,14 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
         }
 
         // ---- softmax denominator: row d of O^T (ones row of V^T), or the explicit sum ---------------
-        if (ones_row) {
+        if (ones_row && !DROP) {
 #pragma unroll
             for (int u = 0; u < DP / 32; ++u)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sum += (32 * u + rho(r) + 4 * hh == d) ? oacc[u][r] : 0.f;
         }
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = (DROP ? drop.inv_keep : 1.0f) / sum;
         if (hh == 0) lse[((size_t)win * g.heads + head) * L + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
 
         // ---- epilogue: normalise, LePE, store (lane = query row, registers = head-dim) -------------
@@ -374,26 +387,32 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
 
 template <typename T, int WS, int DP>
 static int launch_fwd(const AttnGeom &g, const void *qkv, const float *table, float scale, const float *lepe_w,
-                      const float *lepe_b, void *out, float *lse, hipStream_t st) {
+                      const float *lepe_b, void *out, float *lse, const DropArgs &drop, hipStream_t st) {
     using Cfg = FwdCfg<T, WS, DP>;
     const bool bias = table != nullptr, lepe = lepe_w != nullptr;
     const size_t lds = Cfg::lds_bytes(bias);
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "win_attn_fwd: w=%d head dim %d needs %zu B of LDS", WS, g.d, lds);
     const dim3 grid(g.n_win * g.heads), block(Cfg::THREADS);
-#define DSW_FWD_LAUNCH(B_, L_)                                                                                   \
+#define DSW_FWD_LAUNCH2(B_, L_, D_)                                                                              \
     do {                                                                                                         \
-        auto kern = win_attn_fwd_kernel<T, WS, DP, B_, L_>;                                                      \
+        auto kern = win_attn_fwd_kernel<T, WS, DP, B_, L_, D_>;                                                  \
         if (lds > 48 * 1024) {                                                                                   \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_fwd: LDS attribute: %s", hipGetErrorString(e)); \
         }                                                                                                        \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const T *)qkv, table, scale, lepe_w, lepe_b, (T *)out, lse); \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const T *)qkv, table, scale, lepe_w, lepe_b, (T *)out, lse, drop); \
+    } while (0)
+#define DSW_FWD_LAUNCH(B_, L_)                     \
+    do {                                           \
+        if (drop.thr) DSW_FWD_LAUNCH2(B_, L_, true); \
+        else DSW_FWD_LAUNCH2(B_, L_, false);       \
     } while (0)
     if (bias && !lepe) DSW_FWD_LAUNCH(true, false);
     else if (!bias && lepe) DSW_FWD_LAUNCH(false, true);
     else if (!bias && !lepe) DSW_FWD_LAUNCH(false, false);
     else DSW_FWD_LAUNCH(true, true);
 #undef DSW_FWD_LAUNCH
+#undef DSW_FWD_LAUNCH2
     return check_launch("win_attn_fwd_kernel");
 }
 
@@ -422,25 +441,40 @@ int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads,
     return DSW_OK;
 }
 
+// dropout arguments of the C ABI -> kernel form; p in [0, 1)
+int make_drop(const char *who, float p, unsigned long long seed, DropArgs &d) {
+    if (!(p >= 0.f) || p >= 1.f) return fail(DSW_EINVAL, "%s: dropout probability %g outside [0, 1)", who, (double)p);
+    const long thr = lroundf(p * 65536.f);
+    d.thr = (uint32_t)(thr > 65535 ? 65535 : thr);
+    d.seed_lo = (uint32_t)(seed & 0xffffffffull);
+    d.seed_hi = (uint32_t)(seed >> 32);
+    d.inv_keep = 1.0f / (1.0f - p);
+    return DSW_OK;
+}
+
 }  // namespace dsw
 
 using namespace dsw;
 
 extern "C" int dsw_win_attn_fwd(const void *qkv, int dtype, int layout, int n_img, int H, int W, int w, int C,
                                 int heads, int ld_qkv, int ld_out, const float *bias_table, float scale,
-                                const float *lepe_w, const float *lepe_b, void *out, float *lse, void *stream) {
+                                const float *lepe_w, const float *lepe_b, void *out, float *lse, float dropout_p,
+                                unsigned long long dropout_seed, void *stream) {
     AttnGeom g;
     int rc = make_geom("dsw_win_attn_fwd", n_img, H, W, w, C, heads, layout, ld_qkv, ld_out, 0, g);
+    if (rc) return rc;
+    DropArgs drop;
+    rc = make_drop("dsw_win_attn_fwd", dropout_p, dropout_seed, drop);
     if (rc) return rc;
     DSW_REQUIRE(qkv && out && lse, "dsw_win_attn_fwd: null pointer");
     DSW_REQUIRE((lepe_w == nullptr) == (lepe_b == nullptr), "dsw_win_attn_fwd: lepe_w and lepe_b go together");
     hipStream_t st = as_stream(stream);
     const bool big = g.d > 32;
     DSW_DISPATCH_DTYPE(dtype, T, {
-        if (w == 16) return big ? launch_fwd<T, 16, 64>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, st)
-                                : launch_fwd<T, 16, 32>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, st);
-        return big ? launch_fwd<T, 8, 64>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, st)
-                   : launch_fwd<T, 8, 32>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, st);
+        if (w == 16) return big ? launch_fwd<T, 16, 64>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, drop, st)
+                                : launch_fwd<T, 16, 32>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, drop, st);
+        return big ? launch_fwd<T, 8, 64>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, drop, st)
+                   : launch_fwd<T, 8, 32>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, drop, st);
     });
     return DSW_OK;
 }

@@ -85,13 +85,6 @@ class WindowedAttention(nn.Module):
         return F.dropout(p, p=attn_drop, training=self.training) @ v
 
 
-def _check_no_attn_dropout(p, training):
-    if p and training:
-        raise NotImplementedError(
-            "attention dropout inside the fused window-attention kernel is not built; "
-            "set attn_drop = 0 (the reference's DSWT blocks use 0, DSwinT_arch.py:321)")
-
-
 class WindowedMSA(WindowedAttention):
     """DSwinT_arch.py:320-338.  qkv Linear on the un-partitioned [B,H,W,C] tensor (a Linear is
     per token, so it commutes with the partition), one fused attention kernel that cuts the
@@ -105,6 +98,9 @@ class WindowedMSA(WindowedAttention):
         self.qkv = nn.Linear(dim, 3 * dim)
         self.pe = RelativePositionalEncoding(q_size=self.win, k_size=self.win, num_heads=num_heads)
         self.out_proj = nn.Linear(dim, dim)
+        # explicit 64-bit seed of the attention dropout of the next training forward (tests / reproducible runs);
+        # None = draw it from torch's CPU generator
+        self.dropout_seed = None
         # True: when dim is not a multiple of 64 the result is a view of a buffer whose rows are
         # padded to one (what the GEMM library runs fastest on); values and shape are the same, but
         # the tensor is not contiguous.  False: always return a contiguous tensor.
@@ -114,10 +110,10 @@ class WindowedMSA(WindowedAttention):
         """residual = (stream, r), inference only: returns stream + r * attention(x) with the residual taken
         inside out_proj's kernel (the caller's ReZero residual, DSwinT_arch.py:355), instead of attention(x)."""
         B, H, W, C = x.shape
-        _check_no_attn_dropout(self.attn_drop, self.training)
         qkv = K.linear(x, self.qkv, pad_out=True)
+        # attention dropout as F.dropout(..., training=self.training) applies it (DSwinT_arch.py:172), inside the kernels
         z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W),
-                               pad_out=True)
+                               pad_out=True, dropout_p=self.attn_drop if self.training else 0.0, dropout_seed=self.dropout_seed)
         if residual is not None:
             y = K.linear_residual(z, self.out_proj, *residual)
             return y if y is not None else K.rezero_residual(residual[0], residual[1], K.linear(z, self.out_proj, pad_out=True))

@@ -407,7 +407,7 @@ def _dptr(t):
 
 class _WinAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, table, lepe_w, lepe_b, layout, n_img, H, W, w, heads, scale, pad_out):
+    def forward(ctx, qkv, table, lepe_w, lepe_b, layout, n_img, H, W, w, heads, scale, pad_out, drop_p=0.0, drop_seed=0):
         _lib.require_cuda(qkv)
         C3 = qkv.shape[-1]
         C = C3 // 3
@@ -425,8 +425,10 @@ class _WinAttnFn(torch.autograd.Function):
         out = _mark_padded(torch.empty(rows, ldo, dtype=qkv.dtype, device=dev))
         lse = torch.empty(n_win, heads, L, dtype=torch.float32, device=dev)
         call("dsw_win_attn_fwd", _dptr(qkv2), dtype_code(qkv.dtype), layout, n_img, H, W, w, C, heads, ldq, ldo,
-             ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(out), ptr(lse), stream(dev))
+             ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(out), ptr(lse), _c_float(drop_p), ctypes.c_ulonglong(drop_seed),
+             stream(dev))
         ctx.save_for_backward(qkv2, out, lse, tab, lw, lb)
+        ctx.drop = (float(drop_p), int(drop_seed))
         ctx.meta = (layout, n_img, H, W, w, C, heads, scale, ldq, ldo, lead,
                     None if table is None else (table.shape, table.dtype),
                     None if lepe_w is None else (lepe_w.shape, lepe_w.dtype, lepe_b.dtype))
@@ -452,15 +454,26 @@ class _WinAttnFn(torch.autograd.Function):
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
         call("dsw_win_attn_bwd", _dptr(qkv2), ptr(out), _dptr(dout2), dtype_code(qkv2.dtype), layout, n_img, H, W, w, C,
              heads, ldq, ldo, ldg, ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(lse), ptr(dqkv), ptr(d_tab),
-             ptr(d_lw), ptr(d_lb), ptr(ws), ctypes.c_size_t(int(nbytes)), stream(dev))
+             ptr(d_lw), ptr(d_lb), ptr(ws), ctypes.c_size_t(int(nbytes)), _c_float(ctx.drop[0]), ctypes.c_ulonglong(ctx.drop[1]),
+             stream(dev))
         g_tab = None if tab is None else d_tab.view(tmeta[0]).to(tmeta[1])
         g_lw = None if lw is None else d_lw.view(lmeta[0]).to(lmeta[1])
         g_lb = None if lb is None else d_lb.to(lmeta[2])
-        return (dqkv[:, :3 * C].view(lead + (3 * C,)), g_tab, g_lw, g_lb) + (None,) * 8
+        return (dqkv[:, :3 * C].view(lead + (3 * C,)), g_tab, g_lw, g_lb) + (None,) * 10
 
 
-def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w=None, lepe_b=None, pad_out=False):
+def draw_dropout_seed():
+    """64 bits from torch's CPU generator (no device sync; reproducible under torch.manual_seed, and replayed by
+    activation checkpointing, which restores the CPU generator's state before it recomputes a forward)"""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w=None, lepe_b=None, pad_out=False,
+                     dropout_p=0.0, dropout_seed=None):
     """softmax(q k^T * scale + bias) v per (window, head), de-headified.
+
+    dropout_p > 0: attention dropout on the probabilities, decided inside the kernels by a hash of
+    dropout_seed (drawn from torch's CPU generator when None) and the element's position.
 
     qkv [..., 3C].  grid=(B, H, W): tokens are the pixels of B images, windows are cut out by
     address arithmetic and the result keeps the image layout.  grid=None: qkv is [n, w*w, 3C],
@@ -476,8 +489,11 @@ def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w
         n_img, H, W = qkv.shape[0], 0, 0
     else:
         n_img, H, W = grid
+    dropout_p = float(dropout_p)
+    if dropout_p > 0.0 and dropout_seed is None:
+        dropout_seed = draw_dropout_seed()
     return _run(_WinAttnFn, qkv, table, lepe_w, lepe_b, int(layout), int(n_img), int(H), int(W), int(w),
-                            int(heads), float(scale), bool(pad_out))
+                            int(heads), float(scale), bool(pad_out), dropout_p, int(dropout_seed or 0))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -65,18 +65,18 @@ class WindowedMSA(nn.Module):
         self.out_proj = nn.Linear(dim, dim)
         self.attn_drop = attn_drop
         self.proj_drop = nn.Dropout(proj_drop)
+        # explicit 64-bit seed of the attention dropout of the next forward (tests / reproducible runs);
+        # None = draw it from torch's CPU generator
+        self.dropout_seed = None
 
     def forward(self, x, H, W):
-        if self.attn_drop:
-            raise NotImplementedError(
-                "attention dropout inside the fused window-attention kernel is not built; set "
-                "attn_drop = 0 (the reference passes its default 0.1 to SDPA even in eval(), "
-                "msft_arch.py:136, so its outputs are random there)")
         B, N, C = x.shape
         assert N == H * W
         qkv = K.linear(x, self.qkv)
+        # the reference hands attn_drop to SDPA whatever the mode (msft_arch.py:136): dropout in eval() too
         z = K.window_attention(qkv, None, self.window_size, self.num_heads, QKV_CHUNKED, grid=(B, H, W),
-                               lepe_w=self.pe_encoder.weight, lepe_b=self.pe_encoder.bias)
+                               lepe_w=self.pe_encoder.weight, lepe_b=self.pe_encoder.bias,
+                               dropout_p=self.attn_drop, dropout_seed=self.dropout_seed)
         return self.proj_drop(K.linear(z, self.out_proj))
 
 
@@ -99,11 +99,11 @@ class MLP(nn.Module):
 
 class ViTBlock(nn.Module):
     """msft_arch.py:146-167, the caller of WindowedMSA: NCHW in and out.  The NCHW->token copy
-    is fused with ln1 and the token->NCHW copy is one kernel; attn_drop is 0 here (see above)."""
+    is fused with ln1 and the token->NCHW copy is one kernel."""
 
     def __init__(self, window_size, dim, n_heads=4, ffn_scale=2, drop_path=0.0):
         super().__init__()
-        self.msa = WindowedMSA(dim=dim, window_size=window_size, num_heads=n_heads, attn_drop=0.0)
+        self.msa = WindowedMSA(dim=dim, window_size=window_size, num_heads=n_heads)   # attn_drop 0.1, msft_arch.py:149
         self.mlp = MLP(dim, ffn_scale=ffn_scale)
         self.ln1 = nn.LayerNorm(dim)
         self.ln2 = nn.LayerNorm(dim)
