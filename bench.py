@@ -39,6 +39,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 B_PER_GPU, HW, C, HEADS, WIN = 32, 64, 180, 6, 16
+# the kernel `roofline` is about, as rocprofv3 names it: window-attention backward at the WindowedMSA shape
+DOMINANT_KERNEL = "win_attn_bwd_w16_kernel<32, true>"
 
 
 def build_pair(device, seed=0):
@@ -222,7 +224,7 @@ def pmc_traffic(kernel):
         with open(path) as f:
             return json.load(f)[kernel]["traffic"]
     except (OSError, KeyError, ValueError):
-        return None
+        return None   # no pass on record for this kernel name: the field stays empty rather than stale
 
 
 def cpu_baseline(sample_batch=8, budget_s=15.0):
@@ -405,9 +407,13 @@ def main():
         if not args.no_kernels:
             ks = kernel_rooflines(device)
             dom = ks["win_attn_bwd"]
-            line["roofline"] = {"bound": "hbm", "kernel": "win_attn_bwd_kernel<bf16,w16,d32>", "achieved": dom["achieved"],
+            traffic = pmc_traffic(DOMINANT_KERNEL)
+            line["roofline"] = {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": dom["achieved"],
                                 "peak": dom["peak"], "unit": "GB/s", "frac": dom["frac"], "mfma_frac": dom["mfma_frac"],
-                                "traffic": pmc_traffic("win_attn_bwd_kernel<unsigned short, 16, 32, true, true>"),
+                                "traffic": traffic,
+                                "traffic_source": None if traffic is None else
+                                "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --pmc-target` "
+                                "(profiles/pmc_traffic_latest.json), not measured in this run",
                                 "us_per_launch": dom["us"]}
             line["kernels"] = ks
         if sr is not None:

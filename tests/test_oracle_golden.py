@@ -124,3 +124,24 @@ def test_msft_vitblock():
     y = M.vit_block(P, x, m["w"], m["heads"])
     assert rel_err(y, g["y"]) < TOL
     _check_grads(g, x, P, y)
+
+
+def test_dsmsa_helper_methods_follow_the_oracle():
+    """candidate_indexes / cords / integrate of the drop-in class (DSwinT_arch.py:201-253; plain torch ops, run here
+    on the CPU) against the oracle's restatements, which the golden vectors pin"""
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    torch.manual_seed(4)
+    w, C, B, H, W = 8, 12, 2, 32, 48
+    mod = DeformableSparseWindowAttention(w, C, 2).eval()
+    mod.num_win_selected = 0.5
+    sd = torch.randn(B, 4, H // w, W // w)
+    x = torch.randn(B, C, H, W)
+    b, h, ww, sdl = mod.candidate_indexes(x, sd[:, :1])
+    rb, rh, rw, rs, _ = D.candidate_indexes(sd[:, :1], 0.5, 1.0, False)
+    assert torch.equal(b, rb) and torch.equal(h, rh) and torch.equal(ww, rw) and torch.equal(sdl, rs)
+    off = sd[:, 2:].sigmoid()
+    got = mod.cords(b, h, ww, off, H, W)
+    ref = D.cords(rb, rh, rw, off, w, H, W)
+    assert all(torch.equal(a, r) for a, r in zip(got, ref))
+    delta = torch.randn(b.numel(), C, w, w)
+    assert torch.equal(mod.integrate(x, delta, b, got[0], got[1]), D.integrate(x.shape, delta, rb, ref[0], ref[1], w))

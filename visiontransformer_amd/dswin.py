@@ -163,6 +163,44 @@ class DeformableSparseWindowAttention(WindowedAttention):
         self.static_inference = True   # without autograd
         self.static_training = True    # with autograd
 
+    # ---- the reference's helper methods (DSwinT_arch.py:201-253), kept for callers and harnesses that use or wrap
+    # them.  forward() does not call them: selection, corners and the write-back are the kernels above.  Plain
+    # torch ops on whatever device the arguments live on; same arguments, same return values.
+    def candidate_indexes(self, x, scores):
+        """top-k windows of scores [B,1,Hw,Ww] by (Gumbel-)softmax probability -> flat (b, h, w) indices [B*k]
+        and the straight-through value (1 - p).detach() + p (DSwinT_arch.py:201-225)"""
+        B, _, Hw, Ww = scores.shape
+        k = int((Hw * Ww) * self.num_win_selected)
+        flat = scores.reshape(B, -1)
+        if self.training:
+            noise = self.gumbel_noise.to(flat.device) if self.gumbel_noise is not None else self._noise(flat)
+            probs = ((flat + noise) / self.temperature).softmax(dim=-1)
+        else:
+            probs = (flat / self.temperature).softmax(dim=-1)
+        top_p, top_i = probs.topk(k, dim=1)
+        b_idx = torch.arange(B, device=x.device).repeat_interleave(k)
+        return b_idx, (top_i // Ww).flatten(), (top_i % Ww).flatten(), ((1.0 - top_p).detach() + top_p).flatten()
+
+    def cords(self, b_idx, h_idx, w_idx, offsets, H, W):
+        """window corners after the learned shift, clamped into the map (DSwinT_arch.py:227-237)"""
+        shift_h = (offsets[b_idx, 0, h_idx, w_idx] * self.w - self.w / 2.).long()
+        shift_w = (offsets[b_idx, 1, h_idx, w_idx] * self.w - self.w / 2.).long()
+        h1 = (h_idx * self.w + shift_h).clamp(0, H - self.w)
+        w1 = (w_idx * self.w + shift_w).clamp(0, W - self.w)
+        return h1, w1, h1 + self.w, w1 + self.w
+
+    def integrate(self, x, delta, b_idx, h1, w1):
+        """mean of the window deltas [n,C,w,w] at the pixels they cover, zero elsewhere, as a [B,C,H,W] map
+        (DSwinT_arch.py:239-253)"""
+        B, C, H, W = x.shape
+        gi, gj = self.win_grid.to(h1.device)
+        pix = ((h1.view(-1, 1, 1) + gi) * W + (w1.view(-1, 1, 1) + gj)).flatten(1)                 # [n, w*w]
+        plane = (b_idx.view(-1, 1) * C + torch.arange(C, device=h1.device).view(1, C)) * (H * W)    # [n, C]
+        index = (plane.unsqueeze(2) + pix.unsqueeze(1)).reshape(-1)
+        out = torch.zeros(B * C * H * W, dtype=delta.dtype, device=delta.device)
+        out.scatter_reduce_(0, index, delta.reshape(-1), reduce="mean", include_self=False)
+        return out.view(B, C, H, W)
+
     def _noise(self, scores_flat):
         if not self.training:
             return None

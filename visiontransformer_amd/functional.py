@@ -265,14 +265,24 @@ class GradSink:
         self.expected = expected
         self.count = 0
         self.buf = None
+        self.task = None
+
+    def _same_pass(self):
+        """state belongs to one backward pass: a pass that ended early (an exception, a partial backward over a
+        retained graph) must not leave its buffer and count to the next one"""
+        task = torch._C._current_graph_task_id()
+        if task != self.task:
+            self.task, self.count, self.buf = task, 0, None
 
     def target(self, shape, dtype, device):
         """(buffer to write / add into, accumulate flag)"""
+        self._same_pass()
         if self.buf is None:
             return torch.empty(shape, dtype=dtype, device=device), 0
         return self.buf, 1
 
     def deliver(self, buf):
+        self._same_pass()
         self.count += 1
         if self.count == self.expected:
             self.count, self.buf = 0, None
@@ -1074,6 +1084,8 @@ class _RMSNormFn(torch.autograd.Function):
             sink = None
         # the gradient that reached x around the branch (the residual's dy), if it is already there: the
         # kernel writes its sum with the norm's gradient into a fresh buffer (the other tensor is only read)
+        if sink is not None:
+            sink._same_pass()
         prev = sink.buf if sink is not None else None
         if prev is not None:
             prev = prev.reshape(M, C)
@@ -1193,6 +1205,7 @@ class _RezeroFn(torch.autograd.Function):
         if sink is None or not ctx.needs_input_grad[0]:
             return dy, dr, db, None, None, None
         # the residual's share of x's gradient is dy itself: the norm's backward reads it and writes the sum
+        sink._same_pass()
         if sink.buf is not None:  # the norm's gradient came first: its buffer is ours to add into
             sink.buf.view(M, C).add_(dy2)
             return sink.deliver(sink.buf), dr, db, None, None, None
