@@ -268,15 +268,18 @@ def sr_inference(device, rank, world, iters=3):
     the whole job (strong scaling: the frame is fixed).  Time = max over ranks, barriers both sides."""
     import torch.distributed as dist
     from visiontransformer_amd.models import DSWT_DEFAULT, dswt_from_config
-    from visiontransformer_amd.parallel import balanced_grid, plan_tiles, tiled_super_resolve
+    from visiontransformer_amd.parallel import GraphedForward, balanced_grid, plan_tiles, tiled_super_resolve
     torch.manual_seed(0)
     model = dswt_from_config(DSWT_DEFAULT).to(device).eval()
     gen = torch.Generator(device=device).manual_seed(7)
     lr = torch.rand(1, 3, *SR_LR, device=device, generator=gen)
+    # the forward of a tile is captured once per tile shape (untimed, like building the model) and replayed: at
+    # 2+ ranks the tiles are small enough for ~1000 launches per forward to be bound by the host otherwise
+    runner = GraphedForward(model)
 
     def run():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-            return tiled_super_resolve(model, lr, 4, tile="balanced", halo=32, rank=rank, world=world, reduce=world > 1)
+            return tiled_super_resolve(runner, lr, 4, tile="balanced", halo=32, rank=rank, world=world, reduce=world > 1)
 
     out = run()
     ok = bool(torch.isfinite(out).all())

@@ -827,12 +827,21 @@ def _cast_padded(t2, act):
 _PREP_CACHE = {}
 
 
+def _may_keep_operands():
+    """Prepared operands are kept between calls only without autograd and outside stream capture.  Under
+    capture a kept tensor would live in the capturing graph's private memory pool and dangle for every later
+    capture or eager call once that graph is gone; and a graph that skipped the preparation would replay on a
+    copy of the weights taken before capture - so a captured forward always prepares its operands itself,
+    from the parameters as they are at replay time."""
+    return not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
+
+
 def _weight_operands(weight):
     """nn.Linear weight [N, K] -> zero-padded bf16 [ceil64(N), ceil64(K)] and its transpose (one launch).
     Without autograd (inference) the pair is kept per parameter and reused until the parameter is
     modified in place or replaced; with autograd the weights change every step and nothing is kept."""
     N, Kd = weight.shape
-    caching = not torch.is_grad_enabled()
+    caching = _may_keep_operands()
     if caching:
         e = _PREP_CACHE.get(id(weight))
         if e is not None and e[0]() is weight and e[1] == weight._version and e[2] == weight.data_ptr():
@@ -1258,7 +1267,7 @@ def _taps_operand(w4):
 def _conv3x3_operand(weight):
     """Conv2d weight [Co, Ci, 3, 3] -> the kernel's operand; without autograd it is kept per parameter like
     the projection weights."""
-    caching = not torch.is_grad_enabled()
+    caching = _may_keep_operands()
     if caching:
         e = _PREP_CACHE.get(("conv3x3", id(weight)))
         if e is not None and e[0]() is weight and e[1] == weight._version and e[2] == weight.data_ptr():

@@ -58,7 +58,7 @@ class GatedMLP(nn.Module):
         """rows of fc1_gate and fc1_content stacked; kept between calls when autograd is off and the
         parameters have not been modified"""
         ps = (self.fc1_gate.weight, self.fc1_content.weight, self.fc1_gate.bias, self.fc1_content.bias)
-        if torch.is_grad_enabled():
+        if not K._may_keep_operands():   # autograd on, or stream capture (see functional._may_keep_operands)
             return _Stacked(torch.cat(ps[:2]), torch.cat(ps[2:]))
         key = tuple((p._version, p.data_ptr()) for p in ps)
         kept = getattr(self, "_kept_fc1", None)

@@ -130,6 +130,46 @@ def _reflect_crop(img, py0, py1, px0, px1):
     return core
 
 
+class GraphedForward:
+    """The no-grad forward of `model` replayed from HIP graphs, one graph per input shape.
+
+    A DSWT forward is about a thousand launches; below some 80 k LR pixels per tile the host cannot issue them as
+    fast as the GPU retires them.  The inference path has no host read (DS-MSA keeps its pass count on the
+    device), so the whole forward can be captured once per tile shape and replayed.  Replays read the
+    parameters where they live - in-place updates are seen - and the prepared bf16 operands are rebuilt inside
+    the graph (functional._may_keep_operands).  The returned tensor is the graph's own output buffer: consume it
+    before the next call with the same shape.  Modules that draw host-side randomness per call (attention
+    dropout seeds) would replay the captured draw; DSWT inference has none."""
+
+    def __init__(self, model, max_graphs=8):
+        self.model = model
+        self.max_graphs = max_graphs
+        self._graphs = {}
+
+    @torch.no_grad()
+    def __call__(self, x):
+        if not x.is_cuda:
+            return self.model(x)
+        key = (tuple(x.shape), x.dtype, x.device, torch.is_autocast_enabled("cuda"),
+               torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if len(self._graphs) >= self.max_graphs:
+                return self.model(x)
+            static_x = x.clone()
+            for _ in range(2):     # eager warm-up: library algorithm choices, allocator growth, code loading
+                self.model(static_x)
+            torch.cuda.synchronize(x.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_y = self.model(static_x)
+            entry = self._graphs[key] = (graph, static_x, static_y)
+        graph, static_x, static_y = entry
+        static_x.copy_(x)
+        graph.replay()
+        return static_y
+
+
 @torch.no_grad()
 def tiled_super_resolve(model, lr, scale, tile=256, halo=32, rank=0, world=1, reduce=True, clip=False):
     """x`scale` super-resolution of lr [B,3,H,W] by tiles with halo.  Rank r computes tiles
