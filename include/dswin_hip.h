@@ -284,6 +284,21 @@ int dsw_colsum_static(const void *x, int dtype, long long rows, int cols, float 
 int dsw_ema_update(int n, void *const *ema, const void *const *cur, const long long *numel, int dtype, float beta,
                    float one_minus_beta, void *stream);
 
+/* One Adam step over a list of fp32 parameter tensors, in place: replaces the optimizer step of the
+ * reference's trainer (torch.optim.Adam created at toolkit/init.py:133 with betas (0.9, 0.99) and stepped at
+ * toolkit/model_helper2.py:125), which torch runs as eight elementwise passes over the tensor lists, by one
+ * pass (4 reads + 3 writes per element), one launch per 64 tensors.  Per element, fp32, in the order and
+ * rounding of those passes as torch's GPU kernels compute them (bit-identical results):
+ *   m <- fma(one_minus_beta1, g - m, m);  v <- v * beta2;  v <- fma(one_minus_beta2, g * g, v);
+ *   d <- sqrt(v) / bias2_sqrt + eps;      p <- fma(step_size, m / d, p)
+ * with step_size = -lr / (1 - beta1^t) and bias2_sqrt = sqrt(1 - beta2^t) computed by the caller in
+ * double and rounded to float, as torch passes them (t = the step number, from 1).
+ *   param, grad, exp_avg, exp_avg_sq, numel: HOST arrays of n device pointers / element counts (read
+ *   during the call only); every tensor dense fp32.  No weight decay, amsgrad or maximize. */
+int dsw_adam_update(int n, void *const *param, const void *const *grad, void *const *exp_avg, void *const *exp_avg_sq,
+                    const long long *numel, float one_minus_beta1, float beta2, float one_minus_beta2,
+                    float bias2_sqrt, float eps, float step_size, void *stream);
+
 /* Row copy with dtype conversion between two row strides (in elements): dst[r][c] = src[r][c] for
  * c < cols; with zero_pad != 0 the columns cols..dst_ld-1 of every dst row are set to zero.  Used
  * around the projection GEMMs (the nn.Linear calls at DSwinT_arch.py:303,308,334,337 and

@@ -79,9 +79,15 @@ def test_training_step_under_whole_model_checkpointing(cuda0, kind, deterministi
         assert torch.equal(grads[1][n], g), n
 
     # the rest of toolkit/model_helper2.py:122-127 on the checkpointed run, then a validation call (:174-177)
-    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.99))
+    # with the package's Adam (toolkit/init.py:133), beside torch's own on a copy that holds the same gradients
+    from visiontransformer_amd.optim import Adam
+    twin = copy.deepcopy(model)
+    for p, q in zip(model.parameters(), twin.parameters()):
+        q.grad = p.grad.clone()
+    opt = Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.99))
     ema_model = copy.deepcopy(model).eval().requires_grad_(False)
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    scale0 = scaler.get_scale()
     scaler.unscale_(opt)
     torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
     scaler.step(opt)
@@ -89,6 +95,16 @@ def test_training_step_under_whole_model_checkpointing(cuda0, kind, deterministi
     opt.zero_grad(set_to_none=True)
     moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in model.named_parameters())
     assert moved > 0.9 * len(before)
+    twin_opt = torch.optim.Adam(twin.parameters(), lr=2e-4, betas=(0.9, 0.99))
+    inv = 1.0 / scale0                                        # a power of two: exact
+    with torch.no_grad():
+        for q in twin.parameters():
+            q.grad.mul_(inv)                                  # what unscale_ did to the other copy
+    torch.nn.utils.clip_grad_norm_(twin.parameters(), 1.0)
+    twin_opt.step()
+    for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+        same = torch.equal(p.detach(), q.detach())
+        assert same, "%s: largest difference %g" % (n, float((p.detach() - q.detach()).abs().max()))
     from visiontransformer_amd.ema import ParameterEMA
     ema = ParameterEMA(start_step=1, beta=0.995)
     ema.step_ema(ema_model=ema_model, model=model)      # copies (toolkit/param_ema.py:20-23)
