@@ -122,6 +122,27 @@ def _attention_rooflines(device, iters, warm, out):
     for name, t, fl, by in (("win_attn_fwd", t_f, flops_f, by_f), ("win_attn_bwd", t_b, flops_b, by_b)):
         out[name] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t * 1e6, algorithmic=by,
                          flops=fl, mfma_tflops=fl / t / 1e12, mfma_frac=fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS)
+    # inference: q|k|v projection inside the attention kernel (q|k|v never written).  Reads the padded bf16 rows of
+    # x, writes out; the projection's 2*T*C*3C flops join the attention's (the kernel itself multiplies the padded
+    # 192 x 3*32*heads operands).  Its intensity, (4*L*C + 6*C*C) / (2*C*2) = 346 flop/byte, is above the machine's
+    # 312: the matrix cores are the roofline that bounds it.
+    Cp = (C + 63) // 64 * 64
+    xp = K._mark_padded(torch.zeros(T, Cp, device=device, dtype=bf))
+    xp[:, :C] = torch.randn(T, C, device=device).to(bf)
+    xv = xp[:, :C].view(B_PER_GPU, HW, HW, C)
+    lin = torch.nn.Linear(C, 3 * C).to(device)
+    with torch.no_grad(), torch.autocast("cuda", dtype=bf):
+        fused = lambda: K.projected_window_attention(xv, lin, table, WIN, HEADS, QKV_INTERLEAVED, grid=(B_PER_GPU, HW, HW))
+        if fused() is not None:
+            t_p = time_calls(fused, iters, warm)
+            t_2 = time_calls(lambda: K.window_attention(K.linear(xv, lin, pad_out=True), table, WIN, HEADS, QKV_INTERLEAVED,
+                                                        grid=(B_PER_GPU, HW, HW)), iters, warm)
+            fl_p = flops_f + 2.0 * T * C * 3 * C
+            by_p = T * (C + C) * 2
+            out["win_attn_proj_fwd"] = dict(bound="mfma", achieved=fl_p / t_p / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                                            us=t_p * 1e6, flops=fl_p, algorithmic=by_p, hbm_frac=by_p / t_p / 1e9 / HBM_PEAK_GBS,
+                                            separate_kernels_us=t_2 * 1e6,
+                                            note="inference forward; same bits as dsw_linear + dsw_win_attn_fwd")
 
 
 def _window_rooflines(device, iters, warm, k, x, out):

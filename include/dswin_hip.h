@@ -284,6 +284,27 @@ int dsw_colsum_static(const void *x, int dtype, long long rows, int cols, float 
 int dsw_ema_update(int n, void *const *ema, const void *const *cur, const long long *numel, int dtype, float beta,
                    float one_minus_beta, void *stream);
 
+/* Window attention with the q|k|v projection inside the kernel, forward only (inference): the nn.Linear of
+ * DSwinT_arch.py:334 (WindowedMSA.qkv) or :303 (DeformableSparseWindowAttention.in_proj) followed by the
+ * attention of :135-172 as ONE launch; the [tokens, 3C] q|k|v matrix is never written to memory.
+ *   out[token][head*d + e] = sum_k softmax_k(q.k * scale + table) v,   q|k|v = x W^T + bias  per token
+ * with the roundings of the two separate calls (dsw_linear to bf16, then dsw_win_attn_fwd): projection
+ * accumulated in fp32, bias added, rounded to bf16; q scaled and rounded again.
+ *   x        bf16 activations, one row per token, row stride ldx elements (a multiple of 8, >= ldw); the
+ *            columns C..ldw-1 of every row must hold zeros (finite values suffice: they meet zero weights).
+ *            Token addressing as in dsw_win_attn_fwd: H = W = 0 means n_img packed windows of w*w rows, else
+ *            rows are the pixels of n_img images of H x W and the windows are cut out by address arithmetic.
+ *   w_p      the projection weight as dsw_weight_prep leaves it: bf16 [w_rows >= 3C][ldw], ldw a multiple of
+ *            64, zero past column C; row n = output feature n in the q|k|v `layout` (DSW_QKV_*).
+ *   bias     fp32 [3C] or NULL;  bias_table fp32 [(2w-1)^2][heads] or NULL;  lse fp32 [n_win][heads][w*w] or NULL.
+ *   out      bf16 rows of ld_out elements (0 = C); columns C..ld_out-1 are set to zero.
+ * bf16 only, w in {8, 16}, head dim C/heads <= 32: DSW_EUNSUPPORTED otherwise (callers then use the two separate
+ * entry points).  No dropout and no LePE term: the modules that need them (msft_arch.py:94-139) keep the
+ * separate calls. */
+int dsw_win_attn_proj_fwd(const void *x, long long ldx, const void *w_p, int w_rows, int ldw, const float *bias,
+                          int layout, int n_img, int H, int W, int w, int C, int heads, int ld_out,
+                          const float *bias_table, float scale, void *out, float *lse, void *stream);
+
 /* One Adam step over a list of fp32 parameter tensors, in place: replaces the optimizer step of the
  * reference's trainer (torch.optim.Adam created at toolkit/init.py:133 with betas (0.9, 0.99) and stepped at
  * toolkit/model_helper2.py:125), which torch runs as eight elementwise passes over the tensor lists, by one

@@ -244,6 +244,58 @@ def test_window_attention(cuda0, dtype, bias, w, C, heads, layout, grid):
         assert torch.equal(t2.grad, t_g.grad)
 
 
+PROJ_CASES = [
+    # w, C, heads, layout, grid (B,H,W) or number of packed windows; head dim <= 32
+    (16, 180, 6, "interleaved", (1, 32, 48)),
+    (16, 180, 6, "chunked", 5),
+    (8, 180, 6, "interleaved", (2, 16, 24)),
+    (8, 24, 2, "chunked", 3),
+    (16, 48, 3, "chunked", 2),                 # head dim 16
+    (16, 96, 3, "interleaved", (1, 16, 32)),   # head dim 32: no padding column for the ones column of V
+    (16, 256, 8, "chunked", 1),                # 256 input channels: the weight rows do not fit in Q's and K's LDS space
+]
+
+
+@pytest.mark.parametrize("bias,lin_bias", [(True, True), (False, True), (True, False)])
+@pytest.mark.parametrize("w,C,heads,layout,grid", PROJ_CASES)
+def test_projected_window_attention(cuda0, bias, lin_bias, w, C, heads, layout, grid):
+    """q|k|v projection inside the attention kernel (DSwinT_arch.py:334 + :135-172 / :303) against the oracle's
+    attention of the projected rows, and against the two separate kernels it replaces"""
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
+    gen = torch.Generator().manual_seed(7 * C + w)
+    L = w * w
+    lead = (grid[0], grid[1], grid[2]) if isinstance(grid, tuple) else (grid, L)
+    x = torch.randn(lead + (C,), generator=gen).bfloat16()
+    lin = torch.nn.Linear(C, 3 * C, bias=lin_bias)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(3 * C, C, generator=gen) * C ** -0.5)
+        if lin_bias:
+            lin.bias.copy_(torch.randn(3 * C, generator=gen) * 0.5)
+    table = (torch.randn((2 * w - 1) ** 2, heads, generator=gen) * 0.5) if bias else None
+    # the oracle on what the kernels compute with: bf16 activations and weights, the projection rounded to bf16
+    qkv_ref = (x.float() @ lin.weight.detach().bfloat16().float().t() + (lin.bias.detach() if lin_bias else 0.0)).bfloat16().float()
+    ref = D.window_attention_core(qkv_ref, table, w, heads, layout, grid=grid if isinstance(grid, tuple) else None).reshape(lead + (C,))
+    lin = lin.to(cuda0)
+    code = QKV_CHUNKED if layout == "chunked" else QKV_INTERLEAVED
+    g = grid if isinstance(grid, tuple) else None
+    t_g = None if table is None else table.to(cuda0)
+    xp = K.cast_rows(x.to(cuda0).reshape(-1, C), torch.bfloat16, K._ceil_pad(C))       # zero-padded rows, as the norm kernels leave them
+    xv = K._mark_padded(xp)[:, :C].view(lead + (C,))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = K.projected_window_attention(xv, lin, t_g, w, heads, code, grid=g)
+        assert out is not None and out.dtype == torch.bfloat16 and out.shape == lead + (C,)
+        sep = K.window_attention(K.linear(xv, lin, pad_out=True), t_g, w, heads, code, grid=g)
+        padded = K.projected_window_attention(xv, lin, t_g, w, heads, code, grid=g, pad_out=True)
+    assert rel_err(out, ref) < TOL[torch.bfloat16]
+    assert rel_err(out, sep) < 4e-3                                   # one bf16 ulp: same operands, same roundings
+    assert torch.equal(padded, out)
+    if C % 64:
+        assert float(padded._base[:, C:].abs().max()) == 0.0
+    with torch.autocast("cuda", dtype=torch.bfloat16):                # with autograd on, the fused call declines
+        assert K.projected_window_attention(xv, lin, t_g, w, heads, code, grid=g) is None
+
+
 @pytest.mark.parametrize("bias", [True, False])
 @pytest.mark.parametrize("C,heads,layout,grid", [(180, 6, "interleaved", (2, 32, 48)), (180, 6, "chunked", 7), (48, 3, "chunked", 3),
                                                  (108, 2, "interleaved", (1, 32, 16))])

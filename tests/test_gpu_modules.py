@@ -481,3 +481,48 @@ def test_vitblock_inference_fuses_the_residual_into_the_projections(cuda0):
     assert fused.dtype == torch.float32 and fused.shape == x.shape
     assert rel_err(fused, composed) < 5e-3
     assert rel_err(fused - x, composed - x) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [8, 16])
+def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window):
+    """Without autograd the DSWT attention modules project q|k|v inside the attention kernel
+    (DSwinT_arch.py:334 + :135-172, :303): the whole network gives the bits of the run with the two separate kernels,
+    and the fused entry point is the one that ran."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd import _lib, models
+    torch.manual_seed(0)
+    cfg = dict(models.DSWT_DEFAULT)
+    cfg.update(n_blocks=1, n_sub_blocks=2, dim=60, n_heads=2, window_size=window, feature_dim=16)
+    model = models.DSWTransformer(**cfg)
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "rezero" in n:
+                p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=gen))
+            if n.endswith("sparse_discriminator.4.bias"):
+                p[1] += 2.0                                    # open the gates: DS-MSA attends
+    model = model.to(cuda0).eval()
+    x = torch.rand(2, 3, 64, 64, generator=gen).to(cuda0) * 2 - 1
+    calls = []
+    real_call = K.call
+
+    def spy(name, *args):
+        calls.append(name)
+        return real_call(name, *args)
+
+    outs = {}
+    for fuse in (True, False):
+        K.FUSE_PROJECTION = fuse
+        calls.clear()
+        K.call = spy
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                outs[fuse] = model(x).float()
+        finally:
+            K.call = real_call
+            K.FUSE_PROJECTION = True
+        n_fused = calls.count("dsw_win_attn_proj_fwd")
+        assert (n_fused > 0 and "dsw_win_attn_fwd" not in calls) if fuse else (n_fused == 0 and "dsw_win_attn_fwd" in calls)
+    assert torch.isfinite(outs[True]).all()
+    assert torch.equal(outs[True], outs[False])

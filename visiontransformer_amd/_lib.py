@@ -72,6 +72,7 @@ SIGNATURES = {
     "dsw_layernorm_fwd": (_I, [_P, _P, _P, _F, ctypes.c_longlong, _I, _P, _I, ctypes.c_longlong, _P, _P, _P]),
     "dsw_layernorm_bwd": (_I, [_P, _I, ctypes.c_longlong, _P, _P, _P, _P, ctypes.c_longlong, _I, _P, _P, _P]),
     "dsw_ema_update": (_I, [_I, _P, _P, _P, _I, _F, _F, _P]),
+    "dsw_win_attn_proj_fwd": (_I, [_P, ctypes.c_longlong, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P]),
     "dsw_adam_update": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "dsw_colsum_blocks": (_I, [ctypes.c_longlong]),
     "dsw_colsum": (_I, [_P, _I, ctypes.c_longlong, _I, _P, _P, _P]),

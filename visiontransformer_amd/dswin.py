@@ -110,10 +110,16 @@ class WindowedMSA(WindowedAttention):
         """residual = (stream, r), inference only: returns stream + r * attention(x) with the residual taken
         inside out_proj's kernel (the caller's ReZero residual, DSwinT_arch.py:355), instead of attention(x)."""
         B, H, W, C = x.shape
-        qkv = K.linear(x, self.qkv, pad_out=True)
         # attention dropout as F.dropout(..., training=self.training) applies it (DSwinT_arch.py:172), inside the kernels
-        z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W),
-                               pad_out=True, dropout_p=self.attn_drop if self.training else 0.0, dropout_seed=self.dropout_seed)
+        drop_p = self.attn_drop if self.training else 0.0
+        z = None
+        if drop_p == 0.0:   # without autograd: projection and attention in one kernel, q|k|v never written
+            z = K.projected_window_attention(x, self.qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED,
+                                             grid=(B, H, W), pad_out=True)
+        if z is None:
+            qkv = K.linear(x, self.qkv, pad_out=True)
+            z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W),
+                                   pad_out=True, dropout_p=drop_p, dropout_seed=self.dropout_seed)
         if residual is not None:
             y = K.linear_residual(z, self.out_proj, *residual)
             return y if y is not None else K.rezero_residual(residual[0], residual[1], K.linear(z, self.out_proj, pad_out=True))
@@ -235,8 +241,10 @@ class DeformableSparseWindowAttention(WindowedAttention):
             sel = K.select_windows_static(sd, noise, self.temperature, k, w, H, W)
             self.last_selection = sel.detached()
             before = K.gather_windows(x, sel, w, out_dtype=act, sink=sink, pad_out=True)
-            qkv = K.linear(before, self.in_proj, pad_out=True)
-            z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
+            z = K.projected_window_attention(before, self.in_proj, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
+            if z is None:
+                qkv = K.linear(before, self.in_proj, pad_out=True)
+                z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
             after = K.linear(z, self.out_proj, pad_out=True)
             y = K.scatter_mean_residual(x, after, sel, w, sink=sink)
             # no window passed (DSwinT_arch.py:291-292: return x): the last kernel copies instead of convolving
@@ -250,8 +258,10 @@ class DeformableSparseWindowAttention(WindowedAttention):
         # rows of the window matrices stay padded to multiples of 64 elements between the kernels and
         # the projections (views of the first C / 3C columns)
         before = K.gather_windows(x, sel, w, out_dtype=act, sink=sink, pad_out=True)   # [n, L, C]
-        qkv = K.linear(before, self.in_proj, pad_out=True)
-        z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
+        z = K.projected_window_attention(before, self.in_proj, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
+        if z is None:
+            qkv = K.linear(before, self.in_proj, pad_out=True)
+            z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
         after = K.linear(z, self.out_proj, pad_out=True)
         y = K.scatter_mean_residual(x, after, sel, w, sink=sink)          # [B,H,W,C]
         if self.use_torch_convs:

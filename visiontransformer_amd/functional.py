@@ -506,6 +506,50 @@ def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w
                             int(heads), float(scale), bool(pad_out), dropout_p, int(dropout_seed or 0))
 
 
+FUSE_PROJECTION = True   # False: projected_window_attention always declines (the two separate kernels run)
+
+
+def projected_window_attention(x, lin, table, w, heads, layout, grid=None, scale=None, pad_out=False):
+    """window_attention(linear(x, lin), ...) as one kernel (dsw_win_attn_proj_fwd): q|k|v are projected per
+    (window, head) inside the attention kernel and never written to memory.  Inference under bf16 autocast only,
+    head dim <= 32, x in zero-padded bf16 rows (what rms_norm(..., for_projection=True) and
+    gather_windows(..., pad_out=True) return); returns None when the call is not one the kernel takes, and the
+    caller then composes linear() and window_attention()."""
+    if not FUSE_PROJECTION or torch.is_grad_enabled() or autocast_dtype(None) != torch.bfloat16:
+        return None
+    weight, bias = lin.weight, lin.bias
+    N, C = weight.shape
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and N == 3 * C and C % heads == 0 and C // heads <= 32 and w in (8, 16)
+            and weight.is_contiguous() and weight.dtype in (torch.float32, torch.bfloat16) and weight.data_ptr() % 16 == 0):
+        return None
+    x2 = x.reshape(-1, C)
+    xk = _padded_rows(x2, torch.bfloat16)
+    if xk is None:
+        if C % 64 or not x2.is_contiguous():
+            return None
+        xk = x2
+    if xk.data_ptr() % 16:
+        return None
+    if grid is None:
+        n_img, H, W = x.shape[0], 0, 0
+    else:
+        n_img, H, W = grid
+    L = w * w
+    n_win = n_img * (H // w) * (W // w) if H else n_img
+    if xk.shape[0] != n_win * L:
+        return None
+    if scale is None:
+        scale = float((C // heads) ** -0.5)
+    w_p, _ = _weight_operands(weight)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    tab = None if table is None else table.detach().to(torch.float32).contiguous()
+    ldo = _ceil_pad(C) if pad_out else C
+    out = _mark_padded(torch.empty(xk.shape[0], ldo, dtype=torch.bfloat16, device=x.device))
+    call("dsw_win_attn_proj_fwd", _dptr(xk), xk.stride(0), ptr(w_p), w_p.shape[0], w_p.shape[1], ptr(b32), int(layout), int(n_img),
+         int(H), int(W), int(w), C, int(heads), ldo, ptr(tab), _c_float(scale), ptr(out), None, stream(x.device))
+    return out[:, :C].view(x.shape[:-1] + (C,))
+
+
 # ---------------------------------------------------------------------------------------------
 # MSFT multi-scale reshapes (msft_arch.py:37-78, :156-167)
 # ---------------------------------------------------------------------------------------------
