@@ -52,7 +52,9 @@ def main():
             def only_linear():
                 return K.linear(x, lin, pad_out=True)
             a, b = separate(), fused()
-            t_sep, t_fused, t_lin = timeit(separate), timeit(fused), timeit(only_linear)
+            # the three are timed in turn, five rounds, and the medians taken: clocks drift between runs
+            rounds = [(timeit(separate), timeit(fused), timeit(only_linear)) for _ in range(5)]
+            t_sep, t_fused, t_lin = (sorted(r[i] for r in rounds)[2] for i in range(3))
         diff = int((a != b).sum())
         flop = 4.0 * T * w * w * C + 2.0 * T * Cp * 3 * (heads * 32)     # attention + projection as the kernel runs it
         alg = T * (Cp + Cp) * 2                                          # x in, out written; weights and table are L2-resident

@@ -124,12 +124,27 @@ __global__ __launch_bounds__((ProjCfg<WS>::THREADS), (ProjCfg<WS>::F::MIN_WAVES)
     };
     if constexpr (KS > 0) {
         lds_barrier();  // the activation loads stay in flight across it
-        // fully unrolled, but fenced every two k-steps: left alone, the scheduler lifts all 3 * KS weight reads
-        // to the top of the block and spills
+        // Fully unrolled and software-pipelined by hand: the weight fragments of k-step s + 1 are requested before the
+        // MFMAs of k-step s are issued, and a scheduling fence closes every step - left alone, the scheduler lifts
+        // all 3 * KS weight reads to the top of the block and spills.
+        constexpr int AHEAD = 1;
+        uint4 wf[KS][3];
+        auto fetch = [&](int ks) {
+            const bf16_t *wk = wlane + 16 * ks;
+            wf[ks][0] = *reinterpret_cast<const uint4 *>(wk);
+            wf[ks][1] = *reinterpret_cast<const uint4 *>(wk + 32 * WSTR);
+            wf[ks][2] = *reinterpret_cast<const uint4 *>(wk + 64 * WSTR);
+        };
+#pragma unroll
+        for (int s = 0; s < AHEAD && s < KS; ++s) fetch(s);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            k_step(xf[s], s);
-            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+            if (s + AHEAD < KS) fetch(s + AHEAD);
+            aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[s][0]), as_bf16x8(xf[s]), aq, 0, 0, 0);
+            ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[s][1]), as_bf16x8(xf[s]), ak, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[s][2]), as_bf16x8(xf[s]), av, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         // any number of channels (a multiple of 64): fragments fetched four k-steps ahead of their use
