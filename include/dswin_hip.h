@@ -284,6 +284,20 @@ int dsw_colsum_static(const void *x, int dtype, long long rows, int cols, float 
 int dsw_ema_update(int n, void *const *ema, const void *const *cur, const long long *numel, int dtype, float beta,
                    float one_minus_beta, void *stream);
 
+/* fc1 of the gated MLP with the gate applied in the projection's epilogue (DSwinT_arch.py:69:
+ * fc2(act(fc1_gate(x)) * fc1_content(x)), act = SiLU), inference: out = silu(x Wg^T + bg) * (x Wc^T + bc) in one
+ * launch; the [tokens, 2H] pre-activations are never written.  Same bits as dsw_linear on the stacked weight
+ * followed by dsw_gated_silu_fwd (both pre-activations are rounded to bf16 before the gate, as the separate
+ * projection would have stored them).
+ *   a, a_dtype, lda, M, K   as for dsw_linear; K <= 192.
+ *   w_p     prepared weight (dsw_weight_prep layout, bf16, rows of ldw elements) of wrows = 2 * ceil32(H) rows in
+ *           blocks of 64: gate rows 32c..32c+31, then the content rows of the same hidden columns; zero rows past H.
+ *   bias    fp32 [wrows] in the same order (zeros past H), or NULL.
+ *   out     bf16 [M][ldo], ldo >= wrows / 2, a multiple of 8; columns 0..wrows/2-1 are written (those past H come
+ *           out as zero because their weight rows and biases are zero). */
+int dsw_linear_gated_silu(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                          const float *bias, void *out, long long ldo, void *stream);
+
 /* Window attention with the q|k|v projection inside the kernel, forward only (inference): the nn.Linear of
  * DSwinT_arch.py:334 (WindowedMSA.qkv) or :303 (DeformableSparseWindowAttention.in_proj) followed by the
  * attention of :135-172 as ONE launch; the [tokens, 3C] q|k|v matrix is never written to memory.

@@ -790,3 +790,38 @@ def test_layer_norm(cuda0, M, C, mode):
             assert got._base.shape == (M, ldo) and got._base[:, C:].abs().max().item() == 0
         hx, hw, hb = torch.autograd.grad(got, (x, norm.weight, norm.bias), dy.to(torch.bfloat16))
         assert rel_err(hx, gx) < 2e-2 and rel_err(hw, gw) < 2e-2 and rel_err(hb, gb) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,Kd,H,padded_in", [(1000, 180, 360, True), (1000, 180, 360, False), (257, 64, 128, False), (4096 + 3, 192, 40 + 64 * 5, True)])
+def test_linear_gated_silu(cuda0, T, Kd, H, padded_in):
+    """fc1 with the gated SiLU in its epilogue (DSwinT_arch.py:69) against the fp32 formula on the bf16-rounded
+    operands, and bit for bit against the projection kernel followed by the stand-alone gate kernel"""
+    K = _K()
+    gen = torch.Generator().manual_seed(T + H)
+    x = torch.randn(T, Kd, generator=gen)
+    wg, wc = torch.randn(H, Kd, generator=gen) * Kd ** -0.5, torch.randn(H, Kd, generator=gen) * Kd ** -0.5
+    bg, bc = torch.randn(H, generator=gen) * 0.3, torch.randn(H, generator=gen) * 0.3
+    xb, wgb, wcb = x.bfloat16().float(), wg.bfloat16().float(), wc.bfloat16().float()
+    g = (xb @ wgb.t() + bg).bfloat16().float()
+    c = (xb @ wcb.t() + bc).bfloat16().float()
+    ref = torch.nn.functional.silu(g) * c
+    dev = cuda0
+    if padded_in:
+        xin = K._mark_padded(K.cast_rows(x.to(dev), torch.bfloat16, K._ceil_pad(Kd)))[:, :Kd]
+    else:
+        xin = x.to(dev)                                          # the fp32 stream, rounded on the way in
+    iw, ib = K.interleave_gate_content(wg.to(dev), wc.to(dev), bg.to(dev), bc.to(dev))
+
+    class Stacked:
+        weight, bias = torch.cat([wg, wc]).to(dev), torch.cat([bg, bc]).to(dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = K.linear_gated_silu(xin, iw, ib, H)
+        assert out is not None and out.shape == (T, H) and out.dtype == torch.bfloat16
+        sep = K.gated_silu(K.linear(xin, Stacked, pad_out=True), pad_out=True)
+    assert rel_err(out, ref) < 1e-2
+    assert torch.equal(out, sep)
+    if H % 64:
+        assert float(out._base[:, H:].abs().max()) == 0.0
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert K.linear_gated_silu(xin, iw, ib, H) is None       # with autograd on the fused call declines

@@ -487,8 +487,8 @@ def test_vitblock_inference_fuses_the_residual_into_the_projections(cuda0):
 @pytest.mark.parametrize("window", [8, 16])
 def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window):
     """Without autograd the DSWT attention modules project q|k|v inside the attention kernel
-    (DSwinT_arch.py:334 + :135-172, :303): the whole network gives the bits of the run with the two separate kernels,
-    and the fused entry point is the one that ran."""
+    (DSwinT_arch.py:334 + :135-172, :303) and apply the MLP's gate inside fc1's kernel (:69): the whole network gives the
+    bits of the run with the separate kernels, and the fused entry points are the ones that ran."""
     from visiontransformer_amd import functional as K
     from visiontransformer_amd import _lib, models
     torch.manual_seed(0)
@@ -513,7 +513,7 @@ def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window
 
     outs = {}
     for fuse in (True, False):
-        K.FUSE_PROJECTION = fuse
+        K.FUSE_PROJECTION = K.FUSE_GATED_SILU = fuse
         calls.clear()
         K.call = spy
         try:
@@ -521,8 +521,10 @@ def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window
                 outs[fuse] = model(x).float()
         finally:
             K.call = real_call
-            K.FUSE_PROJECTION = True
+            K.FUSE_PROJECTION = K.FUSE_GATED_SILU = True
         n_fused = calls.count("dsw_win_attn_proj_fwd")
         assert (n_fused > 0 and "dsw_win_attn_fwd" not in calls) if fuse else (n_fused == 0 and "dsw_win_attn_fwd" in calls)
+        n_gate = calls.count("dsw_linear_gated_silu")               # fc1 of the MLP with the gate in its epilogue
+        assert (n_gate > 0 and "dsw_gated_silu_fwd" not in calls) if fuse else (n_gate == 0 and "dsw_gated_silu_fwd" in calls)
     assert torch.isfinite(outs[True]).all()
     assert torch.equal(outs[True], outs[False])

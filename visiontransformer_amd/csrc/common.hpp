@@ -75,6 +75,9 @@ __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ float4 operator*(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 operator/(float4 a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// silu(g) * c of the gated MLP (DSwinT_arch.py:69), shared by the stand-alone kernel and the projection epilogue so
+// that both round alike
+__device__ __forceinline__ float gated_silu_value(float g, float c) { return g * (1.f / (1.f + __expf(-g))) * c; }
 
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
     long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
-    int convH, int convW) {
+    int convH, int convW, int gated) {
     using cfg = LnCfg<KS>;
     constexpr int LS = cfg::LS, NKS = cfg::NKS;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -187,6 +187,38 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bv[t][g] = *reinterpret_cast<const float4 *>(biasl + chunk * LN_CN + 4 * hh + t * 32 + 8 * g);
+        if constexpr (sizeof(TC) == 2) {
+            if (gated) {
+                // Gated-SiLU epilogue (DSwinT_arch.py:69): the chunk's first 32 weight rows are gate rows, the other 32
+                // the content rows of the same hidden columns, so a lane holds gate and content of one position in
+                // the same register of the two tiles.  Both are rounded to bf16 first - what the stand-alone
+                // projection would have written - and the chunk leaves as 32 columns (64 bytes per row).
+                const int ob = (nc0 + chunk) * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float y[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float bg = j == 0 ? bv[0][g].x : j == 1 ? bv[0][g].y : j == 2 ? bv[0][g].z : bv[0][g].w;
+                        const float bc = j == 0 ? bv[1][g].x : j == 1 ? bv[1][g].y : j == 2 ? bv[1][g].z : bv[1][g].w;
+                        const float gate = bf16_to_f32(f32_to_bf16(a[0][4 * g + j] + bg));
+                        const float cont = bf16_to_f32(f32_to_bf16(a[1][4 * g + j] + bc));
+                        y[j] = gated_silu_value(gate, cont);
+                    }
+                    io<bf16_t>::st4(reinterpret_cast<bf16_t *>(stg + l31 * SROW) + 8 * g + 4 * hh, make_float4(y[0], y[1], y[2], y[3]));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = i * 16 + (lane >> 2), m = m0 + wave * 32 + row, col = ob + (lane & 3) * 8;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * SROW + (lane & 3) * 16);
+                    bf16_t *dst = reinterpret_cast<bf16_t *>(C) + (size_t)m * ldc + col;
+                    if (m < M && col + 8 <= (ncols >> 1)) *reinterpret_cast<uint4 *>(dst) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                return;
+            }
+        }
 #pragma unroll
         for (int ps = 0; ps < 2 / TPP; ++ps) {
             // the residual's values are asked for before the tile goes through LDS, so that their latency
@@ -506,7 +538,7 @@ int set_lds(const void *kern, size_t lds, const char *who) {
 template <typename TA, typename TC, int KS>
 int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
                   void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, const float *resid, long long ld_resid,
-                  const float *rscale, int convH, int convW, hipStream_t st) {
+                  const float *rscale, int convH, int convW, int gated, hipStream_t st) {
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
@@ -526,12 +558,12 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
         auto kern = linear_nt_kernel<TA, TC, KS, true>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated);
     } else {
         auto kern = linear_nt_kernel<TA, TC, KS, false>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated);
     }
     return check_launch("linear_nt_kernel");
 }
@@ -554,7 +586,7 @@ extern "C" int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w
 
 static int linear_impl(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                        const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
-                       long long lda_copy, const float *resid, long long ld_resid, const float *rscale, void *stream) {
+                       long long lda_copy, const float *resid, long long ld_resid, const float *rscale, void *stream, int gated = 0) {
     if (M <= 0 || M > 0x7fffff00LL || K <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
     DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
@@ -564,7 +596,7 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
                                       "base aligned to 4 elements (K=%d lda=%lld)", K, lda);
     if (ldw < Kp || ldw % 8 || ((uintptr_t)w_p & 15))
         return fail(DSW_EUNSUPPORTED, "dsw_linear: the weight needs rows of >= %d elements (K rounded up to 64), a multiple of 8 (ldw=%d)", Kp, ldw);
-    if (ncols % 4 || ldc < ncols || ldc % 4 || ((uintptr_t)c & 15))
+    if (ncols % 4 || ldc < (gated ? ncols / 2 : ncols) || ldc % 4 || ((uintptr_t)c & 15))
         return fail(DSW_EUNSUPPORTED, "dsw_linear: C needs ncols %% 4 == 0, ldc %% 4 == 0, ldc >= ncols, a 16-byte aligned base (ncols=%d ldc=%lld)",
                     ncols, ldc);
     if (bias != nullptr && (N <= 0 || N % 4 || N > ncols || ((uintptr_t)bias & 15)))
@@ -581,11 +613,14 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
                                       "(ld_resid=%lld)", ld_resid);
     const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 ? 128 : 64);
     const int nslab = Kp / KS;
+    if (gated && (nslab != 1 || c_dtype != DSW_BF16 || ncols % 64 || ldc % 8 || a_copy != nullptr || resid != nullptr || accumulate))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear_gated_silu: needs K <= 192 (or 128 / 64 exactly padded), a bf16 result with rows of a multiple of "
+                                      "8 elements, whole chunks of 64 weight rows (K=%d rows=%d ldo=%lld)", K, ncols, ldc);
     hipStream_t st = as_stream(stream);
     int rc = DSW_OK;
 #define DSW_LINEAR_KS(KSV)                                                                                                     \
     DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
-        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, st); \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, st); \
     }))
     if (KS == 192) DSW_LINEAR_KS(192);
     else if (KS == 128) DSW_LINEAR_KS(128);
@@ -607,6 +642,12 @@ extern "C" int dsw_linear_residual(const void *a, int a_dtype, long long lda, lo
     DSW_REQUIRE(resid && scale, "dsw_linear_residual: null pointer");
     return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, N, out, DSW_F32, ldo, ncols, 0, nullptr, 0, resid, ld_resid, scale,
                        stream);
+}
+
+extern "C" int dsw_linear_gated_silu(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                                     const float *bias, void *out, long long ldo, void *stream) {
+    return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, wrows, out, DSW_BF16, ldo, wrows, 0, nullptr, 0, nullptr, 0, nullptr,
+                       stream, 1);
 }
 
 extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,
@@ -636,7 +677,7 @@ extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B
     int rc = DSW_OK;
 #define DSW_CONV_KS(KSV)                                                                                                          \
     DSW_DISPATCH_DTYPE(x_dtype, TA, DSW_DISPATCH_DTYPE(out_dtype, TC, {                                                           \
-        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, nullptr, 0, nullptr, H, W, st); \
+        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, nullptr, 0, nullptr, H, W, 0, st); \
     }))
     if (KS == 192) DSW_CONV_KS(192);
     else if (KS == 128) DSW_CONV_KS(128);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gated_silu_fwd_kernel(const TH *__restric
         float4 y = f4zero();
         if (j < H) {
             const float4 g = io<TH>::ld4(h + m * ldh + j), c = io<TH>::ld4(h + m * ldh + H + j);
-            y = make_float4(g.x * sigmoidf_(g.x) * c.x, g.y * sigmoidf_(g.y) * c.y, g.z * sigmoidf_(g.z) * c.z, g.w * sigmoidf_(g.w) * c.w);
+            y = make_float4(gated_silu_value(g.x, c.x), gated_silu_value(g.y, c.y), gated_silu_value(g.z, c.z), gated_silu_value(g.w, c.w));
         }
         io<TO>::st4(out + m * ldo + j, y);
     }

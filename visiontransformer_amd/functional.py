@@ -1103,6 +1103,57 @@ def linear_residual(a, lin, resid, r):
     return out.view(resid.shape)
 
 
+FUSE_GATED_SILU = True   # False: linear_gated_silu always declines
+
+
+def interleave_gate_content(gate_w, content_w, gate_b, content_b):
+    """The operand layout of dsw_linear_gated_silu: the rows of the two fc1 weights [H, K] in blocks of 32 -
+    gate rows 32c..32c+31, then the content rows of the same hidden columns - zero rows past H; the biases
+    alike.  -> (weight [2*ceil32(H), K], bias [2*ceil32(H)])"""
+    H, Kd = gate_w.shape
+    Hp = (H + 31) // 32 * 32
+    w = gate_w.new_zeros(Hp // 32, 2, 32, Kd)
+    b = gate_w.new_zeros(Hp // 32, 2, 32, dtype=torch.float32)
+    idx = torch.arange(H, device=gate_w.device)
+    w[idx // 32, 0, idx % 32] = gate_w.detach()
+    w[idx // 32, 1, idx % 32] = content_w.detach()
+    if gate_b is not None:
+        b[idx // 32, 0, idx % 32] = gate_b.detach().float()
+        b[idx // 32, 1, idx % 32] = content_b.detach().float()
+    return w.reshape(2 * Hp, Kd), b.reshape(2 * Hp)
+
+
+def linear_gated_silu(x, inter_w, inter_b, H):
+    """silu(fc1_gate(x)) * fc1_content(x) (DSwinT_arch.py:69) in the projection's own epilogue
+    (dsw_linear_gated_silu): the [tokens, 2H] pre-activations are never written.  inter_w / inter_b from
+    interleave_gate_content.  Inference under bf16 autocast only, K <= 192; returns the result as a view of the
+    first H columns of zero-padded bf16 rows, or None when the call is not one the kernel takes (the caller then
+    composes linear() and gated_silu()).  Same bits as that composition."""
+    if not FUSE_GATED_SILU or torch.is_grad_enabled() or autocast_dtype(None) != torch.bfloat16:
+        return None
+    N2, Kd = inter_w.shape
+    Hp = N2 // 2
+    if not (x.is_cuda and Kd <= 192 and Kd % 4 == 0 and N2 % 64 == 0 and Hp == _ceil_pad(H) and inter_w.is_contiguous()
+            and inter_w.dtype in (torch.float32, torch.bfloat16) and inter_w.data_ptr() % 16 == 0):
+        return None
+    a2 = x.reshape(-1, Kd)
+    T = a2.shape[0]
+    if T == 0:
+        return None
+    xk = _padded_rows(a2, torch.bfloat16)
+    if xk is not None:
+        a2, K_ = xk, _ceil_pad(Kd)
+    elif _mfma_operand(a2) is not None:
+        K_ = Kd
+    else:
+        return None
+    w_p, _ = _weight_operands(inter_w)
+    out = _mark_padded(torch.empty(T, Hp, dtype=torch.bfloat16, device=x.device))
+    call("dsw_linear_gated_silu", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K_, ptr(w_p),
+         N2, w_p.shape[1], ptr(inter_b), ptr(out), Hp, stream(x.device))
+    return out[:, :H].view(x.shape[:-1] + (H,))
+
+
 # ---------------------------------------------------------------------------------------------
 # RMSNorm in front of the attention modules / the MLP (DSwinT_arch.py:343-345, :355-357)
 # ---------------------------------------------------------------------------------------------

@@ -67,11 +67,30 @@ class GatedMLP(nn.Module):
             object.__setattr__(self, "_kept_fc1", kept)
         return kept[1]
 
+    def _interleaved(self):
+        """gate and content rows of fc1 in the layout of the fused projection + gated-SiLU kernel; kept between
+        calls like _stacked()"""
+        ps = (self.fc1_gate.weight, self.fc1_content.weight, self.fc1_gate.bias, self.fc1_content.bias)
+        if not K._may_keep_operands():
+            return K.interleave_gate_content(*ps)
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        kept = getattr(self, "_kept_fc1_inter", None)
+        if kept is None or kept[0] != key:
+            kept = (key, K.interleave_gate_content(*ps))
+            object.__setattr__(self, "_kept_fc1_inter", kept)
+        return kept[1]
+
     def forward(self, x, residual=None):
         """residual = (stream, r), inference only: returns stream + r * mlp(x), the residual taken inside fc2's
         kernel (the caller's ReZero residual, DSwinT_arch.py:357)."""
         if residual is not None:
-            h = K.gated_silu(K.linear(x, self._stacked(), pad_out=True), pad_out=True)
+            h = None
+            Hd = self.fc1_gate.out_features
+            if K.FUSE_GATED_SILU and (self.fc1_gate.bias is None) == (self.fc1_content.bias is None) \
+                    and (Hd + 31) // 32 * 32 == (Hd + 63) // 64 * 64 and self.fc1_gate.in_features <= 192:
+                h = K.linear_gated_silu(x, *self._interleaved(), self.fc1_gate.out_features)   # fc1 and the gate in one kernel
+            if h is None:
+                h = K.gated_silu(K.linear(x, self._stacked(), pad_out=True), pad_out=True)
             y = K.linear_residual(h, self.fc2, *residual)
             return y if y is not None else K.rezero_residual(residual[0], residual[1], K.linear(h, self.fc2))
         if not x.is_cuda:
