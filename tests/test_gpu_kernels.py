@@ -125,6 +125,49 @@ def test_select_tie_rule(cuda0):
     assert sel.cand_idx.cpu().view(-1).tolist() == [1, 2, 4, 0, 6]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [False, True])
+def test_select_at_the_lowest_temperature_with_wide_logits(cuda0, dtype, training):
+    """The end of the reference's annealing (temperature 0.1) with logits spread over +-20: logits / tau spans
+    hundreds, most probabilities underflow to exactly 0 in fp32 and DISTINCT logits tie there, where torch.topk's
+    order is unspecified.  The kernel ranks the logits themselves.  Whatever the ties: its k windows must be a
+    valid top-k of the reference's probabilities (nothing left out beats anything taken), rank by rank the same
+    probabilities, and identical windows wherever the probabilities around them are distinct.  The test also
+    counts how many images tie inside their top-k + 1 (and requires some, so that it tests what it says)."""
+    K = _K()
+    B, Hw, Ww, w, frac, tau = 16, 8, 8, 16, 0.25, 0.1
+    n, k = Hw * Ww, int(Hw * Ww * frac)
+    gen = torch.Generator().manual_seed(77 + int(training))
+    sd = (torch.randn(B, 4, Hw, Ww, generator=gen) * torch.tensor([8.0, 2.0, 2.0, 2.0]).view(1, 4, 1, 1)).to(dtype)
+    sig = sd[:, 1:].sigmoid()
+    noise = D.gumbel_noise((B, n), gen) if training else None
+    ref = D.select_windows(sd.clone(), sig.clone(), w, Hw * w, Ww * w, frac, tau, training, noise)
+    sel = K.select_windows(sd.to(cuda0), sig.to(cuda0), None if noise is None else noise.to(cuda0), tau, k, w, Hw * w, Ww * w)
+    pr = ref["probs"].detach()
+    cand = sel.cand_idx.cpu().long().view(B, k)
+    ref_flat = (ref["cand_h"] * Ww + ref["cand_w"]).view(B, k)
+    taken = pr.gather(1, cand)
+    assert torch.equal(taken, pr.gather(1, ref_flat))                       # rank by rank the same probabilities
+    left = pr.clone().scatter_(1, cand, -1.0)
+    assert bool((left.max(dim=1).values <= taken.min(dim=1).values).all())  # a valid top-k set
+    top = torch.topk(pr, k + 1, dim=1).values
+    tied_rows = (top[:, 1:] == top[:, :-1]).any(dim=1)
+    assert int(tied_rows.sum()) > 0, "no image ties at this temperature: widen the logits"
+    # within an image, a rank whose probability differs from both neighbours' is decided: same window
+    decided = torch.ones(B, k, dtype=torch.bool)
+    decided[:, 1:] &= top[:, 1:k] != top[:, :k - 1]
+    decided &= top[:, :k] != top[:, 1:k + 1]
+    assert torch.equal(cand[decided], ref_flat[decided])
+    assert bool(decided[~tied_rows].all())
+    # where the probabilities tie at zero the kernel still follows the logits (plus noise): the larger one first
+    z = sd[:, 0].reshape(B, n).float() + (noise if noise is not None else 0.0)
+    zt = z.gather(1, cand)
+    # (the division by tau is rounded to the activation dtype, as the reference rounds it: logits that meet in one
+    # bf16 quotient rank by window index, so the order of the raw logits holds to one ulp of that dtype)
+    slack = 1e-4 if dtype == torch.float32 else 2.0 ** -7 * zt[:, :-1].abs() + 1e-4
+    assert bool((zt[:, 1:] <= zt[:, :-1] + slack).all())
+
+
 # ----------------------------------------------------------------------------------------------
 # (2) gather and (4) scatter-mean
 # ----------------------------------------------------------------------------------------------
