@@ -68,13 +68,6 @@ __device__ __forceinline__ void qkv_offsets(const AttnGeom &g, int head, int &qo
     }
 }
 
-// Blocks that share blockIdx % 8 run on one XCD and share its L2: hand the heads of one window
-// (which read the same 128-byte lines of the qkv rows) to such a group.  Bijective for any nwg.
-__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-}
-
 // LDS element type and strides (in elements) chosen conflict-free for the reads below:
 //   row-major [tokens][DP + RPAD]  read 16 B per lane, rows on lanes
 //   transposed [DP][L + 4]         read 8 B (bf16) / 16 B (f32) per lane, rows on lanes

@@ -140,6 +140,15 @@ __device__ __forceinline__ bool column_sum_32x8(const float *__restrict__ src, i
     return true;
 }
 
+// Blocks that share blockIdx % 8 run on one XCD and share its L2.  Maps the hardware block index to a logical one
+// such that every XCD works through one contiguous range of logical indices: neighbours in the logical order (the
+// heads of a window, the rows of a window, vertically adjacent pixel tiles of an image) then meet in one L2 instead
+// of fetching the lines they share once per XCD.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace dsw

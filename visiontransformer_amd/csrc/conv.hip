@@ -58,7 +58,8 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
     for (int i = threadIdx.x; i < C; i += CV_THREADS) ws[9 * C + i] = (bias != nullptr && !FLIP) ? bias[i] : 0.f;
     __syncthreads();
     const int CV = C >> 2, rowq = W * CV, hblocks = (H + CW_ROWS - 1) / CW_ROWS;
-    const int seg = blockIdx.x % segs, hb = (blockIdx.x / segs) % hblocks, b = blockIdx.x / (segs * hblocks);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: the halo rows of vertical neighbours are L2 hits
+    const int seg = bid % segs, hb = (bid / segs) % hblocks, b = bid / (segs * hblocks);
     const int i = seg * CV_THREADS + threadIdx.x;
     if (i >= rowq) return;
     const int xx = i / CV, c = (i - xx * CV) << 2;
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(WG_THREADS) void dwconv_wgrad_kernel(const TG *__re
     extern __shared__ __attribute__((aligned(16))) float red[];  // [CV*3][16]: 3 tap columns + dy sum, x 4 channels
     const int CV = C >> 2, NI = CV * 3, PP = max(1, WG_THREADS / NI);
     const int rows_per_img = (H + DW_ROWS - 1) / DW_ROWS;
-    const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x - b * rows_per_img) * DW_ROWS;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // row groups of one image on one XCD: they share their halo rows
+    const int b = bid / rows_per_img, h0 = (bid - b * rows_per_img) * DW_ROWS;
     const int item = threadIdx.x % NI, part = threadIdx.x / NI;
     const int cv = item / 3, a = item - cv * 3, c = cv << 2;
     const int chunk = (W + PP - 1) / PP, p0 = part * chunk, p1 = min(p0 + chunk, W);
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(WG_THREADS) void dwconv_wgrad_kernel(const TG *__re
     for (int i = threadIdx.x; i < C * 10; i += WG_THREADS) {
         const int ch = i / 10, k = i - ch * 10;
         const int a2 = k < 9 ? k / 3 : 1, slot = k < 9 ? k - a2 * 3 : 3;
-        partial[(size_t)blockIdx.x * C * 10 + i] = red[((size_t)((ch >> 2) * 3 + a2) * 4 + slot) * 4 + (ch & 3)];
+        partial[(size_t)bid * C * 10 + i] = red[((size_t)((ch >> 2) * 3 + a2) * 4 + slot) * 4 + (ch & 3)];
     }
 }
 

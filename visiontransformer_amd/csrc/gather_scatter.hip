@@ -96,7 +96,8 @@ __global__ __launch_bounds__(GS_THREADS) void gather_fwd_kernel(
     const TI *__restrict__ x, const int *__restrict__ win_b, const int *__restrict__ win_h1,
     const int *__restrict__ win_w1, int H, int W, int C, int w, int ldo, TO *__restrict__ out) {
     // out rows are ldo >= C elements apart; the columns C..ldo-1 are set to zero
-    const int n = blockIdx.x / w, i = blockIdx.x - n * w;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the rows of a window on one XCD: they share x rows
+    const int n = bid / w, i = bid - n * w;
     const int b = win_b[n], y = win_h1[n] + i, x0 = win_w1[n];
     const TI *img = x + (size_t)b * H * W * C;
     TO *dst = out + ((size_t)n * w * w + (size_t)i * w) * ldo;
@@ -118,9 +119,10 @@ __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
     const int *__restrict__ win_w1, int H, int W, int C, int w, int ldg, int tiles_per_row, TO *__restrict__ dx) {
     __shared__ Cover cov[2][TILE_PIX + 1];
     const int Hw = H / w, Ww = W / w;
-    const int tile = blockIdx.x % tiles_per_row;
-    const int y = (blockIdx.x / tiles_per_row) % H;
-    const int b = blockIdx.x / (tiles_per_row * H);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
+    const int tile = bid % tiles_per_row;
+    const int y = (bid / tiles_per_row) % H;
+    const int b = bid / (tiles_per_row * H);
     const int x0 = tile * TILE_PIX;
     const int npix = min(TILE_PIX, W - x0);
     for (int t = threadIdx.x; t < 2 * (TILE_PIX + 1); t += GS_THREADS) {
@@ -168,9 +170,10 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_fwd_kernel(
     const int *__restrict__ win_w1, int H, int W, int C, int w, int lda, int tiles_per_row, TY *__restrict__ yout) {
     __shared__ Cover cov[TILE_PIX];
     const int Hw = H / w, Ww = W / w;
-    const int tile = blockIdx.x % tiles_per_row;
-    const int y = (blockIdx.x / tiles_per_row) % H;
-    const int b = blockIdx.x / (tiles_per_row * H);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
+    const int tile = bid % tiles_per_row;
+    const int y = (bid / tiles_per_row) % H;
+    const int b = bid / (tiles_per_row * H);
     const int x0 = tile * TILE_PIX;
     const int npix = min(TILE_PIX, W - x0);
     if (threadIdx.x < npix) cov[threadIdx.x] = find_cover(cellmap, win_h1, win_w1, b, y, x0 + threadIdx.x, Hw, Ww, w);
@@ -205,9 +208,10 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
     int W, int C, int w, int tiles_per_row, TO *__restrict__ dx) {
     __shared__ float fac[2][TILE_PIX + 1];  // sum_n(s_n*g_n)/count at the sample position, 0 if uncovered
     const int Hw = H / w, Ww = W / w;
-    const int tile = blockIdx.x % tiles_per_row;
-    const int y = (blockIdx.x / tiles_per_row) % H;
-    const int b = blockIdx.x / (tiles_per_row * H);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
+    const int tile = bid % tiles_per_row;
+    const int y = (bid / tiles_per_row) % H;
+    const int b = bid / (tiles_per_row * H);
     const int x0 = tile * TILE_PIX;
     const int npix = min(TILE_PIX, W - x0);
     for (int t = threadIdx.x; t < 2 * (TILE_PIX + 1); t += GS_THREADS) {
@@ -260,7 +264,8 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_win_kernel(
     __shared__ float inv_cnt[64];
     __shared__ float red[GS_THREADS / 64];
     const int Hw = H / w, Ww = W / w;
-    const int n = blockIdx.x / w, i = blockIdx.x - n * w;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = bid / w, i = bid - n * w;
     if (n_live != nullptr && n >= *n_live) {
         // a window slot behind the passing ones (callers that never read the count on the host hand over all
         // B*k slots): nothing was written back from it, so its gradients are zero
