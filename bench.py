@@ -217,14 +217,14 @@ def _projection_rooflines(device, iters, warm, x, out):
     x2 = x.view(M, K)
     y = torch.empty(M, Np, device=device, dtype=bf)
     xk = torch.empty(M, Kp, device=device, dtype=bf)
-    fwd = lambda: call("dsw_linear", ptr(x2), f32c, K, M, K, ptr(w_p), Np, Kp, ptr(bias), N, ptr(y), bfc, Np, Np, 0, ptr(xk), Kp, st)
+    fwd = lambda: call("dsw_linear", ptr(x2), f32c, K, M, K, ptr(w_p), Np, Kp, ptr(bias), N, ptr(y), bfc, Np, Np, 0, ptr(xk), Kp, None, 0, st)
     t_f = time_calls(fwd, iters, warm)
     dx = torch.empty(M, K, device=device)
-    dgrad = lambda: call("dsw_linear", ptr(y), bfc, Np, M, Np, ptr(w_pt), Kp, Np, None, 0, ptr(dx), f32c, K, K, 0, None, 0, st)
+    dgrad = lambda: call("dsw_linear", ptr(y), bfc, Np, M, Np, ptr(w_pt), Kp, Np, None, 0, ptr(dx), f32c, K, K, 0, None, 0, None, 0, st)
     t_d = time_calls(dgrad, iters, warm)
     dw, db = torch.empty(N, K, device=device), torch.empty(N, device=device)
     ws = torch.empty(load().dsw_linear_wgrad_workspace(M, N, K), device=device)
-    wgrad = lambda: call("dsw_linear_wgrad", ptr(y), Np, ptr(xk), Kp, M, N, K, ptr(dw), ptr(db), ptr(ws), st)
+    wgrad = lambda: call("dsw_linear_wgrad", ptr(y), Np, ptr(xk), Kp, M, N, K, ptr(dw), ptr(db), ptr(ws), None, 0, st)
     t_w = time_calls(wgrad, iters, warm)
     by_f = M * (K * 4 + Np * 2 + Kp * 2)
     by_d = M * (Np * 2 + K * 4)

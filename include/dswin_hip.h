@@ -172,7 +172,14 @@ int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtyp
 int dsw_win_attn_fwd(const void *qkv, int dtype, int layout, int n_img, int H, int W, int w,
                      int C, int heads, int ld_qkv, int ld_out, const float *bias_table,
                      float scale, const float *lepe_w, const float *lepe_b, void *out,
-                     float *lse, float dropout_p, unsigned long long dropout_seed, void *stream);
+                     float *lse, float dropout_p, unsigned long long dropout_seed, const int *n_live,
+                     void *stream);
+/* n_live (here and below; NULL = all): a counter on the device; packed windows (H = W = 0) with index >= *n_live
+ * are switched off - DS-MSA hands over a slot for every top-k candidate and leaves the number of windows that
+ * passed the gate on the device (DSwinT_arch.py:280-292 reads it on the host instead).  A switched-off window
+ * costs no arithmetic: its rows of the result are set to zero (so that later readers find finite values) and it
+ * adds nothing to any sum.  dsw_linear / dsw_linear_wgrad take the same counter as live_units with the rows per
+ * unit. */
 
 /* bytes of scratch dsw_win_attn_bwd needs (per-(window,head) partial bias-table and LePE
  * weight gradients, reduced in a fixed order by a second kernel inside the call). */
@@ -189,7 +196,7 @@ int dsw_win_attn_bwd(const void *qkv, const void *out, const void *dout, int dty
                      int ld_dout, const float *bias_table, float scale, const float *lepe_w,
                      const float *lepe_b, const float *lse, void *dqkv, float *d_bias_table,
                      float *d_lepe_w, float *d_lepe_b, void *workspace, size_t workspace_bytes,
-                     float dropout_p, unsigned long long dropout_seed, void *stream);
+                     float dropout_p, unsigned long long dropout_seed, const int *n_live, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (5) MSFT multi-scale reshapes, one pass each, no intermediate copies.
@@ -317,7 +324,7 @@ int dsw_linear_gated_silu(const void *a, int a_dtype, long long lda, long long M
  * separate calls. */
 int dsw_win_attn_proj_fwd(const void *x, long long ldx, const void *w_p, int w_rows, int ldw, const float *bias,
                           int layout, int n_img, int H, int W, int w, int C, int heads, int ld_out,
-                          const float *bias_table, float scale, void *out, float *lse, void *stream);
+                          const float *bias_table, float scale, void *out, float *lse, const int *n_live, void *stream);
 
 /* One Adam step over a list of fp32 parameter tensors, in place: replaces the optimizer step of the
  * reference's trainer (torch.optim.Adam created at toolkit/init.py:133 with betas (0.9, 0.99) and stepped at
@@ -367,7 +374,10 @@ int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, i
 int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w_p, void *w_pt, void *stream);
 int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
                int ldw, const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols,
-               int accumulate, void *a_copy, long long lda_copy, void *stream);
+               int accumulate, void *a_copy, long long lda_copy, const int *live_units, int unit_rows, void *stream);
+/* live_units (NULL = all rows), unit_rows: rows at and beyond *live_units * unit_rows are switched off (see n_live
+ * of dsw_win_attn_fwd): workgroups that hold none of the live rows compute nothing and leave zeros in their rows
+ * of c and a_copy (with accumulate: leave c as it is). */
 /* The projection that closes a branch of the reference's ViTBlock together with the ReZero residual around it
  * (DSwinT_arch.py:337 or :69 with :355-357, inference): out = resid + scale[0] * (A W^T + bias), fp32 [M][ncols]
  * with row stride ldo, resid fp32 with row stride ld_resid (it may be out itself), scale one fp32 value on the
@@ -384,7 +394,8 @@ int dsw_linear_residual(const void *a, int a_dtype, long long lda, long long M, 
  *   padding column of x);  workspace: dsw_linear_wgrad_workspace(M, N, K) floats. */
 size_t dsw_linear_wgrad_workspace(long long M, int N, int K);
 int dsw_linear_wgrad(const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K,
-                     float *dw, float *db, float *workspace, void *stream);
+                     float *dw, float *db, float *workspace, const int *live_units, int unit_rows, void *stream);
+/* live_units, unit_rows as for dsw_linear: the switched-off rows are not read and add nothing to dw / db. */
 
 /* The first convolution of the DS-MSA sparse discriminator (nn.Conv2d(dim, 4, 3, 1, 1),
  * DSwinT_arch.py:181) as a GEMM on the matrix cores, for bf16 runs: with Wf[4 t + o][c] = w0[o][c][t]

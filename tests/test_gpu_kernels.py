@@ -584,7 +584,7 @@ def test_linear_kernel(cuda0, M, K, N, a_dtype, c_dtype, pad_a, pad_c, copy):
     Kk = lda if (a_dtype == bf and pad_a) else K
     _lib.call("dsw_linear", _lib.ptr(a), _lib.dtype_code(a_dtype), lda, M, Kk, _lib.ptr(wp), wp.shape[0], wp.shape[1], _lib.ptr(bias), N,
               _lib.ptr(c), _lib.dtype_code(c_dtype), ncols, ncols, 0, _lib.ptr(a_copy) if copy else None, a_copy.shape[1] if copy else 0,
-              _lib.stream(cuda0))
+              None, 0, _lib.stream(cuda0))
     ref = a[:, :K].to(bf).float() @ w.to(bf).float().t() + bias
     tol = 1e-2 if c_dtype == bf else 1e-5 * K
     assert ((c[:, :N].float() - ref).abs().max() / ref.abs().max()).item() < tol
@@ -616,7 +616,7 @@ def test_linear_wgrad_kernel(cuda0, M, K, N):
         db = torch.full((N,), float("nan"), device=cuda0) if K < Kp else None
         ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, N, K), device=cuda0)
         _lib.call("dsw_linear_wgrad", _lib.ptr(dy), Np, _lib.ptr(x), Kp, M, N, K, _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
-                  _lib.ptr(ws), _lib.stream(cuda0))
+                  _lib.ptr(ws), None, 0, _lib.stream(cuda0))
         outs.append((dw, db))
     dw, db = outs[0]
     ref = dy[:, :N].double().t() @ x[:, :K].double()
@@ -628,7 +628,7 @@ def test_linear_wgrad_kernel(cuda0, M, K, N):
     else:
         with pytest.raises(RuntimeError, match="padding column"):
             _lib.call("dsw_linear_wgrad", _lib.ptr(dy), Np, _lib.ptr(x), Kp, M, N, K, _lib.ptr(dw), _lib.ptr(dw), _lib.ptr(ws),
-                      _lib.stream(cuda0))
+                      None, 0, _lib.stream(cuda0))
 
 
 @pytest.mark.gpu
@@ -868,3 +868,60 @@ def test_linear_gated_silu(cuda0, T, Kd, H, padded_in):
         assert float(out._base[:, H:].abs().max()) == 0.0
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert K.linear_gated_silu(xin, iw, ib, H) is None       # with autograd on the fused call declines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,w,C,heads", [(torch.bfloat16, 16, 180, 6), (torch.bfloat16, 8, 24, 2), (torch.float32, 16, 48, 3)])
+def test_switched_off_windows_cost_nothing_and_give_zeros(cuda0, dtype, w, C, heads):
+    """n_live: a counter on the device; window slots at and beyond it are switched off (DS-MSA keeps the number of
+    windows that passed the gate on the device, DSwinT_arch.py:280-292).  Attention and projections: the live part
+    equals a run on the live windows alone bit for bit, the rest is zero, forward and backward."""
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED
+    gen = torch.Generator().manual_seed(w + C)
+    n, live, L = 5, 2, w * w
+    qkv = torch.randn(n, L, 3 * C, generator=gen).to(dtype).to(cuda0)
+    table = (torch.randn((2 * w - 1) ** 2, heads, generator=gen) * 0.5).to(cuda0)
+    r = torch.randn(n, L, C, generator=gen).to(cuda0)
+    n_live = torch.tensor([live], dtype=torch.int32, device=cuda0)
+
+    def run(q, cnt):
+        q = q.clone().requires_grad_()
+        t = table.clone().requires_grad_()
+        o = K.window_attention(q, t, w, heads, QKV_CHUNKED, n_live=cnt)
+        (o.float() * r[:q.shape[0]]).sum().backward()
+        return o.detach(), q.grad, t.grad
+    o_all, dq_all, dt_all = run(qkv, n_live)
+    o_ref, dq_ref, dt_ref = run(qkv[:live], None)
+    assert torch.equal(o_all[:live], o_ref) and torch.equal(dq_all[:live], dq_ref) and torch.equal(dt_all, dt_ref)
+    assert float(o_all[live:].abs().max()) == 0.0 and float(dq_all[live:].abs().max()) == 0.0
+    zero = torch.zeros(1, dtype=torch.int32, device=cuda0)                       # nothing live: all zeros
+    o0, dq0, dt0 = run(qkv, zero)
+    assert float(o0.abs().max()) == 0.0 and float(dq0.abs().max()) == 0.0 and float(dt0.abs().max()) == 0.0
+    if dtype != torch.bfloat16:
+        return
+    # projections under bf16 autocast: rows of switched-off units are not computed, forward, input and weight gradient
+    lin = torch.nn.Linear(C, 3 * C).to(cuda0)
+    x = torch.randn(n, L, C, generator=gen).to(cuda0)
+    g = torch.randn(n, L, 3 * C, generator=gen).to(cuda0)
+    g[live:] = 0.0                                                               # what reaches switched-off rows in DS-MSA
+
+    def run_lin(xx, gg, cnt):
+        lin.zero_grad(set_to_none=True)
+        xx = xx.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = K.linear(xx, lin, pad_out=True, live=None if cnt is None else (cnt, L))
+        (y.float() * gg).sum().backward()
+        return y.detach(), xx.grad, lin.weight.grad.clone(), lin.bias.grad.clone()
+    y_all, dx_all, dw_all, db_all = run_lin(x, g, n_live)
+    y_ref, dx_ref, dw_ref, db_ref = run_lin(x[:live], g[:live], None)
+    assert torch.equal(y_all[:live], y_ref) and torch.equal(dx_all[:live], dx_ref)
+    assert float(y_all[live:].abs().max()) == 0.0 and float(dx_all[live:].abs().max()) == 0.0
+    assert rel_err(dw_all, dw_ref) < 1e-6 and rel_err(db_all, db_ref) < 1e-6    # other split of the row range: other summation order
+    # and the fused projection + attention kernel
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        xp = K._mark_padded(K.cast_rows(x.reshape(-1, C), torch.bfloat16, K._ceil_pad(C)))[:, :C].view(n, L, C)
+        z = K.projected_window_attention(xp, lin, table, w, heads, QKV_CHUNKED, n_live=n_live)
+        z_ref = K.projected_window_attention(xp[:live], lin, table, w, heads, QKV_CHUNKED)
+    if z is not None:
+        assert torch.equal(z[:live], z_ref) and float(z[live:].abs().max()) == 0.0

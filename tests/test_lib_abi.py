@@ -50,9 +50,9 @@ def test_argument_errors_are_reported_without_a_gpu():
     """argument validation happens before any HIP call, so it can be exercised on the CPU box"""
     from visiontransformer_amd import _lib
     lib = _lib.load()
-    rc = lib.dsw_win_attn_fwd(None, 0, 0, 1, 0, 0, 4, 8, 2, 0, 0, None, 1.0, None, None, None, None, 0.0, 0, None)
+    rc = lib.dsw_win_attn_fwd(None, 0, 0, 1, 0, 0, 4, 8, 2, 0, 0, None, 1.0, None, None, None, None, 0.0, 0, None, None)
     assert rc == 2 and b"window size" in lib.dswin_last_error_string()
-    rc = lib.dsw_win_attn_fwd(None, 0, 0, 1, 0, 0, 8, 8, 2, 20, 0, None, 1.0, None, None, None, None, 0.0, 0, None)
+    rc = lib.dsw_win_attn_fwd(None, 0, 0, 1, 0, 0, 8, 8, 2, 20, 0, None, 1.0, None, None, None, None, 0.0, 0, None, None)
     assert rc == 1 and b"row strides" in lib.dswin_last_error_string()
     rc = lib.dsw_gather_fwd(None, 0, None, None, None, 1, 1, 10, 16, 8, 8, None, 0, 0, None)
     assert rc == 1 and b"multiples of the window size" in lib.dswin_last_error_string()

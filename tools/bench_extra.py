@@ -122,9 +122,22 @@ def workload_t(dev):
         torch.nn.functional.l1_loss(y.float(), target).backward()
         model.zero_grad(set_to_none=True)
 
-    dt = sync_time(step, 5, warm=2)
+    import gc
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    sdwa = [m for m in model.modules() if isinstance(m, DeformableSparseWindowAttention)]
+    sync_time(step, 8, warm=4)
+    gc.collect()
+    gc.freeze()
+    dt = sync_time(step, 10, warm=2)
+    # share of the B*k window slots whose gate is open (the device-side count; read here, after the timing)
+    live = sum(int(m.last_selection.n_dev) for m in sdwa) / max(1, sum(m.last_selection.n for m in sdwa))
+    # the variant that reads the pass count on the host and processes only the passing windows
+    for m in sdwa:
+        m.static_training = False
+    dt_host = sync_time(step, 10, warm=3)
     return {"metric": "training patches/sec (DSWT x4, fwd+bwd)", "value": B / dt, "unit": "patches/s", "n_gpus": 1,
             "ms_per_step": dt * 1e3, "dtype": "bf16", "data": "synthetic",
+            "open_gate_share": live, "ms_per_step_with_host_read_of_the_pass_count": dt_host * 1e3,
             "config": {"workload": "T: DSWT default (8 blocks x 3, dim 180, w 16), batch %d of 64x64 LR" % B}}
 
 

@@ -26,7 +26,7 @@ def prep(w):
 def run(a, K, wp, bias, N, c, ncols, a_copy=None):
     _lib.call("dsw_linear", _lib.ptr(a), _lib.dtype_code(a.dtype), a.stride(0), a.shape[0], K, _lib.ptr(wp), wp.shape[0], wp.stride(0),
               _lib.ptr(bias) if bias is not None else None, N, _lib.ptr(c), _lib.dtype_code(c.dtype), c.stride(0), ncols, 0,
-              _lib.ptr(a_copy) if a_copy is not None else None, a_copy.stride(0) if a_copy is not None else 0, _lib.stream(dev))
+              _lib.ptr(a_copy) if a_copy is not None else None, a_copy.stride(0) if a_copy is not None else 0, None, 0, _lib.stream(dev))
 
 
 def case(M, K, N, a_dt, c_dt, pad_a, pad_c, copy, dgrad=False):
@@ -71,7 +71,7 @@ def wcase(M, K, N):
     dw = torch.full((N, K), float("nan"), device=dev); db = torch.full((N,), float("nan"), device=dev) if K < Kp else None
     ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, N, K), device=dev)
     f = lambda: _lib.call("dsw_linear_wgrad", _lib.ptr(dy), Np, _lib.ptr(x), Kp, M, N, K, _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
-                          _lib.ptr(ws), _lib.stream(dev))
+                          _lib.ptr(ws), None, 0, _lib.stream(dev))
     f()
     ref = dy[:, :N].double().t() @ x[:, :K].double()
     err = ((dw.double() - ref).abs().max() / ref.abs().max()).item()

@@ -13,6 +13,6 @@ dw = torch.empty(540, 180, device=dev); db = torch.empty(540, device=dev)
 ws = torch.empty(_lib.load().dsw_linear_wgrad_workspace(M, 540, 180), device=dev)
 for _ in range(3):
     _lib.call("dsw_linear", _lib.ptr(a), _lib.dtype_code(bf), 192, M, 192, _lib.ptr(wp), 576, 192, _lib.ptr(bias), 540, _lib.ptr(c), _lib.dtype_code(bf),
-              576, 576, 0, None, 0, _lib.stream(dev))
-    _lib.call("dsw_linear_wgrad", _lib.ptr(c), 576, _lib.ptr(a), 192, M, 540, 180, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream(dev))
+              576, 576, 0, None, 0, None, 0, _lib.stream(dev))
+    _lib.call("dsw_linear_wgrad", _lib.ptr(c), 576, _lib.ptr(a), 192, M, 540, 180, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), None, 0, _lib.stream(dev))
 torch.cuda.synchronize()

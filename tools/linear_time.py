@@ -12,7 +12,7 @@ def t(M, K, lda, a_dt, N, ncols, c_dt, copy):
     bias = torch.randn(N, device=dev); c = torch.empty(M, ncols, device=dev, dtype=c_dt)
     ac = torch.empty(M, (K + 63) // 64 * 64, device=dev, dtype=bf) if copy else None
     f = lambda: _lib.call("dsw_linear", _lib.ptr(a), _lib.dtype_code(a_dt), lda, M, K, _lib.ptr(wp), wp.shape[0], wp.shape[1], _lib.ptr(bias), N,
-                          _lib.ptr(c), _lib.dtype_code(c_dt), ncols, ncols, 0, _lib.ptr(ac) if copy else None, ac.shape[1] if copy else 0, _lib.stream(dev))
+                          _lib.ptr(c), _lib.dtype_code(c_dt), ncols, ncols, 0, _lib.ptr(ac) if copy else None, ac.shape[1] if copy else 0, None, 0, _lib.stream(dev))
     return bench.time_calls(f, 30) * 1e6
 M = 131072
 print("qkv bf16 %.1f | qkv f32+copy %.1f | out bf16 %.1f | dgrad->f32 %.1f | dgrad->bf16 %.1f" % (

@@ -16,6 +16,10 @@ if os.environ.get("MODEL") == "msft":
             sub.attn_drop = 0.0
 else:
     m = DSWTransformer(**DSWT_DEFAULT).to(dev).train()
+if os.environ.get("STATIC_TRAINING") == "0":      # read the pass count on the host, process only the passing windows
+    for sub in m.modules():
+        if hasattr(sub, "static_training"):
+            sub.static_training = False
 B = int(os.environ.get("T_BATCH", "32"))
 x = torch.rand(B, 3, 64, 64, device=dev); tgt = torch.rand(B, 3, 256, 256, device=dev)
 def step():
@@ -27,7 +31,7 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=90))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=int(os.environ.get("ROWS", "40")), max_name_column_width=90))
 if os.environ.get("SHAPES"):
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof2:
         step(); torch.cuda.synchronize()

@@ -34,10 +34,10 @@ SIGNATURES = {
     "dsw_scatter_mean_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 7 + [_P, _I, _P]),
     "dsw_scatter_mean_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 7 +
                              [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "dsw_win_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _F, ctypes.c_ulonglong, _P]),
+    "dsw_win_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _F, ctypes.c_ulonglong, _P, _P]),
     "dsw_win_attn_bwd_workspace": (_Z, [_I] * 8),
     "dsw_win_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P,
-                              _P, _P, _P, _P, _P, _Z, _F, ctypes.c_ulonglong, _P]),
+                              _P, _P, _P, _P, _P, _Z, _F, ctypes.c_ulonglong, _P, _P]),
     "dsw_unshuffle_nhwc_ln_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
     "dsw_unshuffle_blocks": (_I, [_I, _I, _I, _I]),
     "dsw_unshuffle_nhwc_ln_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -48,7 +48,7 @@ SIGNATURES = {
                            ctypes.c_longlong, _I, _I, _P]),
     "dsw_weight_prep": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "dsw_linear": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P,
-                        ctypes.c_longlong, _P]),
+                        ctypes.c_longlong, _P, _I, _P]),
     "dsw_linear_gated_silu": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _P, ctypes.c_longlong, _P]),
     "dsw_linear_residual": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _I, _P, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _I, _P]),
     "dsw_sd_stencil_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
@@ -56,7 +56,7 @@ SIGNATURES = {
     "dsw_sparse_disc_tail_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "dsw_sparse_disc_tail_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "dsw_linear_wgrad_workspace": (_Z, [ctypes.c_longlong, _I, _I]),
-    "dsw_linear_wgrad": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _I, _I, _P, _P, _P, _P]),
+    "dsw_linear_wgrad": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _I, _P]),
     "dsw_rmsnorm_blocks": (_I, [ctypes.c_longlong]),
     "dsw_rmsnorm_fwd": (_I, [_P, _P, _F, ctypes.c_longlong, _I, _P, _I, ctypes.c_longlong, _P, _P]),
     "dsw_rmsnorm_bwd": (_I, [_P, _I, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, _P, _P, _P, _P]),
@@ -73,7 +73,7 @@ SIGNATURES = {
     "dsw_layernorm_fwd": (_I, [_P, _P, _P, _F, ctypes.c_longlong, _I, _P, _I, ctypes.c_longlong, _P, _P, _P]),
     "dsw_layernorm_bwd": (_I, [_P, _I, ctypes.c_longlong, _P, _P, _P, _P, ctypes.c_longlong, _I, _P, _P, _P]),
     "dsw_ema_update": (_I, [_I, _P, _P, _P, _I, _F, _F, _P]),
-    "dsw_win_attn_proj_fwd": (_I, [_P, ctypes.c_longlong, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P]),
+    "dsw_win_attn_proj_fwd": (_I, [_P, ctypes.c_longlong, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
     "dsw_adam_update": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "dsw_colsum_blocks": (_I, [ctypes.c_longlong]),
     "dsw_colsum": (_I, [_P, _I, ctypes.c_longlong, _I, _P, _P, _P]),

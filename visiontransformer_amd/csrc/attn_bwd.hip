@@ -119,6 +119,16 @@ __global__ __launch_bounds__((BwdCfg<T, WS, DP>::THREADS), (BwdCfg<T, WS, DP>::M
         origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
         pitch = g.W;
     }
+    if (window_is_off(g, win)) {  // uniform over the workgroup: zero gradients, nothing read
+        zero_window_slice<T>(dqkv, C3, origin, pitch, WS, qoff, d, false, 0, tid, THREADS);
+        zero_window_slice<T>(dqkv, C3, origin, pitch, WS, koff, d, false, 0, tid, THREADS);
+        zero_window_slice<T>(dqkv, C3, origin, pitch, WS, voff, d, head == g.heads - 1, 3 * g.C, tid, THREADS);
+        if constexpr (BIAS) {
+            constexpr int TRR = 2 * WS - 1;
+            for (int it = tid; it < TRR * TRR; it += THREADS) ws_table[((size_t)win * g.heads + head) * (TRR * TRR) + it] = 0.f;
+        }
+        return;
+    }
     auto trow = [&](int l) -> size_t { return origin + (size_t)(l / WS) * pitch + (l % WS); };
     const float sc2 = scale * LOG2E;
     auto bits = [](T v) -> uint32_t {
@@ -888,10 +898,12 @@ extern "C" int dsw_win_attn_bwd(const void *qkv, const void *out, const void *do
                                 const float *bias_table, float scale, const float *lepe_w, const float *lepe_b, const float *lse,
                                 void *dqkv, float *d_bias_table, float *d_lepe_w, float *d_lepe_b,
                                 void *workspace, size_t workspace_bytes, float dropout_p, unsigned long long dropout_seed,
-                                void *stream) {
+                                const int *n_live, void *stream) {
     AttnGeom g;
     int rc = make_geom("dsw_win_attn_bwd", n_img, H, W, w, C, heads, layout, ld_qkv, ld_out, ld_dout, g);
     if (rc) return rc;
+    DSW_REQUIRE(n_live == nullptr || (H == 0 && lepe_w == nullptr), "dsw_win_attn_bwd: n_live goes with packed windows (H = W = 0) and no LePE");
+    g.n_live = n_live;
     DropArgs drop;
     rc = make_drop("dsw_win_attn_bwd", dropout_p, dropout_seed, drop);
     if (rc) return rc;

@@ -165,6 +165,14 @@ __global__ __launch_bounds__(512, (DP == 32 ? 4 : 2)) void win_attn_bwd_w16_kern
     const int dw = lane % DWR, rsub = lane / DWR;
 
     const Where cur = locate(blockIdx.x);
+    if (window_is_off(g, cur.win)) {  // uniform over the workgroup: zero gradients, nothing read
+        zero_window_slice<T>(dqkv, C3, cur.origin, cur.pitch, WS, cur.qoff, d, false, 0, tid, THREADS);
+        zero_window_slice<T>(dqkv, C3, cur.origin, cur.pitch, WS, cur.koff, d, false, 0, tid, THREADS);
+        zero_window_slice<T>(dqkv, C3, cur.origin, cur.pitch, WS, cur.voff, d, cur.head == g.heads - 1, 3 * g.C, tid, THREADS);
+        if constexpr (BIAS)
+            for (int it = tid; it < TR * TR; it += THREADS) ws_table[((size_t)cur.win * g.heads + cur.head) * (TR * TR) + it] = 0.f;
+        return;
+    }
     load_item(cur);
     {
         // ---- K and V pass through the operand images, only to be picked up as this wave's B fragments ---

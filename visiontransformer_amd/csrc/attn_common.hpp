@@ -19,6 +19,7 @@ struct AttnGeom {
     int C, heads, d; // channels, heads, head dim
     int layout;      // DSW_QKV_*
     int ldq, ldo, ldg;  // row strides in elements: qkv / dqkv (>= 3C), out (>= C), dout (>= C)
+    const int *n_live;  // device counter or null: packed windows with index >= *n_live are switched off
 };
 
 // Attention dropout (DSwinT_arch.py:172, msft_arch.py:136) without a mask tensor: the keep decision of score
@@ -65,6 +66,29 @@ __device__ __forceinline__ void qkv_offsets(const AttnGeom &g, int head, int &qo
         qoff = head * 3 * g.d;
         koff = qoff + g.d;
         voff = qoff + 2 * g.d;
+    }
+}
+
+// Switched-off windows (DS-MSA slots behind the windows that passed the gate, counted on the device): no arithmetic;
+// the window's rows of the result are set to zero so that later readers find finite values.
+__device__ __forceinline__ bool window_is_off(const AttnGeom &g, int win) { return g.n_live != nullptr && win >= *g.n_live; }
+
+// zero the head's d columns starting at column col0 of the window's L rows of a [rows][ld] matrix, and (last head
+// only) the padding columns first_pad..ld-1
+template <typename T>
+__device__ __forceinline__ void zero_window_slice(T *__restrict__ m, int ld, size_t origin, int pitch, int ws, int col0, int d,
+                                                  bool pad, int first_pad, int tid, int nthreads) {
+    const int L = ws * ws;
+    for (int it = tid; it < L * d; it += nthreads) {
+        const int l = it / d, e = it - l * d;
+        m[(origin + (size_t)(l / ws) * pitch + (l % ws)) * ld + col0 + e] = (T)0;
+    }
+    if (pad && ld > first_pad) {
+        const int np = ld - first_pad;
+        for (int it = tid; it < L * np; it += nthreads) {
+            const int l = it / np, e = it - l * np;
+            m[(origin + (size_t)(l / ws) * pitch + (l % ws)) * ld + first_pad + e] = (T)0;
+        }
     }
 }
 

@@ -53,6 +53,12 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
         origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
         pitch = g.W;
     }
+    if (window_is_off(g, win)) {  // uniform over the workgroup
+        zero_window_slice<T>(out, g.ldo, origin, pitch, WS, head * d, d, head == g.heads - 1, g.C, tid, THREADS);
+        if (lse != nullptr)
+            for (int l = tid; l < L; l += THREADS) lse[((size_t)win * g.heads + head) * L + l] = 0.f;
+        return;
+    }
 
     // ---- stage Q (times scale*log2(e)), K and V ---------------------------------------------------
     // When d < DP the first padding column of V is set to ones: row d of O^T = V^T P^T is then the
@@ -191,6 +197,7 @@ int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads,
     g.ldq = ld_qkv ? ld_qkv : 3 * C;
     g.ldo = ld_out ? ld_out : C;
     g.ldg = ld_dout ? ld_dout : C;
+    g.n_live = nullptr;
     if (g.ldq < 3 * C || g.ldo < C || g.ldg < C || (g.d % 2 == 0 && ((g.ldq | g.ldo | g.ldg) & 1)))
         return fail(DSW_EINVAL, "%s: row strides (%d, %d, %d) must be >= 3C, C, C (and even for an even head dim)", who,
                     g.ldq, g.ldo, g.ldg);
@@ -215,10 +222,12 @@ using namespace dsw;
 extern "C" int dsw_win_attn_fwd(const void *qkv, int dtype, int layout, int n_img, int H, int W, int w, int C,
                                 int heads, int ld_qkv, int ld_out, const float *bias_table, float scale,
                                 const float *lepe_w, const float *lepe_b, void *out, float *lse, float dropout_p,
-                                unsigned long long dropout_seed, void *stream) {
+                                unsigned long long dropout_seed, const int *n_live, void *stream) {
     AttnGeom g;
     int rc = make_geom("dsw_win_attn_fwd", n_img, H, W, w, C, heads, layout, ld_qkv, ld_out, 0, g);
     if (rc) return rc;
+    DSW_REQUIRE(n_live == nullptr || H == 0, "dsw_win_attn_fwd: n_live goes with packed windows (H = W = 0)");
+    g.n_live = n_live;
     DropArgs drop;
     rc = make_drop("dsw_win_attn_fwd", dropout_p, dropout_seed, drop);
     if (rc) return rc;

@@ -64,6 +64,12 @@ __global__ __launch_bounds__((ProjCfg<WS>::THREADS), (ProjCfg<WS>::F::MIN_WAVES)
         origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
         pitch = g.W;
     }
+    if (window_is_off(g, win)) {  // uniform over the workgroup
+        zero_window_slice<bf16_t>(out, g.ldo, origin, pitch, WS, head * d, d, head == g.heads - 1, g.C, threadIdx.x, THREADS);
+        if (lse != nullptr)
+            for (int l = threadIdx.x; l < L; l += THREADS) lse[((size_t)win * g.heads + head) * L + l] = 0.f;
+        return;
+    }
 
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int tok = wave * 32 + l31;
@@ -249,10 +255,12 @@ using namespace dsw;
 
 extern "C" int dsw_win_attn_proj_fwd(const void *x, long long ldx, const void *w_p, int w_rows, int ldw, const float *bias,
                                      int layout, int n_img, int H, int W, int w, int C, int heads, int ld_out,
-                                     const float *bias_table, float scale, void *out, float *lse, void *stream) {
+                                     const float *bias_table, float scale, void *out, float *lse, const int *n_live, void *stream) {
     AttnGeom g;
     const int rc = make_geom("dsw_win_attn_proj_fwd", n_img, H, W, w, C, heads, layout, 0, ld_out, 0, g);
     if (rc) return rc;
+    DSW_REQUIRE(n_live == nullptr || H == 0, "dsw_win_attn_proj_fwd: n_live goes with packed windows (H = W = 0)");
+    g.n_live = n_live;
     DSW_REQUIRE(x && w_p && out, "dsw_win_attn_proj_fwd: null pointer");
     if (g.d > PROJ_DP) return fail(DSW_EUNSUPPORTED, "dsw_win_attn_proj_fwd: head dim %d > %d", g.d, PROJ_DP);
     if (ldw < C || ldw % 64 || w_rows < 3 * C)

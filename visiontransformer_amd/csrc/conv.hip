@@ -108,7 +108,11 @@ constexpr int DW_ROWS = 4;
 constexpr int WG_THREADS = 448;  // 3 parts x (45 quads x 3 tap rows) at C = 180
 template <typename TG, typename TX>
 __global__ __launch_bounds__(WG_THREADS) void dwconv_wgrad_kernel(const TG *__restrict__ dy, const TX *__restrict__ x, int H,
-                                                                  int W, int C, float *__restrict__ partial) {
+                                                                  int W, int C, float *__restrict__ partial,
+                                                                  const int *__restrict__ identity_if_zero) {
+    // the forward was the identity (no window passed the gate): the gradients are zero, and split10_kernel, which
+    // reads the same counter, writes the zeros without looking at the partial sums
+    if (identity_if_zero != nullptr && *identity_if_zero == 0) return;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [CV*3][16]: 3 tap columns + dy sum, x 4 channels
     const int CV = C >> 2, NI = CV * 3, PP = max(1, WG_THREADS / NI);
     const int rows_per_img = (H + DW_ROWS - 1) / DW_ROWS;
@@ -743,7 +747,7 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
         auto kern = dwconv_wgrad_kernel<TG, TX>;
         rc = set_lds_attr(kern, lds2, "dsw_dwconv3x3_bwd");
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WG_THREADS), lds2, st, (const TG *)dy, (const TX *)x, H, W, C, partial);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WG_THREADS), lds2, st, (const TG *)dy, (const TX *)x, H, W, C, partial, identity_if_zero);
     }));
     rc = check_launch("dwconv_wgrad_kernel");
     if (rc) return rc;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
     long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
-    int convH, int convW, int gated) {
+    int convH, int convW, int gated, const int *__restrict__ live_units, int unit_rows) {
     using cfg = LnCfg<KS>;
     constexpr int LS = cfg::LS, NKS = cfg::NKS;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -130,6 +130,31 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const int total_chunks = (ncols + LN_CN - 1) / LN_CN;
     const int nc0 = blockIdx.y * chunks_per_block;
     const int nch = min(chunks_per_block, total_chunks - nc0);  // >= 1 by the grid's construction
+    if (live_units != nullptr) {
+        // Rows at and beyond *live_units * unit_rows belong to units (windows) the caller has switched off on the
+        // device: a block that holds none of the live rows does no work.  It leaves zeros in its part of the result
+        // (and of the bf16 copy), so that whatever reads these rows later finds finite values; with accumulation
+        // into the destination the rows are left as they are.
+        const long long live_rows = (long long)*live_units * unit_rows;
+        if (m0 >= live_rows) {
+            if (resid == nullptr) {
+                const int c0 = nc0 * (gated ? LN_CN / 2 : LN_CN), c1 = min((nc0 + nch) * (gated ? LN_CN / 2 : LN_CN), gated ? ncols / 2 : ncols);
+                const int cq = (c1 - c0) >> 2;
+                for (int i = tid; i < rows * cq; i += LN_THREADS) {
+                    const int r = i / cq, c = c0 + ((i - r * cq) << 2);
+                    io<TC>::st4(C + (size_t)(m0 + r) * ldc + c, f4zero());
+                }
+            }
+            if (a_copy != nullptr && blockIdx.y == 0) {
+                const int Kq = (int)(lda_copy >> 2) < ((K + 63) / 64 * 64) >> 2 ? (int)(lda_copy >> 2) : ((K + 63) / 64 * 64) >> 2;
+                for (int i = tid; i < rows * Kq; i += LN_THREADS) {
+                    const int r = i / Kq, c = (i - r * Kq) << 2;
+                    io<bf16_t>::st4(a_copy + (size_t)(m0 + r) * lda_copy + c, f4zero());
+                }
+            }
+            return;
+        }
+    }
 
     // staging: 8 threads per row, 8 elements each = 64 columns; a slab is KS / 64 such column groups
     // (immediate offsets) over 4 (A: 128 rows) or 2 (weight chunk: 64 rows) row groups
@@ -382,7 +407,8 @@ constexpr size_t WG_LDS = (size_t)2 * WG_BM * WG_LS * sizeof(bf16_t);
 
 __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_t *__restrict__ dY, long long ldy,
                                                                       const bf16_t *__restrict__ X, long long ldx, int M, int K, int Kp,
-                                                                      int Np, int Kpr, int rows_per_block, int convH, int convW, float *__restrict__ partial) {
+                                                                      int Np, int Kpr, int rows_per_block, int convH, int convW, float *__restrict__ partial,
+                                                                      const int *__restrict__ live_units, int unit_rows) {
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t *Ys = reinterpret_cast<bf16_t *>(smem);
     bf16_t *Xs = Ys + WG_BM * WG_LS;
@@ -390,7 +416,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
     const int wn = wave % 3, wk = wave / 3;
     const int n0 = blockIdx.x * WG_TN;
     const int m_begin = blockIdx.y * rows_per_block;
-    const int rows = min(M - m_begin, rows_per_block);  // >= 1 by the grid's construction
+    // rows at and beyond *live_units * unit_rows are switched off by the caller (see linear_nt_kernel): they add
+    // nothing, and a block whose range holds none of the live rows writes a zero partial
+    const long long m_end = live_units != nullptr ? min((long long)M, (long long)*live_units * unit_rows) : (long long)M;
+    const int rows = (int)max(0ll, min(m_end - m_begin, (long long)rows_per_block));
     const int nst = (rows + WG_BM - 1) / WG_BM;
     // 3x3 convolution mode (convH > 0): rows are the pixels of NHWC images, blockIdx.z also runs over the 9
     // taps, and a tap's block reads the rows of X shifted by the tap's offset (zero outside the image): its
@@ -405,9 +434,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
     // staging: piece = 8 consecutive columns; 24 pieces per row, 16 rows per pass of the block
     const int prow = tid / 24, pc = tid - prow * 24;
     const bool y_ok = n0 + pc * 8 < Np, x_ok = k0 + pc * 8 < Kp;
-    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(dY + (size_t)m_begin * ldy + n0, ((size_t)(rows - 1) * ldy + (Np - n0)) * sizeof(bf16_t));
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(dY + (size_t)m_begin * ldy + n0, rows > 0 ? ((size_t)(rows - 1) * ldy + (Np - n0)) * sizeof(bf16_t) : 0);
     const __amdgpu_buffer_rsrc_t rs_x = conv ? make_rsrc(X, ((size_t)(M - 1) * ldx + Kp) * sizeof(bf16_t))
-                                             : make_rsrc(X + (size_t)m_begin * ldx, ((size_t)(rows - 1) * ldx + Kp) * sizeof(bf16_t));
+                                             : make_rsrc(X + (size_t)m_begin * ldx, rows > 0 ? ((size_t)(rows - 1) * ldx + Kp) * sizeof(bf16_t) : 0);
     const unsigned y_off = (unsigned)(((size_t)prow * ldy + pc * 8) * sizeof(bf16_t));
     const unsigned x_off = (unsigned)(((size_t)prow * ldx + k0 + pc * 8) * sizeof(bf16_t));
     const unsigned y_step = (unsigned)(16 * ldy * sizeof(bf16_t)), x_step = (unsigned)(16 * ldx * sizeof(bf16_t));
@@ -460,7 +489,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void linear_wgrad_kernel(const bf16_
     const bf16_t *ytr = Ys + (4 * hh + trq) * WG_LS + wn * 64 + 16 * trg + 4 * trp;
     const bf16_t *xtr = Xs + (4 * hh + trq) * WG_LS + wk * 96 + 16 * trg + 4 * trp;
 
-    load_stage(0);
+    if (nst > 0) load_stage(0);
     for (int st = 0; st < nst; ++st) {
         if (st > 0) lds_barrier();  // the previous stage's reads are over
         write_stage(st);
@@ -538,7 +567,7 @@ int set_lds(const void *kern, size_t lds, const char *who) {
 template <typename TA, typename TC, int KS>
 int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
                   void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, const float *resid, long long ld_resid,
-                  const float *rscale, int convH, int convW, int gated, hipStream_t st) {
+                  const float *rscale, int convH, int convW, int gated, const int *live_units, int unit_rows, hipStream_t st) {
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
@@ -558,12 +587,12 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
         auto kern = linear_nt_kernel<TA, TC, KS, true>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows);
     } else {
         auto kern = linear_nt_kernel<TA, TC, KS, false>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows);
     }
     return check_launch("linear_nt_kernel");
 }
@@ -586,7 +615,8 @@ extern "C" int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w
 
 static int linear_impl(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                        const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
-                       long long lda_copy, const float *resid, long long ld_resid, const float *rscale, void *stream, int gated = 0) {
+                       long long lda_copy, const float *resid, long long ld_resid, const float *rscale, void *stream, int gated = 0,
+                       const int *live_units = nullptr, int unit_rows = 0) {
     if (M <= 0 || M > 0x7fffff00LL || K <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
     DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
@@ -616,11 +646,13 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
     if (gated && (nslab != 1 || c_dtype != DSW_BF16 || ncols % 64 || ldc % 8 || a_copy != nullptr || resid != nullptr || accumulate))
         return fail(DSW_EUNSUPPORTED, "dsw_linear_gated_silu: needs K <= 192 (or 128 / 64 exactly padded), a bf16 result with rows of a multiple of "
                                       "8 elements, whole chunks of 64 weight rows (K=%d rows=%d ldo=%lld)", K, ncols, ldc);
+    if (live_units != nullptr && (unit_rows <= 0 || (resid != nullptr && !accumulate)))
+        return fail(DSW_EINVAL, "dsw_linear: live_units needs unit_rows > 0 and no separate residual (unit_rows=%d)", unit_rows);
     hipStream_t st = as_stream(stream);
     int rc = DSW_OK;
 #define DSW_LINEAR_KS(KSV)                                                                                                     \
     DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
-        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, st); \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, live_units, unit_rows, st); \
     }))
     if (KS == 192) DSW_LINEAR_KS(192);
     else if (KS == 128) DSW_LINEAR_KS(128);
@@ -631,9 +663,9 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
 
 extern "C" int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                           const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
-                          long long lda_copy, void *stream) {
+                          long long lda_copy, const int *live_units, int unit_rows, void *stream) {
     return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, N, c, c_dtype, ldc, ncols, accumulate, a_copy, lda_copy, nullptr, 0,
-                       nullptr, stream);
+                       nullptr, stream, 0, live_units, unit_rows);
 }
 
 extern "C" int dsw_linear_residual(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
@@ -677,7 +709,7 @@ extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B
     int rc = DSW_OK;
 #define DSW_CONV_KS(KSV)                                                                                                          \
     DSW_DISPATCH_DTYPE(x_dtype, TA, DSW_DISPATCH_DTYPE(out_dtype, TC, {                                                           \
-        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, nullptr, 0, nullptr, H, W, 0, st); \
+        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, nullptr, 0, nullptr, H, W, 0, nullptr, 0, st); \
     }))
     if (KS == 192) DSW_CONV_KS(192);
     else if (KS == 128) DSW_CONV_KS(128);
@@ -709,7 +741,8 @@ extern "C" size_t dsw_linear_wgrad_workspace(long long M, int N, int K) { return
 extern "C" size_t dsw_conv3x3_wgrad_workspace(int B, int H, int W, int Co, int Ci) { return wgrad_ws((long long)B * H * W, Co, Ci, 9); }
 
 static int wgrad_launch(const char *who, const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K, int convH,
-                        int convW, float *dw, float *db, float *workspace, void *stream) {
+                        int convW, float *dw, float *db, float *workspace, void *stream, const int *live_units = nullptr, int unit_rows = 0) {
+    if (live_units != nullptr && (unit_rows <= 0 || convH > 0)) return fail(DSW_EINVAL, "%s: live_units needs unit_rows > 0 (unit_rows=%d)", who, unit_rows);
     if (M <= 0 || M > 0x7fffff00LL || N <= 0 || K <= 0) return fail(DSW_EINVAL, "%s: bad sizes M=%lld N=%d K=%d", who, M, N, K);
     DSW_REQUIRE(dy && x && dw && workspace, "%s: null pointer", who);
     const int ntap = convH > 0 ? 9 : 1;
@@ -728,7 +761,7 @@ static int wgrad_launch(const char *who, const void *dy, long long ldy, const vo
     int rc = set_lds((const void *)linear_wgrad_kernel, WG_LDS, who);
     if (rc) return rc;
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3((Np + WG_TN - 1) / WG_TN, S, ntap * (Kpr / WG_TK)), dim3(WG_THREADS), WG_LDS, st,
-                       (const bf16_t *)dy, ldy, (const bf16_t *)x, ldx, (int)M, K, Kp, Np, Kpr, rpb, convH, convW, workspace);
+                       (const bf16_t *)dy, ldy, (const bf16_t *)x, ldx, (int)M, K, Kp, Np, Kpr, rpb, convH, convW, workspace, live_units, unit_rows);
     rc = check_launch("linear_wgrad_kernel");
     if (rc) return rc;
     const int items = N * (ntap * Kpr / 4);
@@ -737,8 +770,8 @@ static int wgrad_launch(const char *who, const void *dy, long long ldy, const vo
 }
 
 extern "C" int dsw_linear_wgrad(const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K, float *dw,
-                                float *db, float *workspace, void *stream) {
-    return wgrad_launch("dsw_linear_wgrad", dy, ldy, x, ldx, M, N, K, 0, 0, dw, db, workspace, stream);
+                                float *db, float *workspace, const int *live_units, int unit_rows, void *stream) {
+    return wgrad_launch("dsw_linear_wgrad", dy, ldy, x, ldx, M, N, K, 0, 0, dw, db, workspace, stream, live_units, unit_rows);
 }
 
 extern "C" int dsw_conv3x3_wgrad(const void *dy, long long ldy, const void *x, long long ldx, int B, int H, int W, int Co, int Ci,

@@ -241,11 +241,15 @@ class DeformableSparseWindowAttention(WindowedAttention):
             sel = K.select_windows_static(sd, noise, self.temperature, k, w, H, W)
             self.last_selection = sel.detached()
             before = K.gather_windows(x, sel, w, out_dtype=act, sink=sink, pad_out=True)
-            z = K.projected_window_attention(before, self.in_proj, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
+            # the slots behind the windows that passed are switched off inside the kernels (device-side count):
+            # no arithmetic for them in the projections and the attention, forward or backward
+            live = (sel.n_dev, w * w)
+            z = K.projected_window_attention(before, self.in_proj, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True,
+                                             n_live=sel.n_dev)
             if z is None:
-                qkv = K.linear(before, self.in_proj, pad_out=True)
-                z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True)
-            after = K.linear(z, self.out_proj, pad_out=True)
+                qkv = K.linear(before, self.in_proj, pad_out=True, live=live)
+                z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True, n_live=sel.n_dev)
+            after = K.linear(z, self.out_proj, pad_out=True, live=live)
             y = K.scatter_mean_residual(x, after, sel, w, sink=sink)
             # no window passed (DSwinT_arch.py:291-292: return x): the last kernel copies instead of convolving
             return K.dwconv3x3_nhwc(y, self.out_conv.weight, self.out_conv.bias, out_dtype=act, identity_if_zero=sel.n_dev)

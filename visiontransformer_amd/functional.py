@@ -417,7 +417,7 @@ def _dptr(t):
 
 class _WinAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, table, lepe_w, lepe_b, layout, n_img, H, W, w, heads, scale, pad_out, drop_p=0.0, drop_seed=0):
+    def forward(ctx, qkv, table, lepe_w, lepe_b, layout, n_img, H, W, w, heads, scale, pad_out, drop_p=0.0, drop_seed=0, n_live=None):
         _lib.require_cuda(qkv)
         C3 = qkv.shape[-1]
         C = C3 // 3
@@ -436,9 +436,10 @@ class _WinAttnFn(torch.autograd.Function):
         lse = torch.empty(n_win, heads, L, dtype=torch.float32, device=dev)
         call("dsw_win_attn_fwd", _dptr(qkv2), dtype_code(qkv.dtype), layout, n_img, H, W, w, C, heads, ldq, ldo,
              ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(out), ptr(lse), _c_float(drop_p), ctypes.c_ulonglong(drop_seed),
-             stream(dev))
+             None if n_live is None else ptr(n_live), stream(dev))
         ctx.save_for_backward(qkv2, out, lse, tab, lw, lb)
         ctx.drop = (float(drop_p), int(drop_seed))
+        ctx.n_live = n_live
         ctx.meta = (layout, n_img, H, W, w, C, heads, scale, ldq, ldo, lead,
                     None if table is None else (table.shape, table.dtype),
                     None if lepe_w is None else (lepe_w.shape, lepe_w.dtype, lepe_b.dtype))
@@ -465,11 +466,11 @@ class _WinAttnFn(torch.autograd.Function):
         call("dsw_win_attn_bwd", _dptr(qkv2), ptr(out), _dptr(dout2), dtype_code(qkv2.dtype), layout, n_img, H, W, w, C,
              heads, ldq, ldo, ldg, ptr(tab), _c_float(scale), ptr(lw), ptr(lb), ptr(lse), ptr(dqkv), ptr(d_tab),
              ptr(d_lw), ptr(d_lb), ptr(ws), ctypes.c_size_t(int(nbytes)), _c_float(ctx.drop[0]), ctypes.c_ulonglong(ctx.drop[1]),
-             stream(dev))
+             None if ctx.n_live is None else ptr(ctx.n_live), stream(dev))
         g_tab = None if tab is None else d_tab.view(tmeta[0]).to(tmeta[1])
         g_lw = None if lw is None else d_lw.view(lmeta[0]).to(lmeta[1])
         g_lb = None if lb is None else d_lb.to(lmeta[2])
-        return (dqkv[:, :3 * C].view(lead + (3 * C,)), g_tab, g_lw, g_lb) + (None,) * 10
+        return (dqkv[:, :3 * C].view(lead + (3 * C,)), g_tab, g_lw, g_lb) + (None,) * 11
 
 
 def draw_dropout_seed():
@@ -479,7 +480,7 @@ def draw_dropout_seed():
 
 
 def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w=None, lepe_b=None, pad_out=False,
-                     dropout_p=0.0, dropout_seed=None):
+                     dropout_p=0.0, dropout_seed=None, n_live=None):
     """softmax(q k^T * scale + bias) v per (window, head), de-headified.
 
     dropout_p > 0: attention dropout on the probabilities, decided inside the kernels by a hash of
@@ -491,6 +492,8 @@ def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w
     lepe_w/lepe_b: depthwise 3x3 conv [C,1,3,3]/[C] applied to V inside each window and added.
     qkv may be a view of the first 3C columns of a buffer with padded rows (see `linear`); with
     pad_out the result is such a view too (rows padded to a multiple of 64 elements, zeros).
+    n_live (packed windows only): int32 counter on the device; windows with index >= its value are switched off -
+    no arithmetic, zero rows in the result, zero gradients.
     """
     C = qkv.shape[-1] // 3
     if scale is None:
@@ -503,13 +506,13 @@ def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w
     if dropout_p > 0.0 and dropout_seed is None:
         dropout_seed = draw_dropout_seed()
     return _run(_WinAttnFn, qkv, table, lepe_w, lepe_b, int(layout), int(n_img), int(H), int(W), int(w),
-                            int(heads), float(scale), bool(pad_out), dropout_p, int(dropout_seed or 0))
+                            int(heads), float(scale), bool(pad_out), dropout_p, int(dropout_seed or 0), n_live)
 
 
 FUSE_PROJECTION = True   # False: projected_window_attention always declines (the two separate kernels run)
 
 
-def projected_window_attention(x, lin, table, w, heads, layout, grid=None, scale=None, pad_out=False):
+def projected_window_attention(x, lin, table, w, heads, layout, grid=None, scale=None, pad_out=False, n_live=None):
     """window_attention(linear(x, lin), ...) as one kernel (dsw_win_attn_proj_fwd): q|k|v are projected per
     (window, head) inside the attention kernel and never written to memory.  Inference under bf16 autocast only,
     head dim <= 32, x in zero-padded bf16 rows (what rms_norm(..., for_projection=True) and
@@ -546,7 +549,8 @@ def projected_window_attention(x, lin, table, w, heads, layout, grid=None, scale
     ldo = _ceil_pad(C) if pad_out else C
     out = _mark_padded(torch.empty(xk.shape[0], ldo, dtype=torch.bfloat16, device=x.device))
     call("dsw_win_attn_proj_fwd", _dptr(xk), xk.stride(0), ptr(w_p), w_p.shape[0], w_p.shape[1], ptr(b32), int(layout), int(n_img),
-         int(H), int(W), int(w), C, int(heads), ldo, ptr(tab), _c_float(scale), ptr(out), None, stream(x.device))
+         int(H), int(W), int(w), C, int(heads), ldo, ptr(tab), _c_float(scale), ptr(out), None, None if n_live is None else ptr(n_live),
+         stream(x.device))
     return out[:, :C].view(x.shape[:-1] + (C,))
 
 
@@ -750,7 +754,7 @@ class _SparseDiscFn(torch.autograd.Function):
                 dwf = torch.empty(36, C, **f32)
                 dbf = torch.empty(36, **f32) if C < Kp else None
                 ws = torch.empty(int(_lib.load().dsw_linear_wgrad_workspace(M, 36, C)), **f32)
-                call("dsw_linear_wgrad", ptr(G), 64, ptr(xk), Kp, M, 36, C, ptr(dwf), None if dbf is None else ptr(dbf), ptr(ws), stream(dev))
+                call("dsw_linear_wgrad", ptr(G), 64, ptr(xk), Kp, M, 36, C, ptr(dwf), None if dbf is None else ptr(dbf), ptr(ws), None, 0, stream(dev))
                 g[0] = dwf.view(3, 3, 4, C).permute(2, 3, 0, 1).contiguous()
                 g[1] = dbf[16:20] if dbf is not None else dt0.sum(0)
             else:
@@ -912,13 +916,14 @@ def _mfma_operand(t2):
     return None
 
 
-def _mfma_linear(a2, K, w_op, bias, N, out, ncols, a_copy, accumulate=False):
+def _mfma_linear(a2, K, w_op, bias, N, out, ncols, a_copy, accumulate=False, live=None):
     """out[:, :ncols] (+)= a2[:, :K] @ w_op[:ncols, :]^T (+ bias); a_copy (optional) receives a2 in padded bf16 rows"""
     call("dsw_linear", ctypes.c_void_p(a2.data_ptr()), dtype_code(a2.dtype), a2.stride(0) if a2.shape[0] > 1 else a2.shape[1],
          a2.shape[0], K, ptr(w_op), w_op.shape[0], w_op.shape[1], None if bias is None else ptr(bias), N, ptr(out),
          dtype_code(out.dtype), out.stride(0) if out.shape[0] > 1 else out.shape[1], ncols, 1 if accumulate else 0,
          None if a_copy is None else ptr(a_copy),
-         0 if a_copy is None else a_copy.shape[1], stream(out.device))
+         0 if a_copy is None else a_copy.shape[1], None if live is None else ptr(live[0]), 0 if live is None else int(live[1]),
+         stream(out.device))
 
 
 class _LinearFn(torch.autograd.Function):
@@ -940,7 +945,7 @@ class _LinearFn(torch.autograd.Function):
       chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act_dtype, pad_out):
+    def forward(ctx, x, weight, bias, act_dtype, pad_out, live=None):
         N, Kd = weight.shape
         x2 = x.reshape(-1, Kd)
         T = x2.shape[0]
@@ -968,7 +973,7 @@ class _LinearFn(torch.autograd.Function):
                     a2 = xk = _cast_padded(x2, act_dtype)
                     K = Kp
                 y_p = torch.empty(T, Nout, dtype=act_dtype, device=x2.device)
-                _mfma_linear(a2, K, w_p, b32, N, y_p, Nout, a_copy)
+                _mfma_linear(a2, K, w_p, b32, N, y_p, Nout, a_copy, live=live)
                 if xk is None:
                     xk = x2  # no weight gradient wanted: only the shape is read
                 w_saved = w_pt
@@ -986,6 +991,7 @@ class _LinearFn(torch.autograd.Function):
             _mark_padded(y_p)  # padding columns = zero weight rows x finite inputs + zero bias
         ctx.save_for_backward(xk, w_saved)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, N, Kd, mfma)
+        ctx.live = live if mfma else None
         return y_p[:, :N].view(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -1021,11 +1027,11 @@ class _LinearFn(torch.autograd.Function):
                         K = Np
                 if xdt == act:
                     dx_p = _mark_padded(torch.empty(T, Kp, dtype=act, device=dy2.device))
-                    _mfma_linear(a2, K, w_s, None, 0, dx_p, Kp, a_copy)
+                    _mfma_linear(a2, K, w_s, None, 0, dx_p, Kp, a_copy, live=ctx.live)
                     dx = dx_p[:, :Kd].view(xshape) if Kp != Kd else dx_p.view(xshape)
                 else:
                     dx = torch.empty(T, Kd, dtype=xdt, device=dy2.device)
-                    _mfma_linear(a2, K, w_s, None, 0, dx, Kd, a_copy)
+                    _mfma_linear(a2, K, w_s, None, 0, dx, Kd, a_copy, live=ctx.live)
                     dx = dx.view(xshape)
             if dyk is None and (need_dw or (need_dx and dx is None)):
                 dyk = _cast_padded(dy2, act) if dy2.dtype != act else dy2.contiguous()
@@ -1046,8 +1052,9 @@ class _LinearFn(torch.autograd.Function):
                     fused_db = want_db and Kd < Kp
                     dbf = torch.empty(N, dtype=torch.float32, device=dyk.device) if fused_db else None
                     ws = torch.empty(int(_lib.load().dsw_linear_wgrad_workspace(T, N, Kd)), dtype=torch.float32, device=dyk.device)
+                    live = ctx.live
                     call("dsw_linear_wgrad", ptr(dyk), Np, ptr(xk), Kp, T, N, Kd, ptr(dw), None if dbf is None else ptr(dbf), ptr(ws),
-                         stream(dyk.device))
+                         None if live is None else ptr(live[0]), 0 if live is None else int(live[1]), stream(dyk.device))
                     dw = dw.to(wdt)
                     if fused_db:
                         db = dbf.to(bdt)
@@ -1059,15 +1066,18 @@ class _LinearFn(torch.autograd.Function):
                     dw = (dyk.t() @ xk).float()[:N, :Kd].to(wdt)
             if want_db and db is None:
                 db = colsum(dyk)[:N].to(bdt)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x, lin, pad_out=False):
+def linear(x, lin, pad_out=False, live=None):
     """`lin(x)` for an nn.Linear `lin`, honouring CUDA autocast like F.linear does.  pad_out: leave
     the result in rows padded to a multiple of 64 elements (returned as a view of the first
-    out_features columns); for callers whose consumers accept such views."""
+    out_features columns); for callers whose consumers accept such views.
+    live = (counter, unit_rows): an int32 counter on the device; the rows at and beyond counter * unit_rows are
+    switched off (DS-MSA: the window slots behind the ones that passed the gate) - under bf16 autocast the kernels do
+    no work for them, forward or backward, and leave zeros in their place; other paths compute them like any row."""
     act = autocast_dtype(x.dtype)
-    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out))
+    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out), live)
 
 
 def linear_residual(a, lin, resid, r):
