@@ -460,6 +460,16 @@ int dsw_rezero_dropout_fwd(const float *x, const void *branch, int b_dtype, long
 int dsw_rezero_dropout_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r,
                            const unsigned char *mask, float keep_scale, long long M, int C, void *d_branch,
                            long long ld_db, float *partial, void *stream);
+/* The same with the keep decisions taken from a 64-bit seed instead of a mask tensor (no mask is drawn, written or
+ * read): elements 2i, 2i+1 of the dense [M][C] matrix share the 32-bit hash of pair index i (mod 2^32) - the
+ * murmur3 finaliser of (i + seed_lo) ^ seed_hi - the even element takes its bits 0-15, the odd one bits 16-31, an
+ * element is kept when its 16 bits are >= round(p * 65536), and kept values are scaled by 1 / (1 - p); p in [0, 1).
+ * Forward and backward evaluate the same function of (seed, position). */
+int dsw_rezero_dropout_seeded_fwd(const float *x, const void *branch, int b_dtype, long long ldb, const float *r, float p,
+                                  unsigned long long seed, long long M, int C, float *y, void *stream);
+int dsw_rezero_dropout_seeded_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r, float p,
+                                  unsigned long long seed, long long M, int C, void *d_branch, long long ld_db, float *partial,
+                                  void *stream);
 
 /* Dense 3x3 convolution, stride 1, zero padding 1, on an NHWC tensor (the LastChannelConv2D layers of the
  * reference's model assembly, DSwinT_arch.py:36-44, used at :372 and :420) on the matrix cores: the product kernel of dsw_linear with one k slab per tap, the rows of tap t read shifted by

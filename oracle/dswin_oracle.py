@@ -73,6 +73,21 @@ def deheadify(x):
     return x.permute(0, 2, 1, 3).contiguous().view(N, L, -1)
 
 
+def _pair_hash(pair, seed):
+    """the 32-bit hash of pair indices (uint32 array) under a 64-bit seed: (pair + seed_lo) ^ seed_hi through the
+    murmur3 finaliser (include/dswin_hip.h, dsw_win_attn_fwd / dsw_rezero_dropout_seeded_fwd)"""
+    import numpy as np
+    seed_lo, seed_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x = (pair + seed_lo) ^ seed_hi
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x85EBCA6B)
+        x ^= x >> np.uint32(13)
+        x *= np.uint32(0xC2B2AE35)
+        x ^= x >> np.uint32(16)
+    return x
+
+
 def dropout_keep_mask(n_win, num_heads, L, p, seed):
     """The keep decisions of the build's in-kernel attention dropout, [n_win, h, L, L] bool, from the rule
     include/dswin_hip.h states for dsw_win_attn_fwd (torch's own dropout draws cannot be reproduced across
@@ -81,20 +96,27 @@ def dropout_keep_mask(n_win, num_heads, L, p, seed):
     finaliser; key k takes bits 0-15 (k even) or 16-31 (k odd) of x and is kept when they are >= round(p*65536)."""
     import numpy as np
     thr = min(int(round(p * 65536.0)), 65535)
-    seed_lo, seed_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
     rows = np.arange(n_win * num_heads * L, dtype=np.uint64).reshape(-1, 1)
     pair = ((rows * np.uint64(L // 2) + np.arange(L // 2, dtype=np.uint64).reshape(1, -1)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    with np.errstate(over="ignore"):
-        x = (pair + seed_lo) ^ seed_hi
-        x ^= x >> np.uint32(16)
-        x *= np.uint32(0x85EBCA6B)
-        x ^= x >> np.uint32(13)
-        x *= np.uint32(0xC2B2AE35)
-        x ^= x >> np.uint32(16)
+    x = _pair_hash(pair, seed)
     keep = np.empty((rows.shape[0], L), dtype=bool)
     keep[:, 0::2] = (x & np.uint32(0xFFFF)) >= thr
     keep[:, 1::2] = (x >> np.uint32(16)) >= thr
     return torch.from_numpy(keep).view(n_win, num_heads, L, L)
+
+
+def elementwise_keep_mask(numel, p, seed):
+    """The keep decisions of the seeded dropout on a dense tensor of `numel` elements (the drop_path of the
+    reference's ViTBlock, DSwinT_arch.py:352, applied inside the residual kernel): elements 2i, 2i+1 share the hash
+    of pair index i mod 2^32, low / high 16 bits, kept when >= round(p*65536).  -> flat bool tensor."""
+    import numpy as np
+    thr = min(int(round(p * 65536.0)), 65535)
+    pair = (np.arange((numel + 1) // 2, dtype=np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    x = _pair_hash(pair, seed)
+    keep = np.empty(2 * pair.shape[0], dtype=bool)
+    keep[0::2] = (x & np.uint32(0xFFFF)) >= thr
+    keep[1::2] = (x >> np.uint32(16)) >= thr
+    return torch.from_numpy(keep[:numel])
 
 
 def attention(q, k, v, C, num_heads, attn_drop=0.0, pe=0, training=False, keep=None):

@@ -741,8 +741,9 @@ def test_rezero_residual(cuda0, bdtype, padded):
 @pytest.mark.parametrize("bdtype,padded", [(torch.float32, False), (torch.bfloat16, True)])
 @pytest.mark.parametrize("p", [0.1, 0.6, 1.0])
 def test_rezero_residual_with_dropout(cuda0, bdtype, padded, p):
-    """x + r * dropout(branch) with the mask applied inside the residual kernel: the mask is the one torch's
-    generator gives for the same seed, values and the three gradients match the torch expression on it."""
+    """x + r * dropout(branch) with the dropout applied inside the residual kernel: the keep decisions are the
+    oracle's function of (seed, position) - no mask tensor exists - or an explicit mask; values and the three
+    gradients match the torch expression on that mask."""
     from visiontransformer_amd import functional as K
     torch.manual_seed(11)
     B, H, W, C = 2, 9, 11, 180
@@ -754,19 +755,31 @@ def test_rezero_residual_with_dropout(cuda0, bdtype, padded, p):
     br = buf[:, :C].view(B, H, W, C).detach().requires_grad_()
     dy = torch.randn(B, H, W, C, device=cuda0)
     drop = torch.nn.Dropout(p).train()
-    torch.manual_seed(5)
-    mask = torch.empty(B * H * W, C, dtype=torch.uint8, device=cuda0).bernoulli_(1.0 - p).view(B, H, W, C)
     keep = 1.0 / (1.0 - p) if p < 1.0 else 0.0
-    assert p == 1.0 or abs(float(mask.float().mean()) - (1 - p)) < 0.02
-    ref = x + r * (br.float() * mask * keep)
-    gx, gr, gb = torch.autograd.grad(ref, (x, r, br), dy)
-    torch.manual_seed(5)
-    got = K.rezero_residual(x, r, br, dropout=drop)
-    hx, hr, hb = torch.autograd.grad(got, (x, r, br), dy)
     tol = 1e-5 if bdtype == torch.float32 else 1e-2
-    assert rel_err(got, ref) < 1e-6 and rel_err(hx, gx) < 1e-6
-    assert rel_err(hr, gr) < 1e-4 and rel_err(hb.float(), gb.float()) < tol
-    assert torch.equal(hb == 0, (mask == 0) | (dy == 0) if p < 1.0 else torch.ones_like(mask, dtype=torch.bool))
+    seed = 0x1234_5678_9ABC_DEF1
+    if p < 1.0:
+        masks = [(D.elementwise_keep_mask(B * H * W * C, p, seed).view(B, H, W, C).to(cuda0).to(torch.uint8), dict(dropout_seed=seed))]
+    else:
+        masks = [(torch.zeros(B, H, W, C, dtype=torch.uint8, device=cuda0), {})]
+    explicit = torch.empty(B, H, W, C, dtype=torch.uint8, device=cuda0).bernoulli_(1.0 - p)
+    masks.append((explicit, dict(dropout_mask=explicit)))
+    for mask, kw in masks:
+        assert p == 1.0 or abs(float(mask.float().mean()) - (1 - p)) < 0.02
+        ref = x + r * (br.float() * mask * keep)
+        gx, gr, gb = torch.autograd.grad(ref, (x, r, br), dy)
+        got = K.rezero_residual(x, r, br, dropout=drop, **kw)
+        hx, hr, hb = torch.autograd.grad(got, (x, r, br), dy)
+        assert rel_err(got, ref) < 1e-6 and rel_err(hx, gx) < 1e-6
+        assert rel_err(hr, gr) < 1e-4 and rel_err(hb.float(), gb.float()) < tol
+        assert torch.equal(hb == 0, (mask == 0) | (dy == 0) if p < 1.0 else torch.ones_like(mask, dtype=torch.bool))
+    if p < 1.0:     # the seed comes from torch's CPU generator when none is given: reproducible under manual_seed
+        torch.manual_seed(5)
+        a = K.rezero_residual(x, r, br, dropout=drop)
+        torch.manual_seed(5)
+        b = K.rezero_residual(x, r, br, dropout=drop)
+        c = K.rezero_residual(x, r, br, dropout=drop)
+        assert torch.equal(a, b) and not torch.equal(a, c)
     # evaluation mode: no mask, the plain residual
     assert torch.equal(K.rezero_residual(x, r, br, dropout=drop.eval()), K.rezero_residual(x, r, br))
 

@@ -873,7 +873,6 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
 
 int make_geom(const char *who, int n_img, int H, int W, int w, int C, int heads, int layout, int ld_qkv, int ld_out,
               int ld_dout, AttnGeom &g);
-int make_drop(const char *who, float p, unsigned long long seed, DropArgs &d);
 
 }  // namespace dsw
 

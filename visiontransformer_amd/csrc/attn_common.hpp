@@ -28,20 +28,7 @@ struct AttnGeom {
 // serves the two adjacent keys 2j, 2j+1 of a query row: pair index = ((window * heads + head) * L + q) * L/2 + j
 // (mod 2^32); the even key takes the hash's low 16 bits, the odd key the high 16 bits, and an element is kept
 // when its 16 bits are >= thr = round(p * 65536).  Kept probabilities are scaled by 1 / (1 - p).
-struct DropArgs {
-    uint32_t thr;      // 0: no dropout
-    uint32_t seed_lo, seed_hi;
-    float inv_keep;    // 1 / (1 - p)
-};
-__device__ __forceinline__ uint32_t drop_hash(uint32_t pair_idx, uint32_t seed_lo, uint32_t seed_hi) {
-    uint32_t x = (pair_idx + seed_lo) ^ seed_hi;  // then the murmur3 finaliser
-    x ^= x >> 16;
-    x *= 0x85EBCA6Bu;
-    x ^= x >> 13;
-    x *= 0xC2B2AE35u;
-    x ^= x >> 16;
-    return x;
-}
+// (DropArgs and drop_hash are in common.hpp: the residual kernels use the same rule on their elements)
 
 // Row of the C layout of a 32x32 MFMA result held in register r by lane half hh.
 __device__ __forceinline__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }

@@ -149,6 +149,29 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
+// Dropout without a mask tensor: a keep decision is a function of a 64-bit seed and a position, which the forward
+// and the backward kernels both evaluate (and which a CPU check can evaluate too).  One 32-bit hash serves a PAIR
+// of adjacent elements: x = (pair index + seed_lo) ^ seed_hi through the murmur3 finaliser; the first element
+// takes bits 0-15 of x, the second bits 16-31, and an element is kept when its 16 bits are >= thr =
+// round(p * 65536).  Kept values are scaled by 1 / (1 - p).  How positions map to pair indices is the caller's
+// (attention: see attn_common.hpp; element-wise: element index / 2).
+struct DropArgs {
+    uint32_t thr;      // 0: no dropout
+    uint32_t seed_lo, seed_hi;
+    float inv_keep;    // 1 / (1 - p)
+};
+__device__ __forceinline__ uint32_t drop_hash(uint32_t pair_idx, uint32_t seed_lo, uint32_t seed_hi) {
+    uint32_t x = (pair_idx + seed_lo) ^ seed_hi;  // then the murmur3 finaliser
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+
+int make_drop(const char *who, float p, unsigned long long seed, DropArgs &d);  // C-ABI arguments -> kernel form
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace dsw

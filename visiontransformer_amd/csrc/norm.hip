@@ -248,10 +248,19 @@ __device__ __forceinline__ float4 drop4(float4 v, uint32_t m4, float keep) {
                        (m4 & 0xff000000u) ? v.w * keep : 0.f);
 }
 
+// the same with the decisions taken from the seed (DropArgs): e0 = index of the first of the 4 elements in the
+// dense [M][C] matrix (a multiple of 4); elements 2i, 2i+1 share pair index i (mod 2^32)
+__device__ __forceinline__ float4 drop4_seeded(float4 v, long long e0, const DropArgs &d) {
+    const uint32_t pair = (uint32_t)(e0 >> 1);
+    const uint32_t h0 = drop_hash(pair, d.seed_lo, d.seed_hi), h1 = drop_hash(pair + 1u, d.seed_lo, d.seed_hi);
+    return make_float4((h0 & 0xffffu) >= d.thr ? v.x * d.inv_keep : 0.f, (h0 >> 16) >= d.thr ? v.y * d.inv_keep : 0.f,
+                       (h1 & 0xffffu) >= d.thr ? v.z * d.inv_keep : 0.f, (h1 >> 16) >= d.thr ? v.w * d.inv_keep : 0.f);
+}
+
 template <typename TB>
 __global__ __launch_bounds__(256) void rezero_fwd_kernel(const float *__restrict__ x, const TB *__restrict__ b, long long ldb,
                                                          const float *__restrict__ r, const unsigned char *__restrict__ mask, float keep,
-                                                         long long M, int C, float *__restrict__ y) {
+                                                         DropArgs drop, long long M, int C, float *__restrict__ y) {
     const float rv = *r;
     const int per_row = C / 4;
     const long long items = M * per_row;
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(256) void rezero_fwd_kernel(const float *__restrict
         const float4 xv = *reinterpret_cast<const float4 *>(x + m * C + j);
         float4 bv = io<TB>::ld4(b + m * ldb + j);
         if (mask != nullptr) bv = drop4(bv, *reinterpret_cast<const uint32_t *>(mask + m * C + j), keep);
+        else if (drop.thr) bv = drop4_seeded(bv, m * C + j, drop);
         *reinterpret_cast<float4 *>(y + m * C + j) = xv + bv * rv;
     }
 }
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(256) void rezero_fwd_kernel(const float *__restrict
 template <typename TB>
 __global__ __launch_bounds__(256) void rezero_bwd_kernel(const float *__restrict__ dy, const TB *__restrict__ b, long long ldb,
                                                          const float *__restrict__ r, const unsigned char *__restrict__ mask, float keep,
-                                                         long long M, int C, TB *__restrict__ db, long long ld_db,
+                                                         DropArgs drop, long long M, int C, TB *__restrict__ db, long long ld_db,
                                                          float *__restrict__ partial) {
     __shared__ float red[4];
     const float rv = *r;
@@ -285,6 +295,7 @@ __global__ __launch_bounds__(256) void rezero_bwd_kernel(const float *__restrict
             float4 g = *reinterpret_cast<const float4 *>(dy + m * C + j);
             const float4 bv = io<TB>::ld4(b + m * ldb + j);
             if (mask != nullptr) g = drop4(g, *reinterpret_cast<const uint32_t *>(mask + m * C + j), keep);
+            else if (drop.thr) g = drop4_seeded(g, m * C + j, drop);
             acc += g.x * bv.x + g.y * bv.y + g.z * bv.z + g.w * bv.w;
             o = g * rv;
         }
@@ -308,21 +319,22 @@ unsigned rz_blocks(long long items) { return (unsigned)((items + 255) / 256 < RZ
 extern "C" int dsw_rezero_blocks(long long M, long long ld) { return M > 0 && ld > 0 ? (int)rz_blocks(M * (ld / 4)) : 0; }
 
 static int rezero_fwd_impl(const char *who, const float *x, const void *branch, int b_dtype, long long ldb, const float *r,
-                           const unsigned char *mask, float keep, long long M, int C, float *y, void *stream) {
+                           const unsigned char *mask, float keep, long long M, int C, float *y, void *stream,
+                           const DropArgs &drop = DropArgs{0u, 0u, 0u, 1.f}) {
     int rc = rz_check(who, M, C, ldb);
     if (rc) return rc;
     DSW_REQUIRE(x && branch && r && y, "%s: null pointer", who);
     if ((uintptr_t)mask & 3) return fail(DSW_EUNSUPPORTED, "%s: the mask needs a 4-byte aligned base", who);
     DSW_DISPATCH_DTYPE(b_dtype, TB, {
         hipLaunchKernelGGL(rezero_fwd_kernel<TB>, dim3(rz_blocks(M * (C / 4))), dim3(256), 0, as_stream(stream), x, (const TB *)branch, ldb, r,
-                           mask, keep, M, C, y);
+                           mask, keep, drop, M, C, y);
     });
     return check_launch("rezero_fwd_kernel");
 }
 
 static int rezero_bwd_impl(const char *who, const float *dy, const void *branch, int b_dtype, long long ldb, const float *r,
                            const unsigned char *mask, float keep, long long M, int C, void *d_branch, long long ld_db, float *partial,
-                           void *stream) {
+                           void *stream, const DropArgs &drop = DropArgs{0u, 0u, 0u, 1.f}) {
     int rc = rz_check(who, M, C, ldb);
     if (rc) return rc;
     if (ld_db < C || ld_db % 4) return fail(DSW_EUNSUPPORTED, "%s: gradient row stride %lld (a multiple of 4, >= C)", who, ld_db);
@@ -330,7 +342,7 @@ static int rezero_bwd_impl(const char *who, const float *dy, const void *branch,
     if ((uintptr_t)mask & 3) return fail(DSW_EUNSUPPORTED, "%s: the mask needs a 4-byte aligned base", who);
     DSW_DISPATCH_DTYPE(b_dtype, TB, {
         hipLaunchKernelGGL(rezero_bwd_kernel<TB>, dim3(rz_blocks(M * (ld_db / 4))), dim3(256), 0, as_stream(stream), dy, (const TB *)branch,
-                           ldb, r, mask, keep, M, C, (TB *)d_branch, ld_db, partial);
+                           ldb, r, mask, keep, drop, M, C, (TB *)d_branch, ld_db, partial);
     });
     return check_launch("rezero_bwd_kernel");
 }
@@ -356,6 +368,24 @@ extern "C" int dsw_rezero_dropout_bwd(const float *dy, const void *branch, int b
                                       float *partial, void *stream) {
     DSW_REQUIRE(mask, "dsw_rezero_dropout_bwd: null mask");
     return rezero_bwd_impl("dsw_rezero_dropout_bwd", dy, branch, b_dtype, ldb, r, mask, keep_scale, M, C, d_branch, ld_db, partial, stream);
+}
+
+extern "C" int dsw_rezero_dropout_seeded_fwd(const float *x, const void *branch, int b_dtype, long long ldb, const float *r, float p,
+                                             unsigned long long seed, long long M, int C, float *y, void *stream) {
+    DropArgs drop;
+    const int rc = make_drop("dsw_rezero_dropout_seeded_fwd", p, seed, drop);
+    if (rc) return rc;
+    return rezero_fwd_impl("dsw_rezero_dropout_seeded_fwd", x, branch, b_dtype, ldb, r, nullptr, 1.f, M, C, y, stream, drop);
+}
+
+extern "C" int dsw_rezero_dropout_seeded_bwd(const float *dy, const void *branch, int b_dtype, long long ldb, const float *r, float p,
+                                             unsigned long long seed, long long M, int C, void *d_branch, long long ld_db,
+                                             float *partial, void *stream) {
+    DropArgs drop;
+    const int rc = make_drop("dsw_rezero_dropout_seeded_bwd", p, seed, drop);
+    if (rc) return rc;
+    return rezero_bwd_impl("dsw_rezero_dropout_seeded_bwd", dy, branch, b_dtype, ldb, r, nullptr, 1.f, M, C, d_branch, ld_db, partial,
+                           stream, drop);
 }
 
 // ---- LayerNorm over channel rows (the nn.LayerNorm layers of msft's ViTBlock, msft_arch.py:152-153, applied

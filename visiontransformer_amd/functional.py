@@ -1277,14 +1277,18 @@ def gated_silu(h, pad_out=False):
 # ---------------------------------------------------------------------------------------------
 class _RezeroFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, branch, sink=None, mask=None, keep=1.0):
+    def forward(ctx, x, r, branch, sink=None, mask=None, keep=1.0, seeded=None):
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         b2, ldb = _row_view4(branch, C)
         M = x2.shape[0]
         r32 = r.detach().float().reshape(1).contiguous()
         y = torch.empty(M, C, dtype=torch.float32, device=x.device)
-        if mask is None:
+        if seeded is not None:     # (p, seed): the keep decisions are a hash of the seed and the position, no mask tensor
+            call("dsw_rezero_dropout_seeded_fwd", ptr(x2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), _c_float(seeded[0]),
+                 ctypes.c_ulonglong(seeded[1]), M, C, ptr(y), stream(x.device))
+            ctx.save_for_backward(b2, r32)
+        elif mask is None:
             call("dsw_rezero_fwd", ptr(x2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(y), stream(x.device))
             ctx.save_for_backward(b2, r32)
         else:
@@ -1292,6 +1296,7 @@ class _RezeroFn(torch.autograd.Function):
                  ptr(y), stream(x.device))
             ctx.save_for_backward(b2, r32, mask)
         ctx.meta = (x.shape, branch.shape, ldb, r.shape, r.dtype, sink, float(keep))
+        ctx.seeded = seeded
         return y.view(x.shape)
 
     @staticmethod
@@ -1308,7 +1313,10 @@ class _RezeroFn(torch.autograd.Function):
             ld_db = ldb if ldb > C else C     # padded rows stay padded on the way back
             dbuf = _mark_padded(torch.empty(M, ld_db, dtype=b2.dtype, device=b2.device))
             partial = torch.empty(_lib.load().dsw_rezero_blocks(M, ld_db), dtype=torch.float32, device=b2.device)
-            if mask is None:
+            if ctx.seeded is not None:
+                call("dsw_rezero_dropout_seeded_bwd", ptr(dy2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), _c_float(ctx.seeded[0]),
+                     ctypes.c_ulonglong(ctx.seeded[1]), M, C, ptr(dbuf), ld_db, ptr(partial), stream(b2.device))
+            elif mask is None:
                 call("dsw_rezero_bwd", ptr(dy2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), M, C, ptr(dbuf), ld_db, ptr(partial),
                      stream(b2.device))
             else:
@@ -1317,21 +1325,23 @@ class _RezeroFn(torch.autograd.Function):
             db = (dbuf[:, :C] if ld_db != C else dbuf).view(bshape)
             dr = partial.sum().reshape(rshape).to(rdt)
         if sink is None or not ctx.needs_input_grad[0]:
-            return dy, dr, db, None, None, None
+            return dy, dr, db, None, None, None, None
         # the residual's share of x's gradient is dy itself: the norm's backward reads it and writes the sum
         sink._same_pass()
         if sink.buf is not None:  # the norm's gradient came first: its buffer is ours to add into
             sink.buf.view(M, C).add_(dy2)
-            return sink.deliver(sink.buf), dr, db, None, None, None
-        return sink.deliver(dy2.view(xshape)), dr, db, None, None, None
+            return sink.deliver(sink.buf), dr, db, None, None, None, None
+        return sink.deliver(dy2.view(xshape)), dr, db, None, None, None, None
 
 
-def rezero_residual(x, r, branch, sink=None, dropout=None):
+def rezero_residual(x, r, branch, sink=None, dropout=None, dropout_seed=None, dropout_mask=None):
     """x + r * dropout(branch) for the fp32 stream x [..., C], a one-element parameter r and a branch of the
     same shape in fp32 / bf16 (dense or a view of padded rows).  dropout: the nn.Dropout the reference puts on
-    the branch (DSwinT_arch.py:352, :355-357) or None; in training its Bernoulli mask is drawn from torch's
-    generator as one byte per element and applied inside the residual kernel (forward and backward), in
-    place of a dropout pass, its mask pass and their backward over the branch."""
+    the branch (DSwinT_arch.py:352, :355-357) or None; in training it is applied inside the residual kernel
+    (forward and backward), in place of a dropout pass, its mask pass and their backward over the branch.  The
+    keep decisions are a hash of a 64-bit seed - dropout_seed, or drawn from torch's CPU generator (reproducible
+    under torch.manual_seed, replayed by activation checkpointing) - and the element's position: no mask tensor is
+    drawn, stored or read.  dropout_mask: an explicit uint8 mask [..., C] (0 = dropped) to use instead."""
     C = x.shape[-1]
     ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and r.numel() == 1
           and branch.shape == x.shape and branch.dtype in (torch.float32, torch.bfloat16))
@@ -1341,7 +1351,12 @@ def rezero_residual(x, r, branch, sink=None, dropout=None):
     if dropout is None or not dropout.training or dropout.p == 0:
         return _run(_RezeroFn, x, r, branch, sink)
     p = float(dropout.p)
-    mask = torch.empty(x.numel() // C, C, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p)
+    if dropout_mask is None and p < 1.0:
+        seed = draw_dropout_seed() if dropout_seed is None else int(dropout_seed)
+        return _run(_RezeroFn, x, r, branch, sink, None, 1.0, (p, seed))
+    if dropout_mask is None:        # p = 1: everything dropped
+        dropout_mask = torch.zeros(x.numel() // C, C, dtype=torch.uint8, device=x.device)
+    mask = dropout_mask.reshape(-1, C).contiguous()
     return _run(_RezeroFn, x, r, branch, sink, mask, 1.0 / (1.0 - p) if p < 1.0 else 0.0)
 
 
