@@ -686,102 +686,376 @@ __global__ __launch_bounds__(1024) void bias_grad_reduce_kernel(const float *__r
 // With out = SDPA(q,k,v) + LePE(v):  delta = rowsum(dO * (out - LePE(v)))   (for the main kernel),
 // dV_lepe = conv^T(dO) written into the v slots of dqkv (the main kernel adds its dV on top),
 // and per-window partial sums of the depthwise weight / bias gradients.
-template <typename T, int WS>
-__global__ __launch_bounds__(256) void lepe_bwd_pre_kernel(AttnGeom g, const T *__restrict__ qkv, const T *__restrict__ out,
-                                                           const T *__restrict__ dout, const float *__restrict__ lepe_w,
-                                                           const float *__restrict__ lepe_b, T *__restrict__ dqkv,
-                                                           float *__restrict__ delta_out, float *__restrict__ ws_lepe) {
-    constexpr int L = WS * WS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int d = g.d, C = g.C, C3 = g.ldq;
-    T *Vs = reinterpret_cast<T *>(smem);  // [L][d]
-    T *Gs = Vs + L * d;                   // dO
-    T *Os = Gs + L * d;                   // out
-    float *wl = reinterpret_cast<float *>(Os + L * d + ((L * d) & 1));  // [d][10]: 9 taps + bias
-    const int tid = threadIdx.x;
-    const int win = blockIdx.x / g.heads, head = blockIdx.x - win * g.heads;
-    int qoff, koff, voff;
-    qkv_offsets(g, head, qoff, koff, voff);
-    size_t origin;
-    int pitch;
-    if (g.H == 0) {
-        origin = (size_t)win * L;
-        pitch = WS;
-    } else {
-        const int per = g.nWh * g.nWw;
-        const int b = win / per, r = win - b * per;
-        const int wr = r / g.nWw, wc = r - wr * g.nWw;
-        origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
-        pitch = g.W;
-    }
-    auto trow = [&](int l) -> size_t { return origin + (size_t)(l / WS) * pitch + (l % WS); };
-    for (int it = tid; it < L * d; it += 256) {
-        const int row = it / d, e = it - row * d;
-        const size_t tr = trow(row);
-        Vs[it] = qkv[tr * C3 + voff + e];
-        Gs[it] = dout[tr * g.ldg + head * d + e];
-        Os[it] = out[tr * g.ldo + head * d + e];
-    }
-    for (int it = tid; it < d * 10; it += 256) {
-        const int e = it / 10, k = it - e * 10;
-        wl[it] = k < 9 ? lepe_w[(size_t)(head * d + e) * 9 + k] : lepe_b[head * d + e];
-    }
-    __syncthreads();
-    // delta
-    for (int q = tid; q < L; q += 256) {
-        const int qi = q / WS, qj = q - qi * WS;
-        float acc = 0.f;
-        for (int e = 0; e < d; ++e) {
-            float lp = wl[e * 10 + 9];
+// In LDS one element holds CH channels of one position: a bf16 pair in 4 bytes when CH = 2.
+template <typename T, int CH> struct LepeElem { using type = T; };
+template <> struct LepeElem<bf16_t, 2> { using type = uint32_t; };
+
+// CH floats side by side: with CH = 2 the arithmetic below is packed fp32 (v_pk_fma_f32) on the channel pair
+template <int CH> struct LepeVec { typedef float type __attribute__((ext_vector_type(CH))); };
+
+// a window row of WS positions (16-byte aligned when the element has 4 bytes) as floats
+template <typename T, int WS, int CH, typename E>
+__device__ __forceinline__ void lepe_row(const E *p, typename LepeVec<CH>::type (&x)[WS]) {
+    if constexpr (sizeof(E) == 4) {
 #pragma unroll
-            for (int a = -1; a <= 1; ++a)
+        for (int j0 = 0; j0 < WS; j0 += 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(p + j0);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                for (int bb = -1; bb <= 1; ++bb) {
-                    const int ni = qi + a, nj = qj + bb;
-                    if (ni >= 0 && ni < WS && nj >= 0 && nj < WS) lp += wl[e * 10 + (a + 1) * 3 + bb + 1] * io<T>::ld(Vs + (ni * WS + nj) * d + e);
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (CH == 2) {
+                    x[j0 + u][0] = __uint_as_float(w[u] << 16);
+                    x[j0 + u][1] = __uint_as_float(w[u] & 0xffff0000u);
+                } else {
+                    x[j0 + u][0] = __uint_as_float(w[u]);
                 }
-            acc += io<T>::ld(Gs + q * d + e) * (io<T>::ld(Os + q * d + e) - lp);
-        }
-        delta_out[((size_t)win * g.heads + head) * L + q] = acc;
-    }
-    // dV_lepe[k][e] = sum_taps W[e][tap] * dO[k - tap][e]
-    for (int it = tid; it < L * d; it += 256) {
-        const int k = it / d, e = it - k * d;
-        const int ki = k / WS, kj = k - ki * WS;
-        float acc = 0.f;
-#pragma unroll
-        for (int a = -1; a <= 1; ++a)
-#pragma unroll
-            for (int bb = -1; bb <= 1; ++bb) {
-                const int ni = ki - a, nj = kj - bb;
-                if (ni >= 0 && ni < WS && nj >= 0 && nj < WS) acc += wl[e * 10 + (a + 1) * 3 + bb + 1] * io<T>::ld(Gs + (ni * WS + nj) * d + e);
-            }
-        io<T>::st(dqkv + trow(k) * C3 + voff + e, acc);
-    }
-    // weight / bias gradient partials of this window
-    for (int it = tid; it < d * 10; it += 256) {
-        const int e = it / 10, k = it - e * 10;
-        float acc = 0.f;
-        if (k == 9) {
-            for (int q = 0; q < L; ++q) acc += io<T>::ld(Gs + q * d + e);
-        } else {
-            const int a = k / 3 - 1, bb = k - (k / 3) * 3 - 1;
-            for (int q = 0; q < L; ++q) {
-                const int ni = q / WS + a, nj = q % WS + bb;
-                if (ni >= 0 && ni < WS && nj >= 0 && nj < WS) acc += io<T>::ld(Gs + q * d + e) * io<T>::ld(Vs + (ni * WS + nj) * d + e);
             }
         }
-        ws_lepe[((size_t)win * C + head * d + e) * 10 + k] = acc;
+    } else {
+#pragma unroll
+        for (int j = 0; j < WS; ++j) x[j][0] = io<T>::ld(p + j);
     }
 }
 
-// d_lepe_w[c][tap], d_lepe_b[c] = sum over windows (ascending) of the partials
-__global__ __launch_bounds__(256) void lepe_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int C, float *__restrict__ d_w,
-                                                               float *__restrict__ d_b) {
-    __shared__ float red[8][33];
+// sum over the lanes that are a multiple of WS apart; lanes 0 .. WS-1 hold the total
+template <int WS> __device__ __forceinline__ float sum_lanes_ws_apart(float x) {
+    if constexpr (WS == 8) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, false));  // row_ror:8
+    x += rows_odd_to_even(x);
+    x += upper_half_to_lower(x);
+    return x;
+}
+
+// geometry of the pre-pass that host and kernel share
+template <int WS, int CH> struct LepePre {
+    static constexpr int L = WS * WS;
+    static constexpr int LP = (WS + 2) * WS;  // V and dO: a row of zeros above and below the window
+    static constexpr int PP = LP + 4;         // positions per channel row in LDS; the + 4 spreads the 16-byte reads
+    static constexpr int PO = L + 4;          //   of the lanes that differ in the channel over the banks
+    static constexpr int NPASS = WS / (4 * CH);  // items = (d / CH) * WS <= (64 / CH) * WS = NPASS * 256
+    static_assert(NPASS >= 1, "items of one pass");
+};
+
+template <typename T, int WS, int CH>
+__global__ __launch_bounds__(256) void lepe_bwd_pre_kernel(AttnGeom g, const T *__restrict__ qkv, const T *__restrict__ out,
+                                                           const T *__restrict__ dout, const float *__restrict__ lepe_w,
+                                                           const float *__restrict__ lepe_b, T *__restrict__ dqkv,
+                                                           float *__restrict__ delta_out, float *__restrict__ ws_lepe, int wpb,
+                                                           int nw) {
+    // One block per (group of wpb consecutive windows, head); nw of the group's windows are in LDS at a time (nw > 1
+    // when the items of one window fill only a quarter or half of the block).
+    // A work item is (CH channels, window row i): it holds row i of dO and walks the three neighbouring rows of V and
+    // dO once, which gives, from 7 row reads, the LePE values of its row (for delta), dV_lepe of its row, and its
+    // share of the 9 tap + 1 bias gradients.  LDS holds [channel group][position], so a row is one or two 16-byte
+    // reads at a fixed offset from the item's base address, and V and dO carry a row of zeros above and below the
+    // window (no row predicates).
+    // delta sums over channels (lanes WS apart, then the waves through LDS); the weight gradient sums over the
+    // group's windows (in registers when one pass covers all items) and over rows: ONE partial row per group
+    // leaves the block.
+    using G = LepePre<WS, CH>;
+    using E = typename LepeElem<T, CH>::type;
+    constexpr int L = G::L, LP = G::LP, PP = G::PP, PO = G::PO, NPASS = G::NPASS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int d = g.d, dc = d / CH, C = g.C, C3 = g.ldq;
+    E *Vs = reinterpret_cast<E *>(smem);  // [nw][dc][PP]
+    E *Gs = Vs + nw * dc * PP;            // dO
+    E *Os = Gs + nw * dc * PP;            // out, then dV_lepe: [nw][dc][PO]
+    float *wl = reinterpret_cast<float *>(Os + nw * dc * PO);  // [d][10]: 9 taps + bias
+    float *wsum = wl + d * 10;                                  // [d][10] gradient sums
+    float *Pw = wsum + d * 10;                                  // [NPASS * 4][L] per-wave sums of delta
+    long long *org = reinterpret_cast<long long *>(Pw + NPASS * 4 * L);  // [4] first token row of each window in LDS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.x / g.heads, head = blockIdx.x - grp * g.heads;
+    const int n_items = dc * WS;
+    const int ipw = 256 / nw;                       // threads per window (nw > 1 only when NPASS == 1)
+    const int slot = tid / ipw, it0 = tid - slot * ipw;
+    int qoff, koff, voff;
+    qkv_offsets(g, head, qoff, koff, voff);
+    const int pitch = g.H == 0 ? WS : g.W;
+    for (int it = tid; it < d * 10; it += 256) {
+        const int e = it / 10, k = it - e * 10;
+        wl[it] = k < 9 ? lepe_w[(size_t)(head * d + e) * 9 + k] : lepe_b[head * d + e];
+        wsum[it] = 0.f;
+    }
+    for (int it = tid; it < nw * dc * 2 * WS; it += 256) {  // the rows of zeros
+        const int ch = it / (2 * WS), r = it - ch * 2 * WS;
+        const int off = ch * PP + (r < WS ? r : LP - 2 * WS + r);
+        Vs[off] = E(0);
+        Gs[off] = E(0);
+    }
+    __syncthreads();
+    using V = typename LepeVec<CH>::type;
+    V we[10], wacc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            wacc[k][c] = 0.f;
+            if constexpr (NPASS == 1) we[k][c] = wl[(CH * min(it0 / WS, dc - 1) + c) * 10 + k];
+        }
+    const int win_end = min(g.n_win, (grp + 1) * wpb);
+    for (int w0 = grp * wpb; w0 < win_end; w0 += nw) {
+        const int n_act = min(nw, win_end - w0);
+        if (tid < n_act) {
+            const int win = w0 + tid;
+            if (g.H == 0) {
+                org[tid] = (long long)win * L;
+            } else {
+                const int per = g.nWh * g.nWw;
+                const int b = win / per, r = win - b * per;
+                const int wr = r / g.nWw, wc = r - wr * g.nWw;
+                org[tid] = ((long long)b * g.H + wr * WS) * g.W + wc * WS;
+            }
+        }
+        __syncthreads();  // the previous windows' readers are done
+        auto trow = [&](int rw) -> size_t {  // rw = slot * L + position in the window
+            const int l = rw & (L - 1);
+            return (size_t)org[rw / L] + (size_t)(l / WS) * pitch + (l % WS);
+        };
+        const int n = n_act * L * dc;  // elements of one array to stage, [slot][position][channel group]
+        if constexpr (CH == 2) {
+            // SB loads of each of the three arrays are in flight per thread before the first LDS write: with few
+            // windows per block at a time, the bytes in flight are what hides the HBM latency
+            constexpr int SB = 8;
+            const int step_row = 256 / dc, step_e = 256 - step_row * dc;
+            int rw = tid / dc, e2 = tid - rw * dc;
+            for (int base = tid; base < n; base += 256 * SB) {
+                uint32_t rv[SB], rg[SB], ro[SB];
+                int lv[SB], lo[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    lv[u] = -1;
+                    if (base + u * 256 < n) {
+                        const size_t tr = trow(rw);
+                        const int ch = (rw / L) * dc + e2, l = rw & (L - 1);
+                        lv[u] = ch * PP + WS + l;
+                        lo[u] = ch * PO + l;
+                        rv[u] = *reinterpret_cast<const uint32_t *>(qkv + tr * C3 + voff + 2 * e2);
+                        rg[u] = *reinterpret_cast<const uint32_t *>(dout + tr * g.ldg + head * d + 2 * e2);
+                        ro[u] = *reinterpret_cast<const uint32_t *>(out + tr * g.ldo + head * d + 2 * e2);
+                    }
+                    rw += step_row;
+                    e2 += step_e;
+                    if (e2 >= dc) {
+                        e2 -= dc;
+                        ++rw;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u)
+                    if (lv[u] >= 0) {
+                        Vs[lv[u]] = rv[u];
+                        Gs[lv[u]] = rg[u];
+                        Os[lo[u]] = ro[u];
+                    }
+            }
+        } else {
+            for (int it = tid; it < n; it += 256) {
+                const int rw = it / dc, e = it - rw * dc;
+                const size_t tr = trow(rw);
+                const int ch = (rw / L) * dc + e, l = rw & (L - 1);
+                Vs[ch * PP + WS + l] = qkv[tr * C3 + voff + e];
+                Gs[ch * PP + WS + l] = dout[tr * g.ldg + head * d + e];
+                Os[ch * PO + l] = out[tr * g.ldo + head * d + e];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ps = 0; ps < NPASS; ++ps) {
+            if (ps * 256 >= n_items) break;  // the same for the whole block
+            const int item = it0 + ps * 256;
+            const int i = item % WS;
+            const bool act = item < n_items && slot < n_act;
+            const int ep = act ? item / WS : 0;  // the item's channel group
+            if constexpr (NPASS > 1) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) we[k][c] = wl[(CH * ep + c) * 10 + k];
+            }
+            const E *vrow = Vs + (slot * dc + ep) * PP + (i + 1) * WS, *grow = Gs + (slot * dc + ep) * PP + (i + 1) * WS;
+            E *orow = Os + (slot * dc + ep) * PO + i * WS;
+            // first the V rows (LePE of this row for delta, the tap gradients), then the dO rows (dV_lepe): the two
+            // halves share only row i of dO and the taps, which keeps the registers of each half apart
+            V gc[WS];
+            float part[WS];
+            lepe_row<T, WS, CH>(grow, gc);
+            if (!act) {  // an idle lane adds nothing to delta and to the gradient sums
+#pragma unroll
+                for (int j = 0; j < WS; ++j) gc[j] = V(0.f);
+            }
+            if constexpr (NPASS > 1) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) wacc[k] = V(0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < WS; ++j) wacc[9] += gc[j];
+            {
+                V lp[WS];
+#pragma unroll
+                for (int j = 0; j < WS; ++j) lp[j] = we[9];
+#pragma unroll
+                for (int a = -1; a <= 1; ++a) {
+                    V x[WS];
+                    lepe_row<T, WS, CH>(vrow + a * WS, x);  // V of row i + a
+#pragma unroll
+                    for (int bb = -1; bb <= 1; ++bb) {
+                        const int k = (a + 1) * 3 + bb + 1;
+#pragma unroll
+                        for (int j = 0; j < WS; ++j)
+                            if (j + bb >= 0 && j + bb < WS) {
+                                lp[j] += we[k] * x[j + bb];
+                                wacc[k] += gc[j] * x[j + bb];
+                            }
+                    }
+                }
+                // delta[q] = sum_e dO[q][e] * (out[q][e] - LePE(v)[q][e])
+                V o[WS];
+                lepe_row<T, WS, CH>(orow, o);
+#pragma unroll
+                for (int j = 0; j < WS; ++j) {
+                    const V t = gc[j] * (o[j] - lp[j]);
+                    part[j] = t[0];
+                    if constexpr (CH == 2) part[j] += t[1];
+                    part[j] = sum_lanes_ws_apart<WS>(part[j]);
+                }
+            }
+            asm volatile("" ::: "memory");
+            {
+                // dV_lepe[k] = sum_taps W[tap] * dO[k - tap]: dO of row i - a; it takes out's place in LDS (each
+                // element of Os is read and written by this item alone)
+                V dv[WS];
+#pragma unroll
+                for (int j = 0; j < WS; ++j) dv[j] = V(0.f);
+#pragma unroll
+                for (int a = -1; a <= 1; ++a) {
+                    V x[WS];
+                    if (a != 0) lepe_row<T, WS, CH>(grow - a * WS, x);
+#pragma unroll
+                    for (int bb = -1; bb <= 1; ++bb) {
+                        const int k = (a + 1) * 3 + bb + 1;
+#pragma unroll
+                        for (int j = 0; j < WS; ++j)
+                            if (j - bb >= 0 && j - bb < WS) dv[j] += we[k] * (a != 0 ? x[j - bb] : gc[j - bb]);
+                    }
+                }
+                if (act) {
+                    if constexpr (CH == 2) {
+#pragma unroll
+                        for (int j0 = 0; j0 < WS; j0 += 4)
+                            *reinterpret_cast<uint4 *>(orow + j0) =
+                                make_uint4(pack_bf16(dv[j0][0], dv[j0][1]), pack_bf16(dv[j0 + 1][0], dv[j0 + 1][1]),
+                                           pack_bf16(dv[j0 + 2][0], dv[j0 + 2][1]), pack_bf16(dv[j0 + 3][0], dv[j0 + 3][1]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < WS; ++j) io<T>::st(orow + j, dv[j][0]);
+                    }
+                }
+            }
+            if (lane < WS) {  // lane == i here
+#pragma unroll
+                for (int j = 0; j < WS; ++j) Pw[(ps * 4 + wave) * L + lane * WS + j] = part[j];
+            }
+            if constexpr (NPASS > 1) {  // (one pass: the sums stay in registers until the group's windows are done)
+#pragma unroll
+                for (int o2 = 1; o2 < WS; o2 <<= 1)
+#pragma unroll
+                    for (int k = 0; k < 10; ++k)
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) wacc[k][c] += __shfl_xor(wacc[k][c], o2, 64);
+                if (i == 0 && act) {  // the one writer of these channels' sums
+#pragma unroll
+                    for (int k = 0; k < 10; ++k)
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) wsum[(CH * ep + c) * 10 + k] += wacc[k][c];
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (NPASS == 1) {
+            if (tid < n_act * L) {  // nw * L <= 256 (nw > 1 only with 8 x 8 windows)
+                const int sl = tid / L, q = tid & (L - 1);
+                const int w_first = sl * (ipw >> 6), w_live = (n_items + 63) >> 6;
+                float acc = 0.f;
+                for (int wv = 0; wv < w_live; ++wv) acc += Pw[(w_first + wv) * L + q];
+                delta_out[((size_t)(w0 + sl) * g.heads + head) * L + q] = acc;
+            }
+        } else {
+            const int live_slots = (n_items + 63) >> 6;
+            for (int q = tid; q < L; q += 256) {
+                float acc = 0.f;
+                for (int sl = 0; sl < live_slots; ++sl) acc += Pw[sl * L + q];
+                delta_out[((size_t)w0 * g.heads + head) * L + q] = acc;
+            }
+        }
+        for (int it = tid; it < n; it += 256) {
+            const int rw = it / dc, e = it - rw * dc;
+            const int ch = (rw / L) * dc + e, l = rw & (L - 1);
+            if constexpr (CH == 2) *reinterpret_cast<uint32_t *>(dqkv + trow(rw) * C3 + voff + 2 * e) = Os[ch * PO + l];
+            else dqkv[trow(rw) * C3 + voff + e] = Os[ch * PO + l];
+        }
+    }
+    if constexpr (NPASS == 1) {
+        // rows of a channel group are adjacent lanes; then the windows side by side in the block, one after the other
+#pragma unroll
+        for (int o2 = 1; o2 < WS; o2 <<= 1)
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) wacc[k][c] += __shfl_xor(wacc[k][c], o2, 64);
+        for (int sl = 0; sl < nw; ++sl) {
+            if (slot == sl && it0 % WS == 0 && it0 < n_items) {
+                const int e0 = CH * (it0 / WS);
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) wsum[(e0 + c) * 10 + k] += wacc[k][c];
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+    for (int it = tid; it < d * 10; it += 256) ws_lepe[((size_t)grp * C + head * d) * 10 + it] = wsum[it];
+}
+
+// windows per block of the pre-pass: enough blocks to fill the chip several times over, few enough partial rows for
+// the reduction to be short; a multiple of the nw windows a block holds in LDS at a time
+static int lepe_wpb(const AttnGeom &g, int nw) {
+    const long long blocks = (long long)g.n_win * g.heads;
+    long long w = blocks / 2048;
+    w = w < 1 ? 1 : (w > 16 ? 16 : w);
+    return (int)((w + nw - 1) / nw * nw);
+}
+static int lepe_groups(const AttnGeom &g, int nw) { return (g.n_win + lepe_wpb(g, nw) - 1) / lepe_wpb(g, nw); }
+
+template <typename T, int WS, int CH>
+static int launch_lepe_pre(const AttnGeom &g, const T *qkv, const T *out, const T *dout, const float *lepe_w,
+                           const float *lepe_b, T *dqkv, float *ws_delta, float *ws_lepe, int *groups, hipStream_t st) {
+    using G = LepePre<WS, CH>;
+    using E = typename LepeElem<T, CH>::type;
+    const int dc = g.d / CH, n_items = dc * WS;
+    const int nw = G::NPASS > 1 ? 1 : (n_items <= 64 ? 4 : (n_items <= 128 ? 2 : 1));
+    const size_t l2 = (size_t)nw * dc * (2 * G::PP + G::PO) * sizeof(E) + (size_t)(g.d * 20 + G::NPASS * 4 * G::L) * sizeof(float) +
+                      4 * sizeof(long long);
+    if (l2 > 160 * 1024) return fail(DSW_EUNSUPPORTED, "win_attn_bwd: LePE with w=%d head dim %d needs %zu B of LDS", WS, g.d, l2);
+    auto pre = lepe_bwd_pre_kernel<T, WS, CH>;
+    if (l2 > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+        if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_bwd: LDS attribute: %s", hipGetErrorString(e));
+    }
+    *groups = lepe_groups(g, nw);
+    hipLaunchKernelGGL(pre, dim3(*groups * g.heads), dim3(256), l2, st, g, qkv, out, dout, lepe_w, lepe_b, dqkv, ws_delta, ws_lepe,
+                       lepe_wpb(g, nw), nw);
+    return check_launch("lepe_bwd_pre_kernel");
+}
+
+// d_lepe_w[c][tap], d_lepe_b[c] = sum over window groups (ascending) of the partials
+__global__ __launch_bounds__(1024) void lepe_grad_reduce_kernel(const float *__restrict__ ws, int n_win, int C, float *__restrict__ d_w,
+                                                                float *__restrict__ d_b) {
+    __shared__ float red[32][33];
     int i;
     float acc;
-    if (!column_sum_32x8(ws, n_win, C * 10, red, i, acc)) return;
+    if (!column_sum_32<32>(ws, n_win, C * 10, red, i, acc)) return;
     const int c = i / 10, k = i - c * 10;
     if (k < 9) d_w[c * 9 + k] = acc;
     else d_b[c] = acc;
@@ -803,18 +1077,21 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
     const size_t lds = Cfg::lds_bytes(bias);
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "win_attn_bwd: w=%d head dim %d needs %zu B of LDS", WS, g.d, lds);
     const dim3 grid(g.n_win * g.heads), block(Cfg::THREADS);
-    int rc;
+    int rc, lepe_rows = 0;  // lepe_rows: partial rows of the LePE weight gradient the pre-pass leaves
     if (lepe) {
-        const size_t l2 = (size_t)(3 * Cfg::L * g.d + 1) * sizeof(T) + (size_t)g.d * 10 * sizeof(float) + 16;
-        if (l2 > 160 * 1024) return fail(DSW_EUNSUPPORTED, "win_attn_bwd: LePE with w=%d head dim %d needs %zu B of LDS", WS, g.d, l2);
-        auto pre = lepe_bwd_pre_kernel<T, WS>;
-        if (l2 > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-            if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_bwd: LDS attribute: %s", hipGetErrorString(e));
+        // 2-byte elements go through the kernel two channels at a time when every row starts on a 4-byte boundary
+        // (with an even head dim every head's offset into a row is even in both layouts of qkv)
+        if constexpr (sizeof(T) == 2) {
+            if (((g.d | g.ldq | g.ldo | g.ldg) & 1) == 0)
+                rc = launch_lepe_pre<T, WS, 2>(g, (const T *)qkv, (const T *)out, (const T *)dout, lepe_w, lepe_b, (T *)dqkv, ws_delta,
+                                               ws_lepe, &lepe_rows, st);
+            else
+                rc = launch_lepe_pre<T, WS, 1>(g, (const T *)qkv, (const T *)out, (const T *)dout, lepe_w, lepe_b, (T *)dqkv, ws_delta,
+                                               ws_lepe, &lepe_rows, st);
+        } else {
+            rc = launch_lepe_pre<T, WS, 1>(g, (const T *)qkv, (const T *)out, (const T *)dout, lepe_w, lepe_b, (T *)dqkv, ws_delta, ws_lepe,
+                                           &lepe_rows, st);
         }
-        hipLaunchKernelGGL(pre, grid, dim3(256), l2, st, g, (const T *)qkv, (const T *)out, (const T *)dout, lepe_w, lepe_b,
-                           (T *)dqkv, ws_delta, ws_lepe);
-        rc = check_launch("lepe_bwd_pre_kernel");
         if (rc) return rc;
     }
 #define DSW_BWD_LAUNCH2(B_, P_, D_)                                                                              \
@@ -864,7 +1141,7 @@ static int launch_bwd(const AttnGeom &g, const void *qkv, const void *out, const
         if (rc) return rc;
     }
     if (lepe) {
-        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3((g.C * 10 + 31) / 32), dim3(256), 0, st, ws_lepe, g.n_win, g.C,
+        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3((g.C * 10 + 31) / 32), dim3(1024), 0, st, ws_lepe, lepe_rows, g.C,
                            d_lepe_w, d_lepe_b);
         rc = check_launch("lepe_grad_reduce_kernel");
     }

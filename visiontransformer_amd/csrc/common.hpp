@@ -123,20 +123,33 @@ __device__ __forceinline__ float block_max(float v, float *red) {
     } while (0)
 
 // dst[c] = sum_r src[r][c] for a row-major [rows][cols] fp32 matrix of per-block partial sums, in a fixed
-// order: a block takes 32 consecutive columns, its 8 thread slices every 8th row, and the slices are
-// added in slice order.  The body of the small reduction kernels at the end of the backward passes.
-__device__ __forceinline__ bool column_sum_32x8(const float *__restrict__ src, int rows, int cols, float (*red)[33], int &col, float &total) {
+// order: a block of 32 * SL threads takes 32 consecutive columns, its SL thread slices every SL-th row (four rows
+// of a slice in flight at a time, each with its own running sum: the loop is bound by the latency of its loads),
+// and the slices are added in slice order.  The body of the small reduction kernels at the end of the backward
+// passes.
+template <int SL>
+__device__ __forceinline__ bool column_sum_32(const float *__restrict__ src, int rows, int cols, float (*red)[33], int &col, float &total) {
     const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
     col = blockIdx.x * 32 + e;
     float acc = 0.f;
-    if (col < cols)
-        for (int r = sl; r < rows; r += 8) acc += src[(size_t)r * cols + col];
+    if (col < cols) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = sl;
+        for (; r + 3 * SL < rows; r += 4 * SL) {
+            a0 += src[(size_t)r * cols + col];
+            a1 += src[(size_t)(r + SL) * cols + col];
+            a2 += src[(size_t)(r + 2 * SL) * cols + col];
+            a3 += src[(size_t)(r + 3 * SL) * cols + col];
+        }
+        for (; r < rows; r += SL) a0 += src[(size_t)r * cols + col];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     red[sl][e] = acc;
     __syncthreads();
     if (sl != 0 || col >= cols) return false;
     total = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) total += red[k][e];
+    for (int k = 0; k < SL; ++k) total += red[k][e];
     return true;
 }
 

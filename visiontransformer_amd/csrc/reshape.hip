@@ -160,12 +160,13 @@ __global__ __launch_bounds__(RS_THREADS) void unshuffle_ln_bwd_kernel(
     store_nchw_tile<T>(dx, gg, ld, b, c, H, W, s, ho, wo0, ntok);
 }
 
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float *__restrict__ partial, int nblocks, int Co,
-                                                              float *__restrict__ d_gamma, float *__restrict__ d_beta) {
-    __shared__ float red[8][33];
+// (thousands of partial rows, a few hundred columns: 32 row slices per block keep enough loads in flight)
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float *__restrict__ partial, int nblocks, int Co,
+                                                               float *__restrict__ d_gamma, float *__restrict__ d_beta) {
+    __shared__ float red[32][33];
     int i;
     float acc;
-    if (!column_sum_32x8(partial, nblocks, 2 * Co, red, i, acc)) return;  // a partial row is [d_gamma | d_beta]
+    if (!column_sum_32<32>(partial, nblocks, 2 * Co, red, i, acc)) return;  // a partial row is [d_gamma | d_beta]
     const int which = i / Co, ch = i - which * Co;
     (which ? d_beta : d_gamma)[ch] = acc;
 }
@@ -265,7 +266,7 @@ extern "C" int dsw_unshuffle_nhwc_ln_bwd(const void *dy, const void *x, int dtyp
     });
     rc = check_launch("unshuffle_ln_bwd_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * Co + 31) / 32), dim3(256), 0, st, partial, nblocks, Co, d_gamma, d_beta);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * Co + 31) / 32), dim3(1024), 0, st, partial, nblocks, Co, d_gamma, d_beta);
     return check_launch("ln_param_reduce_kernel");
 }
 
