@@ -339,8 +339,12 @@ def test_dswt_model_golden(cuda0):
     _check_grads(mod, g, x, y, cuda0)
 
 
-def test_msft_model_golden(cuda0):
+@pytest.mark.parametrize("stream", [True, False])
+def test_msft_model_golden(cuda0, monkeypatch, stream):
+    """stream=True: the trunk on the channels-last fp32 stream (no NCHW <-> token copies); False: module by module on
+    NCHW tensors as the reference runs it.  Both against the reference's own output and gradients."""
     from visiontransformer_amd import models
+    monkeypatch.setattr(models, "NHWC_STREAM", stream)
     g, m = load_golden("model_msft")
     mod = _load_into(models.MSFTransformer(**m["cfg"]), g, cuda0).eval()
     for sub in mod.modules():
@@ -351,6 +355,39 @@ def test_msft_model_golden(cuda0):
     assert y.shape == g["y"].shape
     assert rel_err(y, g["y"]) < TOL
     _check_grads(mod, g, x, y, cuda0)
+
+
+def test_msft_model_bf16_stream_against_fp32(cuda0, monkeypatch):
+    """The channels-last trunk under bf16 autocast (projection kernels for the 1x1 convolutions, NHWC 3x3 kernels,
+    fused residuals) against the fp32 run of the module-by-module path: output and parameter gradients within the
+    bf16 bar.  The ReZero gates are opened (they are zero at init, which would hide every block)."""
+    from visiontransformer_amd import models
+    g, m = load_golden("model_msft")
+    mod = _load_into(models.MSFTransformer(**m["cfg"]), g, cuda0).eval()
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if n.endswith("rezero"):
+                p.fill_(0.5)
+    for sub in mod.modules():
+        if hasattr(sub, "attn_drop"):
+            sub.attn_drop = 0.0
+    x = g["x"].to(cuda0)
+    res = []
+    for stream, autocast in ((False, False), (True, True), (False, True)):
+        monkeypatch.setattr(models, "NHWC_STREAM", stream)
+        mod.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            y = mod(x)
+        y.float().square().mean().backward()
+        res.append((y.float().detach(), {n: p.grad.float().clone() for n, p in mod.named_parameters() if p.grad is not None}))
+    (y32, g32), (y16, g16), (y16n, g16n) = res
+    assert rel_err(y16, y32) < 2e-2
+    assert set(g16) == set(g32)
+    worst = max((rel_err(g16[n], g32[n]), n) for n in g32 if g32[n].abs().max() > 0)
+    # the gradients have crossed every block in bf16: the bar is what the module-by-module path itself shows under
+    # the same autocast (stock convolutions and LayerNorms on a bf16 stream), with 6e-2 as the floor
+    worst_nchw = max((rel_err(g16n[n], g32[n]), n) for n in g32 if g32[n].abs().max() > 0)
+    assert worst[0] < max(6e-2, 1.25 * worst_nchw[0]), (worst, worst_nchw)
 
 
 def test_prepared_weights_follow_the_parameters(cuda0):

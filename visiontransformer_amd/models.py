@@ -247,6 +247,21 @@ class DSWTransformer(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # MSFT
 # ------------------------------------------------------------------------------------------------
+NHWC_STREAM = True   # False: MSFTransformer runs its trunk module by module on NCHW tensors, as the reference does
+
+
+def _pointwise(conv):
+    """a 1x1 convolution as the projection of token rows it is: weight [Co, Ci, 1, 1] -> [Co, Ci]"""
+    return _Stacked(conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+
+
+def _conv3x3_nhwc(x, conv):
+    y = K.conv3x3_nhwc(x, conv)   # bf16 autocast: NHWC kernels (fwd and bwd), no layout copies
+    if y is not None:
+        return y
+    return conv(x.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
+
+
 class MSFBlock_3(nn.Module):
     """msft_arch.py:169-210: a pyramid of PatchMerging -> ViTBlock -> PatchUnMerging levels fused
     with the full-resolution map by one more ViTBlock."""
@@ -279,6 +294,28 @@ class MSFBlock_3(nn.Module):
         lv = self.post_level_fuse(torch.cat(maps, dim=1))
         return torch.addcmul(x, self.rezero, self.fuse(torch.cat([x, lv], dim=1)))
 
+    def forward_nhwc(self, x):
+        """The same function on the channels-last fp32 stream x [B, H, W, dim]: the 1x1 convolutions are
+        projections of the token rows, the 3x3 one runs in the NHWC kernels, the transformer blocks work on the
+        token rows where they lie, and the closing 1x1 convolution is fused with the ReZero residual when autograd
+        is off.  No tensor changes layout inside the block."""
+        B, H, W, C = x.shape
+        maps = []
+        z = K.linear(x, _pointwise(self.init_ds))
+        for i in range(self.levels - 1):
+            z = K.linear(z, _pointwise(self.level_ds[i]))
+            merge, vit, unmerge = self.level_layer[i]
+            s = merge.scale
+            t = merge.forward_nhwc(z).float()
+            maps.append(unmerge.forward_tokens(vit.forward_tokens(t, H // s, W // s), H // s, W // s))
+        lv = _conv3x3_nhwc(maps[0] if len(maps) == 1 else torch.cat(maps, dim=-1), self.post_level_fuse)
+        t = self.fuse[0].forward_tokens(torch.cat([x, lv], dim=-1).view(B, H * W, -1), H, W)
+        close = _pointwise(self.fuse[1])
+        y = K.linear_residual(t, close, x.view(B, H * W, C), self.rezero)
+        if y is None:
+            y = K.rezero_residual(x.view(B, H * W, C), self.rezero, K.linear(t, close))
+        return y.view(B, H, W, C)
+
 
 class MSFTResidualBlock(nn.Module):
     """msft_arch.py:257-273."""
@@ -293,6 +330,12 @@ class MSFTResidualBlock(nn.Module):
 
     def forward(self, x):
         return self.out_layer(self.layers(x)) + x
+
+    def forward_nhwc(self, x):
+        y = x
+        for blk in self.layers:
+            y = blk.forward_nhwc(y)
+        return _conv3x3_nhwc(y, self.out_layer) + x
 
 
 class MSFTransformer(nn.Module):
@@ -326,7 +369,19 @@ class MSFTransformer(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         x = self.feature_extractor(self.padding(x))
-        x = self.feature_transition(self.layers(x)) + x
+        if NHWC_STREAM and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.dim % 8 == 0:
+            # the trunk on a channels-last fp32 stream (the attention modules work on token rows: every NCHW <-> token
+            # copy of the blocks falls away, and the convolutions between them run in the NHWC kernels)
+            xs = x.permute(0, 2, 3, 1).float().contiguous()
+            y = xs
+            for blk in self.layers:
+                y = blk.forward_nhwc(y)
+            y = _conv3x3_nhwc(y, self.feature_transition) + xs
+            x = y.permute(0, 3, 1, 2)
+            if not torch.is_autocast_enabled("cuda"):
+                x = x.contiguous()
+        else:
+            x = self.feature_transition(self.layers(x)) + x
         x = self.img_reconstruction(x)
         return x[:, :, :H * self.scale_factor, :W * self.scale_factor]
 

@@ -32,6 +32,15 @@ class PatchMerging(nn.Module):
                                        out_dtype=_ln_out_dtype(x))
         return K.shuffle_nchw(K.linear(t, self.linear) if t.is_cuda else self.linear(t), 1)
 
+    def forward_nhwc(self, z):
+        """The same function between channels-last tensors: z [B, H, W, c] -> tokens [B, (H/s)*(W/s), c*s*s]
+        (channel order of PixelUnshuffle: c*s*s + dy*s + dx).  No NCHW tensor on the way."""
+        B, H, W, c = z.shape
+        s = self.scale
+        u = torch.empty(B, (H // s) * (W // s), c * s * s, dtype=torch.float32, device=z.device)
+        u.view(B, H // s, W // s, c, s, s).copy_(z.view(B, H // s, s, W // s, s, c).permute(0, 1, 3, 5, 2, 4))
+        return K.linear(K.layer_norm(u, self.norm, for_projection=True), self.linear)
+
 
 class PatchUnMerging(nn.Module):
     """msft_arch.py:59-78: NHWC -> LayerNorm -> Linear(no bias) -> NCHW -> PixelShuffle."""
@@ -48,6 +57,14 @@ class PatchUnMerging(nn.Module):
         t = K.unshuffle_nhwc_layernorm(x, self.norm.weight, self.norm.bias, 1, self.norm.eps,
                                        out_dtype=_ln_out_dtype(x))
         return K.shuffle_nchw(K.linear(t, self.linear) if t.is_cuda else self.linear(t), self.scale)
+
+    def forward_tokens(self, t, h, w):
+        """The same function from the fp32 tokens t [B, h*w, dim] to the channels-last map [B, h*s, w*s, dim/s/s]."""
+        B, _, dim = t.shape
+        s = self.scale
+        c = dim // (s * s)
+        y = K.linear(K.layer_norm(t, self.norm, for_projection=True), self.linear)
+        return y.view(B, h, w, c, s, s).permute(0, 1, 4, 2, 5, 3).reshape(B, h * s, w * s, c)
 
 
 class WindowedMSA(nn.Module):
@@ -117,3 +134,19 @@ class ViTBlock(nn.Module):
         t = self.drop_path(self.msa(n1, H, W)) + t
         t = self.drop_path(self.mlp(K.layer_norm(t, self.ln2, for_projection=True))) + t
         return K.shuffle_nchw(t.view(B, H, W, C), 1)
+
+    def forward_tokens(self, t, H, W):
+        """The block on the fp32 token stream t [B, H*W, C] (what forward computes between its two layout copies).
+        The residual additions and the block's drop_path are one kernel each (the keep decisions of the dropout are
+        a seeded hash of the position: no mask tensor); under bf16 autocast the stream stays fp32, as the LayerNorm
+        outputs of the reference do."""
+        one = self._one(t.device)
+        n1 = K.layer_norm(t, self.ln1, for_projection=True)
+        t = K.rezero_residual(t, one, self.msa(n1, H, W), dropout=self.drop_path)
+        return K.rezero_residual(t, one, self.mlp(K.layer_norm(t, self.ln2, for_projection=True)), dropout=self.drop_path)
+
+    def _one(self, device):
+        o = getattr(self, "_one_buf", None)
+        if o is None or o.device != device:
+            o = self._one_buf = torch.ones(1, device=device)
+        return o
