@@ -14,9 +14,11 @@ for (B, H, C, heads) in ((32, 64, 216, 4), (32, 32, 96, 6))[:1 if PMC else 2]:
     qkv = torch.randn(B, H * H, 3 * C, device=dev, dtype=torch.bfloat16, requires_grad=True)
     lw = torch.randn(C, 1, 3, 3, device=dev, requires_grad=True)
     lb = torch.randn(C, device=dev, requires_grad=True)
+    NOLEPE = os.environ.get("NOLEPE") == "1"
+    DROP = float(os.environ.get("DROP", "0.1"))
     def step():
-        z = K.window_attention(qkv, None, 8, heads, QKV_CHUNKED, grid=(B, H, H), lepe_w=lw, lepe_b=lb,
-                               dropout_p=0.1, dropout_seed=5)
+        z = K.window_attention(qkv, None, 8, heads, QKV_CHUNKED, grid=(B, H, H), lepe_w=None if NOLEPE else lw,
+                               lepe_b=None if NOLEPE else lb, dropout_p=DROP, dropout_seed=5)
         z.backward(torch.ones_like(z))
     for _ in range(2 if PMC else 3):
         step()

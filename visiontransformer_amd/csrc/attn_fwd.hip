@@ -23,7 +23,7 @@ template <typename T, int WS, int DP, bool BIAS, bool LEPE, bool DROP>
 __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::MIN_WAVES)) void win_attn_fwd_kernel(
     AttnGeom g, const T *__restrict__ qkv, const float *__restrict__ table, float scale,
     const float *__restrict__ lepe_w, const float *__restrict__ lepe_b, T *__restrict__ out,
-    float *__restrict__ lse, DropArgs drop) {
+    float *__restrict__ lse, DropArgs drop, int lepe_in_lds) {
     using Cfg = FwdCfg<T, WS, DP>;
     constexpr int L = Cfg::L, THREADS = Cfg::THREADS, QS = Cfg::QS, VS = Cfg::VS;
     constexpr int TS = bias_lds<WS>::TS, TMAX = (2 * WS - 2) * (TS + 1);
@@ -143,8 +143,17 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
         }
     }
     __syncthreads();
+    const float *lp = nullptr;
+    if constexpr (LEPE && BF) {
+        if (lepe_in_lds) {  // uniform; the launcher sets it for an even head dim when the extra LDS fits
+            float *lpw = tb + (BIAS ? bias_lds<WS>::FLOATS : 0);
+            lepe_values<T, WS, DP, THREADS>(Vt, lpw, lepe_w, lepe_b, head, d, tid);
+            __syncthreads();
+            lp = lpw;
+        }
+    }
 
-    win_attn_fwd_core<T, WS, DP, BIAS, LEPE, DROP>(g, Qs, Ks, Vt, tb, win, head, origin, pitch, lepe_w, lepe_b, out, lse, drop);
+    win_attn_fwd_core<T, WS, DP, BIAS, LEPE, DROP>(g, Qs, Ks, Vt, tb, win, head, origin, pitch, lepe_w, lepe_b, out, lse, drop, lp);
 }
 
 template <typename T, int WS, int DP>
@@ -152,8 +161,11 @@ static int launch_fwd(const AttnGeom &g, const void *qkv, const float *table, fl
                       const float *lepe_b, void *out, float *lse, const DropArgs &drop, hipStream_t st) {
     using Cfg = FwdCfg<T, WS, DP>;
     const bool bias = table != nullptr, lepe = lepe_w != nullptr;
-    const size_t lds = Cfg::lds_bytes(bias);
+    size_t lds = Cfg::lds_bytes(bias);
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "win_attn_fwd: w=%d head dim %d needs %zu B of LDS", WS, g.d, lds);
+    // bf16, even head dim: the window's LePE values are computed once into LDS when they fit beside the operands
+    const int lepe_in_lds = lepe && sizeof(T) == 2 && (g.d & 1) == 0 && lds + Cfg::lepe_lds_bytes() <= 160 * 1024;
+    if (lepe_in_lds) lds += Cfg::lepe_lds_bytes();
     const dim3 grid(g.n_win * g.heads), block(Cfg::THREADS);
 #define DSW_FWD_LAUNCH2(B_, L_, D_)                                                                              \
     do {                                                                                                         \
@@ -162,7 +174,7 @@ static int launch_fwd(const AttnGeom &g, const void *qkv, const float *table, fl
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_fwd: LDS attribute: %s", hipGetErrorString(e)); \
         }                                                                                                        \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const T *)qkv, table, scale, lepe_w, lepe_b, (T *)out, lse, drop); \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const T *)qkv, table, scale, lepe_w, lepe_b, (T *)out, lse, drop, lepe_in_lds); \
     } while (0)
 #define DSW_FWD_LAUNCH(B_, L_)                     \
     do {                                           \

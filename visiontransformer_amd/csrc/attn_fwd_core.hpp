@@ -24,17 +24,64 @@ template <typename T, int WS, int DP> struct FwdCfg {
     static constexpr size_t lds_bytes(bool bias) {
         return (size_t)(2 * L * QS + N_V) * sizeof(T) + (bias ? bias_lds<WS>::FLOATS * sizeof(float) : 0);
     }
+    // LePE values of the window, fp32 [L][LPS], computed once per workgroup ahead of the attention (bf16 kernels)
+    static constexpr int LPS = DP + 4;  // 16-byte reads of four head-dim columns, lanes (= queries) spread over the banks
+    static constexpr size_t lepe_lds_bytes() { return (size_t)L * LPS * sizeof(float); }
 };
+
+// LePE of one window and head (msft_arch.py:113-125: a depthwise 3x3 convolution of V inside the window, zero
+// padding at its border) from the bf16 V image in LDS ([L][QS] row-major) into lp [L][LPS] fp32, for an even head
+// dim.  A work item is (channel pair, window row): it walks the three neighbouring rows of V once, 3 * WS LDS
+// reads for 2 * WS outputs (the per-element form needs 9 reads and 9 weight loads per output).  The caller puts
+// a workgroup barrier before (V staged) and after (lp complete).
+template <typename T, int WS, int DP, int THREADS>
+__device__ __forceinline__ void lepe_values(const T *Vt, float *lp, const float *__restrict__ lepe_w,
+                                            const float *__restrict__ lepe_b, int head, int d, int tid) {
+    using Cfg = FwdCfg<T, WS, DP>;
+    constexpr int QS = Cfg::QS, LPS = Cfg::LPS, DW = DP / 2;
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    for (int item = tid; item < DW * WS; item += THREADS) {
+        const int ep = item % DW, i = item / DW, e = 2 * ep;  // lanes along the channel pairs: consecutive LDS words
+        if (e >= d) continue;
+        const float *w0 = lepe_w + (size_t)(head * d + e) * 9, *w1 = w0 + 9;
+        v2 acc[WS];
+        const v2 b2 = {lepe_b[head * d + e], lepe_b[head * d + e + 1]};
+#pragma unroll
+        for (int j = 0; j < WS; ++j) acc[j] = b2;
+#pragma unroll
+        for (int a = -1; a <= 1; ++a) {
+            const int row = i + a;
+            if (row < 0 || row >= WS) continue;
+            v2 x[WS];
+#pragma unroll
+            for (int j = 0; j < WS; ++j) {
+                const uint32_t pr = *reinterpret_cast<const uint32_t *>(Vt + (row * WS + j) * QS + e);
+                x[j] = v2{__uint_as_float(pr << 16), __uint_as_float(pr & 0xffff0000u)};
+            }
+#pragma unroll
+            for (int bb = -1; bb <= 1; ++bb) {
+                const v2 wt = {w0[(a + 1) * 3 + bb + 1], w1[(a + 1) * 3 + bb + 1]};
+#pragma unroll
+                for (int j = 0; j < WS; ++j)
+                    if (j + bb >= 0 && j + bb < WS) acc[j] += wt * x[j + bb];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WS; ++j) *reinterpret_cast<v2 *>(lp + (i * WS + j) * LPS + e) = acc[j];
+    }
+}
 
 // Expects, in LDS: Qs [L][QS] = q * scale * log2(e), Ks [L][QS], Vt (bf16: V [L][QS]; f32: V^T [DP][VS]), all
 // zero-padded from d to DP with the first padding column of V set to one, and (BIAS) the mirrored
 // relative-position table tb; a workgroup barrier after the staging is the caller's.  `origin` / `pitch`
 // address token (i, j) of the window at row origin + i * pitch + j of `out`.  lse may be null (not wanted).
+// LEPE: lp, when not null, holds the window's LePE values [L][Cfg::LPS] in LDS (lepe_values below) and the epilogue
+// adds them; with lp null the epilogue evaluates the 9 taps per output element itself.
 template <typename T, int WS, int DP, bool BIAS, bool LEPE, bool DROP>
 __device__ __forceinline__ void win_attn_fwd_core(const AttnGeom &g, T *Qs, T *Ks, T *Vt, const float *tb, int win, int head,
                                                   size_t origin, int pitch, const float *__restrict__ lepe_w,
                                                   const float *__restrict__ lepe_b, T *__restrict__ out,
-                                                  float *__restrict__ lse, const DropArgs &drop) {
+                                                  float *__restrict__ lse, const DropArgs &drop, const float *lp = nullptr) {
     using Cfg = FwdCfg<T, WS, DP>;
     constexpr int L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, QS = Cfg::QS, VS = Cfg::VS;
     constexpr int TS = bias_lds<WS>::TS, TMAX = (2 * WS - 2) * (TS + 1);
@@ -202,12 +249,27 @@ __device__ __forceinline__ void win_attn_fwd_core(const AttnGeom &g, T *Qs, T *K
 #pragma unroll
         for (int u = 0; u < DP / 32; ++u) {
             float o[16];
+            float lpv[16];
+            if constexpr (LEPE) {
+                if (lp != nullptr) {  // registers 4g..4g+3 are four consecutive head-dim columns
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(lp + q * Cfg::LPS + 32 * u + 8 * g4 + 4 * hh);
+                        lpv[4 * g4] = t4.x;
+                        lpv[4 * g4 + 1] = t4.y;
+                        lpv[4 * g4 + 2] = t4.z;
+                        lpv[4 * g4 + 3] = t4.w;
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dd = 32 * u + rho(r) + 4 * hh;
                 float v = oacc[u][r] * inv;
                 if constexpr (LEPE) {
-                    if (dd < d) {
+                    if (lp != nullptr) {
+                        v += lpv[r];
+                    } else if (dd < d) {
                         const int c = head * d + dd;
                         float acc = lepe_b[c];
 #pragma unroll
