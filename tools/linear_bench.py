@@ -100,6 +100,8 @@ if os.environ.get('MSFT'):   # the projections of workload C's fuse block (dim 2
         C, C3, Hd = dims
         for (K, N) in ((C, C3), (C, C), (C, Hd), (Hd, C), (C3, C)):
             case(M, K, N, bf, bf, 1, 1, 0)
+        case(M, Hd, C, f32, bf, 0, 1, 1)   # a foreign fp32 input of the second MLP projection, with the bf16 copy
+        case(M, C3, C, bf, f32, 1, 0, 0)
         for (K, N) in ((C, C3), (C, C), (C, Hd), (Hd, C)):
             wcase(M, K, N)
     sys.exit(0)

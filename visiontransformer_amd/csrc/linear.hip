@@ -23,7 +23,8 @@ namespace {
 constexpr int LN_BM = 128;       // rows of A per workgroup
 constexpr int LN_CN = 64;        // output columns per chunk
 constexpr int LN_THREADS = 256;  // 4 waves, 32 rows each
-constexpr int LN_MAXACC = 3;     // chunks whose accumulators persist across k slabs
+constexpr int LN_MAXACC = 3;     // chunks whose accumulators persist across k slabs; 4 with slabs of <= 128 (LN_MAXACC_NARROW)
+constexpr int LN_MAXACC_NARROW = 4;  // 256 columns: msft's 216-wide outputs in one pass over A
 
 template <int KS> struct LnCfg {
     static constexpr int LS = KS + 8;  // LDS row stride in elements: 16-byte reads of 32 rows fall on distinct banks
@@ -108,7 +109,9 @@ __device__ __forceinline__ void chunk_mfma(const bf16_t *brow, const bf16x8 (&af
     }
 }
 
-template <typename TA, typename TC, int KS, bool PERSIST>
+// NACC: 0 = one k slab (a chunk is stored as soon as it is complete); > 0 = several slabs, the accumulators of NACC
+// chunks persist across them
+template <typename TA, typename TC, int KS, int NACC>
 __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     int convH, int convW, int gated, const int *__restrict__ live_units, int unit_rows) {
     using cfg = LnCfg<KS>;
     constexpr int LS = cfg::LS, NKS = cfg::NKS;
+    constexpr bool PERSIST = NACC > 0;
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t *As = reinterpret_cast<bf16_t *>(smem);
     bf16_t *Bs = As + LN_BM * LS;
@@ -187,9 +191,9 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
 #pragma unroll
     for (int q = 0; q < 2; ++q) w_off[q] = (unsigned)(((q * 32 + srow) * ldw + scol) * sizeof(bf16_t));
 
-    f32x16 acc[PERSIST ? LN_MAXACC : 1][2];
+    f32x16 acc[PERSIST ? NACC : 1][2];
 #pragma unroll
-    for (int c = 0; c < (PERSIST ? LN_MAXACC : 1); ++c)
+    for (int c = 0; c < (PERSIST ? NACC : 1); ++c)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -334,7 +338,8 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                     const uint4 v = ap[p * (KS / 64) + j].pack(kslab * KS + j * 64 + scol, K);
                     *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * LS + j * 64 + scol) = v;
                     // (convolution: the centre tap's rows are the block's own rows)
-                    if (copy_row != nullptr && p * 32 + srow < rows && (!conv || tap == 4))
+                    // (a half-empty last slab: the columns at and beyond the padded K are not part of the copy's rows)
+                    if (copy_row != nullptr && p * 32 + srow < rows && (!conv || tap == 4) && kslab * KS + j * 64 < ((K + 63) & ~63))
                         *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + kslab * KS + j * 64) = v;
                 }
             write_b();
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
             if constexpr (PERSIST) {
                 // chunk is uniform; a switch keeps the accumulators in registers
 #pragma unroll
-                for (int cc = 0; cc < LN_MAXACC; ++cc)
+                for (int cc = 0; cc < NACC; ++cc)
                     if (cc == chunk) chunk_mfma<NKS, LS>(brow, afr, acc[cc]);
             } else {
                 chunk_mfma<NKS, LS>(brow, afr, acc[0]);
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     }
     if constexpr (PERSIST) {
 #pragma unroll
-        for (int cc = 0; cc < LN_MAXACC; ++cc)
+        for (int cc = 0; cc < NACC; ++cc)
             if (cc < nch) store_tiles(acc[cc], cc);
     }
 }
@@ -598,8 +603,10 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
+    // slabs of <= 128 leave registers for a fourth persistent chunk
+    constexpr int NACC = KS <= 128 ? LN_MAXACC_NARROW : LN_MAXACC;
     if (nslab > 1) {
-        cpb = total < LN_MAXACC ? total : LN_MAXACC;
+        cpb = total < NACC ? total : NACC;
     } else {
         // enough workgroups for two per CU; every extra block column re-reads A (from L2 at best)
         int gy = (512 + mt - 1) / mt;
@@ -611,12 +618,12 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "dsw_linear: %d output columns per block need %zu bytes of LDS", cpb * LN_CN, lds);
     int rc;
     if (nslab > 1) {
-        auto kern = linear_nt_kernel<TA, TC, KS, true>;
+        auto kern = linear_nt_kernel<TA, TC, KS, NACC>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
                            bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows);
     } else {
-        auto kern = linear_nt_kernel<TA, TC, KS, false>;
+        auto kern = linear_nt_kernel<TA, TC, KS, 0>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
                            bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows);
@@ -668,8 +675,12 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
     } else if (resid != nullptr && (ld_resid < ncols || ld_resid % 4 || ((uintptr_t)resid & 15)))
         return fail(DSW_EUNSUPPORTED, "dsw_linear_residual: the residual needs a row stride >= ncols, a multiple of 4, and a 16-byte aligned base "
                                       "(ld_resid=%lld)", ld_resid);
-    const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 ? 128 : 64);
-    const int nslab = Kp / KS;
+    // k slab: the widest that divides the padded K; a K beyond 192 that only 64 divides (msft: 448, 704) takes slabs
+    // of 128 with the last one half empty (A is masked at K, so what the weight rows hold there does not matter:
+    // the next row's finite values, or zero past the end of the matrix) rather than twice as many slabs of 64,
+    // each with its own round of barriers
+    const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 || Kp > 192 ? 128 : 64);
+    const int nslab = (Kp + KS - 1) / KS;
     if (gated && (nslab != 1 || c_dtype != DSW_BF16 || ncols % 64 || ldc % 8 || a_copy != nullptr || resid != nullptr || accumulate))
         return fail(DSW_EUNSUPPORTED, "dsw_linear_gated_silu: needs K <= 192 (or 128 / 64 exactly padded), a bf16 result with rows of a multiple of "
                                       "8 elements, whole chunks of 64 weight rows (K=%d rows=%d ldo=%lld)", K, ncols, ldc);
