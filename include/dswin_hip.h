@@ -441,6 +441,13 @@ int dsw_gated_silu_fwd(const void *h, int h_dtype, long long ldh, int H, long lo
 int dsw_gated_silu_bwd(const void *dout, int dout_dtype, long long ld_dout, const void *h, int h_dtype,
                        long long ldh, int H, long long M, void *dh, void *stream);
 
+/* The activation of msft's MLP (msft_arch.py:25: nn.GELU(), the erf form) between its two projections, on rows with
+ * their own stride: y[m][j] = gelu(x[m][j]), j < C, columns C..ldy-1 zeroed; backward dx = dy * gelu'(x), columns
+ * C..ld_dx-1 zeroed.  One dtype (fp32 or bf16) for all operands; C and the row strides are multiples of 4. */
+int dsw_gelu_fwd(const void *x, int dtype, long long ldx, int C, long long M, void *y, long long ldy, void *stream);
+int dsw_gelu_bwd(const void *dy, long long ld_dy, const void *x, int dtype, long long ldx, int C, long long M, void *dx,
+                 long long ld_dx, void *stream);
+
 /* The ReZero residual of the reference's ViTBlock (DSwinT_arch.py:355-357), y = x + r * branch, in one
  * pass: x, y fp32 [M][C]; branch fp32 or bf16 with row stride ldb; r one fp32 value on the device.
  * Backward (dx = dy needs no kernel): d_branch = r * dy in branch's dtype with row stride ld_db (columns

@@ -600,6 +600,36 @@ def test_linear_kernel(cuda0, M, K, N, a_dtype, c_dtype, pad_a, pad_c, copy):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,padded_in,pad_out", [(515, 432, True, True), (1000, 192, False, True), (77, 100, True, False)])
+def test_gelu_rows(cuda0, dtype, M, C, padded_in, pad_out):
+    """nn.GELU() of msft's MLP (msft_arch.py:25, the erf form) on dense rows and on views of zero-padded rows, forward
+    and backward, against torch's own gelu of the same inputs evaluated in fp32 (1e-6 for fp32; one bf16 rounding for
+    bf16); the padding columns of the result and of the gradient are zero."""
+    from visiontransformer_amd import functional as K
+    gen = torch.Generator().manual_seed(M + C)
+    ld = _ceil64(C) if padded_in else C
+    buf = torch.zeros(M, ld)
+    buf[:, :C] = torch.randn(M, C, generator=gen) * 2.0
+    base = buf.to(dtype).to(cuda0)
+    x = base[:, :C].detach().requires_grad_()
+    dy = torch.randn(M, C, generator=gen).to(dtype).to(cuda0)
+    y = K.gelu(x, pad_out=pad_out)
+    assert y.shape == (M, C) and y.dtype == dtype
+    if pad_out and _ceil64(C) > C:
+        assert y.stride(0) == _ceil64(C)
+        whole = torch.as_strided(y, (M, _ceil64(C)), (_ceil64(C), 1), y.storage_offset())
+        assert whole[:, C:].abs().max().item() == 0
+    gx, = torch.autograd.grad(y, x, dy)
+    xr = x.detach().float().requires_grad_()
+    yr = torch.nn.functional.gelu(xr)
+    gr, = torch.autograd.grad(yr, xr, dy.float())
+    tol = 1e-6 if dtype == torch.float32 else 2 ** -8
+    assert ((y.float() - yr).abs() <= tol * (1 + yr.abs())).all()
+    assert ((gx.float() - gr).abs() <= (1e-5 if dtype == torch.float32 else 2 ** -7) * (1 + gr.abs())).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N", [(300, 180, 540), (1000, 96, 100), (4096 + 24, 192, 64), (128 * 300 + 5, 180, 180),
                                    (2000, 360, 180), (3000, 216, 648), (700, 432, 216)])
 def test_linear_wgrad_kernel(cuda0, M, K, N):

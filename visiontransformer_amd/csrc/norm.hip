@@ -236,6 +236,83 @@ extern "C" int dsw_gated_silu_bwd(const void *dout, int dout_dtype, long long ld
     return check_launch("gated_silu_bwd_kernel");
 }
 
+// ---- GELU of msft's MLP (msft_arch.py:25: nn.GELU(), the erf form) on rows with their own stride ------------------
+// y[m][j] = x/2 * (1 + erf(x / sqrt 2)), j < C; columns C..ldy-1 := 0.  Backward: dx = dy * (Phi(x) + x * phi(x)).
+// The projections hand over and take views of zero-padded rows; an element-wise torch op on such a view runs in its
+// strided kernel at a third of the rate.
+namespace dsw {
+namespace {
+
+__device__ __forceinline__ float gelu_value(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_slope(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ x, long long ldx, int C, long long M, T *__restrict__ y,
+                                                       long long ldy) {
+    const int per_row = (int)(ldy / 4);
+    const long long items = M * per_row;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const long long m = it / per_row;
+        const int j = (int)(it - m * per_row) * 4;
+        float4 r = f4zero();
+        if (j < C) {
+            const float4 v = io<T>::ld4(x + m * ldx + j);
+            r = make_float4(gelu_value(v.x), gelu_value(v.y), gelu_value(v.z), gelu_value(v.w));
+        }
+        io<T>::st4(y + m * ldy + j, r);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T *__restrict__ dy, long long ld_dy, const T *__restrict__ x, long long ldx,
+                                                       int C, long long M, T *__restrict__ dx, long long ld_dx) {
+    const int per_row = (int)(ld_dx / 4);
+    const long long items = M * per_row;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const long long m = it / per_row;
+        const int j = (int)(it - m * per_row) * 4;
+        float4 r = f4zero();
+        if (j < C) {
+            const float4 v = io<T>::ld4(x + m * ldx + j), g = io<T>::ld4(dy + m * ld_dy + j);
+            r = make_float4(g.x * gelu_slope(v.x), g.y * gelu_slope(v.y), g.z * gelu_slope(v.z), g.w * gelu_slope(v.w));
+        }
+        io<T>::st4(dx + m * ld_dx + j, r);
+    }
+}
+
+int gelu_check(const char *who, long long M, int C, long long l0, long long l1, long long l2) {
+    if (M <= 0 || C <= 0 || l0 < C || l1 < C || l2 < C) return fail(DSW_EINVAL, "%s: bad sizes M=%lld C=%d ld=%lld / %lld / %lld", who, M, C, l0, l1, l2);
+    if (C % 4 || l0 % 4 || l1 % 4 || l2 % 4) return fail(DSW_EUNSUPPORTED, "%s: C and the row strides must be multiples of 4 (C=%d, %lld, %lld, %lld)", who, C, l0, l1, l2);
+    return DSW_OK;
+}
+
+}  // namespace
+}  // namespace dsw
+
+extern "C" int dsw_gelu_fwd(const void *x, int dtype, long long ldx, int C, long long M, void *y, long long ldy, void *stream) {
+    int rc = gelu_check("dsw_gelu_fwd", M, C, ldx, ldy, ldy);
+    if (rc) return rc;
+    DSW_REQUIRE(x && y, "dsw_gelu_fwd: null pointer");
+    DSW_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL(gelu_fwd_kernel<T>, dim3(gs_blocks(M * (ldy / 4))), dim3(256), 0, as_stream(stream), (const T *)x, ldx, C, M, (T *)y, ldy);
+    });
+    return check_launch("gelu_fwd_kernel");
+}
+
+extern "C" int dsw_gelu_bwd(const void *dy, long long ld_dy, const void *x, int dtype, long long ldx, int C, long long M, void *dx,
+                            long long ld_dx, void *stream) {
+    int rc = gelu_check("dsw_gelu_bwd", M, C, ld_dy, ldx, ld_dx);
+    if (rc) return rc;
+    DSW_REQUIRE(dy && x && dx, "dsw_gelu_bwd: null pointer");
+    DSW_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(gs_blocks(M * (ld_dx / 4))), dim3(256), 0, as_stream(stream), (const T *)dy, ld_dy,
+                           (const T *)x, ldx, C, M, (T *)dx, ld_dx);
+    });
+    return check_launch("gelu_bwd_kernel");
+}
+
 // ---- ReZero residual of the reference's ViTBlock (DSwinT_arch.py:355-357): y = x + r * branch -------
 // x, y: the fp32 stream [M][C]; branch: fp32 or bf16 rows with their own stride (the padded views the
 // attention modules and the MLP return); r: one fp32 parameter on the device.

@@ -1272,6 +1272,41 @@ def gated_silu(h, pad_out=False):
     return _run(_GatedSiluFn, h, H, bool(pad_out))
 
 
+class _GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad_out):
+        C = x.shape[-1]
+        x2, ldx = _row_view4(x, C)
+        M = x2.shape[0]
+        ldo = _ceil_pad(C) if pad_out else C
+        out = _mark_padded(torch.empty(M, ldo, dtype=x.dtype, device=x.device))
+        call("dsw_gelu_fwd", _dptr(x2), dtype_code(x2.dtype), ldx, C, M, ptr(out), ldo, stream(x.device))
+        ctx.save_for_backward(x2)
+        ctx.meta = (x.shape, ldx)
+        return (out[:, :C] if ldo != C else out).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, = ctx.saved_tensors
+        xshape, ldx = ctx.meta
+        M, C = x2.shape
+        if dy.dtype != x2.dtype:
+            dy = dy.to(x2.dtype)
+        d2, ldg = _row_view4(dy, C)
+        # the gradient keeps the row stride of x: padded rows (padding zeroed) go on to the projection's backward
+        dx = _mark_padded(torch.empty(M, ldx, dtype=x2.dtype, device=x2.device))
+        call("dsw_gelu_bwd", _dptr(d2), ldg, _dptr(x2), dtype_code(x2.dtype), ldx, C, M, ptr(dx), ldx, stream(x2.device))
+        return (dx[:, :C] if ldx != C else dx).view(xshape), None
+
+
+def gelu(x, pad_out=False):
+    """nn.GELU() (the erf form, msft_arch.py:25) on fp32 / bf16 rows, dense or views of zero-padded rows (what the
+    projections return and take); with pad_out the result is such a view too"""
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % 4 == 0 and x.numel() > 0):
+        return torch.nn.functional.gelu(x)
+    return _run(_GeluFn, x, bool(pad_out))
+
+
 # ---------------------------------------------------------------------------------------------
 # ReZero residual of the ViTBlock (DSwinT_arch.py:355-357)
 # ---------------------------------------------------------------------------------------------

@@ -111,7 +111,7 @@ class MLP(nn.Module):
         if not x.is_cuda:
             return self.mlp(x)
         # the two Linears through the projection kernels (they read the LayerNorm's fp32 output where it lies)
-        return self.mlp[3](K.linear(self.mlp[1](K.linear(x, self.mlp[0])), self.mlp[2]))
+        return self.mlp[3](K.linear(K.gelu(K.linear(x, self.mlp[0], pad_out=True), pad_out=True), self.mlp[2]))
 
 
 class ViTBlock(nn.Module):
