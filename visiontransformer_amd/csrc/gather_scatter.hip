@@ -20,44 +20,71 @@ struct Cover {
     int n;
 };
 
-__device__ __forceinline__ Cover find_cover(const int *__restrict__ cellmap, const int *__restrict__ win_h1,
-                                            const int *__restrict__ win_w1, int b, int y, int x, int Hw,
-                                            int Ww, int w) {
+// The covering windows of pixel (y, x), ascending by window id.  Both rounds of reads are issued as a group:
+// the four candidate cells first (cells outside the grid count as empty), then - only if one of them holds a
+// window - the corners of the four candidates (an empty candidate reads window 0, which exists then, and is
+// dropped), so a lookup costs two memory latencies whatever it finds.  SG: also the product
+// scores_delta * gates_delta of each covering window, in the same order.
+template <bool SG>
+__device__ __forceinline__ Cover find_cover_sg(const int *__restrict__ cellmap, const int *__restrict__ win_h1,
+                                               const int *__restrict__ win_w1, const float *__restrict__ scores_delta,
+                                               const float *__restrict__ gates_delta, int b, int y, int x, int Hw, int Ww,
+                                               int w, float (&sg)[4]) {
     Cover cv;
     cv.n = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { cv.id[i] = 0x7fffffff; cv.tok[i] = 0; }
+    for (int i = 0; i < 4; ++i) { cv.id[i] = 0x7fffffff; cv.tok[i] = 0; sg[i] = 0.f; }
     const int r_hi = min((y + (w >> 1)) / w, Hw - 1);
     const int c_hi = min((x + (w >> 1)) / w, Ww - 1);
+    int ids[4];
 #pragma unroll
-    for (int dr = 1; dr >= 0; --dr) {
-        const int r = r_hi - dr;
-        if (r < 0) continue;
+    for (int q = 0; q < 4; ++q) {
+        const int r = r_hi - 1 + (q >> 1), c = c_hi - 1 + (q & 1);
+        const int v = cellmap[((size_t)b * Hw + max(r, 0)) * Ww + max(c, 0)];
+        ids[q] = (r >= 0 && c >= 0) ? v : -1;
+    }
+    if ((ids[0] & ids[1] & ids[2] & ids[3]) < 0) return cv;  // every candidate is empty
+    int h1[4], w1[4];
+    float prod[4];
 #pragma unroll
-        for (int dc = 1; dc >= 0; --dc) {
-            const int c = c_hi - dc;
-            if (c < 0) continue;
-            const int id = cellmap[((size_t)b * Hw + r) * Ww + c];
-            if (id < 0) continue;
-            const int h1 = win_h1[id], w1 = win_w1[id];
-            const int ly = y - h1, lx = x - w1;
-            if (ly < 0 || ly >= w || lx < 0 || lx >= w) continue;
-            // insertion into the ascending list (<= 4 entries)
-            int pos = cv.n;
+    for (int q = 0; q < 4; ++q) {
+        const int j = max(ids[q], 0);
+        h1[q] = win_h1[j];
+        w1[q] = win_w1[j];
+        if constexpr (SG) prod[q] = scores_delta[j] * gates_delta[j];
+    }
 #pragma unroll
-            for (int s = 3; s > 0; --s) {
-                if (s <= pos && cv.id[s - 1] > id) {
-                    cv.id[s] = cv.id[s - 1];
-                    cv.tok[s] = cv.tok[s - 1];
-                    pos = s - 1;
-                }
+    for (int q = 0; q < 4; ++q) {
+        const int id = ids[q];
+        const int ly = y - h1[q], lx = x - w1[q];
+        if (id < 0 || ly < 0 || ly >= w || lx < 0 || lx >= w) continue;
+        // insertion into the ascending list (<= 4 entries; free slots hold the largest id): one pass of
+        // compare-and-exchange with fixed indices, so the list stays in registers
+        int nid = id, ntok = ly * w + lx;
+        float nsg = SG ? prod[q] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool sw = nid < cv.id[s];
+            const int tid_ = cv.id[s], ttok = cv.tok[s];
+            cv.id[s] = sw ? nid : tid_;
+            cv.tok[s] = sw ? ntok : ttok;
+            nid = sw ? tid_ : nid;
+            ntok = sw ? ttok : ntok;
+            if constexpr (SG) {
+                const float tsg = sg[s];
+                sg[s] = sw ? nsg : tsg;
+                nsg = sw ? tsg : nsg;
             }
-            cv.id[pos] = id;
-            cv.tok[pos] = ly * w + lx;
-            cv.n += 1;
         }
+        cv.n += 1;
     }
     return cv;
+}
+__device__ __forceinline__ Cover find_cover(const int *__restrict__ cellmap, const int *__restrict__ win_h1,
+                                            const int *__restrict__ win_w1, int b, int y, int x, int Hw,
+                                            int Ww, int w) {
+    float sg[4];
+    return find_cover_sg<false>(cellmap, win_h1, win_w1, nullptr, nullptr, b, y, x, Hw, Ww, w, sg);
 }
 
 // torchvision's bilinear sample at (y + .5, x + .5): taps (y, x), (y, xh), (yh, x), (yh, xh)
@@ -125,6 +152,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
     const int b = bid / (tiles_per_row * H);
     const int x0 = tile * TILE_PIX;
     const int npix = min(TILE_PIX, W - x0);
+    int many = 0;
     for (int t = threadIdx.x; t < 2 * (TILE_PIX + 1); t += GS_THREADS) {
         const int row = t / (TILE_PIX + 1), col = t - row * (TILE_PIX + 1);
         const int yy = y - 1 + row, xx = x0 - 1 + col;
@@ -132,32 +160,78 @@ __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
         cv.n = 0;
         if (yy >= 0 && xx >= 0 && xx < W) cv = find_cover(cellmap, win_h1, win_w1, b, yy, xx, Hw, Ww, w);
         cov[row][col] = cv;
+        many |= cv.n > 1;
     }
-    __syncthreads();
-    const int CV = C >> 2, L = w * w;
+    const int overlap = __syncthreads_or(many);  // some sample position of the tile lies in two or more windows
+    const int CV = C >> 2, L = w * w, total = npix * CV;
     const float wy_self = (y < H - 1) ? 0.5f : 1.0f;
-    for (int it = threadIdx.x; it < npix * CV; it += GS_THREADS) {
-        const int p = it / CV, c = (it - p * CV) << 2;
-        const int x = x0 + p;
-        const float wx_self = (x < W - 1) ? 0.5f : 1.0f;
-        float4 acc = f4zero();
-        int touched = 0;
+    TO *drow = dx + (((size_t)b * H + y) * W + x0) * C;
+    // A thread takes GB_U items (pixel, 4 channels) per trip and asks for everything they need before it uses
+    // any of it: the first covering window's row of each of the 4 sample positions, the second one's where the
+    // tile has overlapping windows at all, and the destination when accumulating - one memory latency per trip
+    // instead of one per load.  A slot with no window reads row 0 of dout (a valid address: some window exists
+    // when any position is covered) and is not added; third and fourth covering windows are fetched one by one
+    // afterwards.  The sums run in the order (row, col), then window id ascending.
+    constexpr int GB_U = 1;
+    for (int base = threadIdx.x; base < total; base += GB_U * GS_THREADS) {
+        float4 v[GB_U][4], v2[GB_U][4], old[GB_U];
+        int pp[GB_U], cc[GB_U], cnt[GB_U][4];
 #pragma unroll
-        for (int row = 0; row < 2; ++row) {
+        for (int u = 0; u < GB_U; ++u) {
+            const int it = min(base + u * GS_THREADS, total - 1);  // past the end: a valid item, dropped below
+            const int p = it / CV, c = (it - p * CV) << 2;
+            pp[u] = p;
+            cc[u] = c;
+            int any = 0;
 #pragma unroll
-            for (int col = 0; col < 2; ++col) {
-                const Cover &cv = cov[row][p + col];
-                const float wt = (row ? wy_self : 0.5f) * (col ? wx_self : 0.5f);
-                touched += cv.n;
-                for (int s = 0; s < cv.n; ++s)
-                    acc = acc + io<TG>::ld4(dout + ((size_t)cv.id[s] * L + cv.tok[s]) * ldg + c) * wt;
+            for (int q = 0; q < 4; ++q) {
+                cnt[u][q] = cov[q >> 1][p + (q & 1)].n;
+                any |= cnt[u][q];
+            }
+            if (any) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const Cover &cv = cov[q >> 1][p + (q & 1)];
+                    const size_t row = cnt[u][q] > 0 ? (size_t)cv.id[0] * L + cv.tok[0] : 0;
+                    v[u][q] = io<TG>::ld4(dout + row * ldg + c);
+                }
+                if (overlap) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const Cover &cv = cov[q >> 1][p + (q & 1)];
+                        const size_t row = cnt[u][q] > 1 ? (size_t)cv.id[1] * L + cv.tok[1] : 0;
+                        v2[u][q] = io<TG>::ld4(dout + row * ldg + c);
+                    }
+                }
+                if constexpr (ACC) old[u] = io<TO>::ld4(drow + (size_t)p * C + c);
             }
         }
-        TO *dst = dx + (((size_t)b * H + y) * W + x) * C + c;
-        if constexpr (ACC) {
-            if (touched) io<TO>::st4(dst, io<TO>::ld4(dst) + acc);
-        } else {
-            io<TO>::st4(dst, acc);
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) {
+            if (base + u * GS_THREADS >= total) break;
+            const int p = pp[u], c = cc[u];
+            const float wx_self = (x0 + p < W - 1) ? 0.5f : 1.0f;
+            float4 acc = f4zero();
+            int touched = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = cnt[u][q];
+                const float wt = ((q >> 1) ? wy_self : 0.5f) * ((q & 1) ? wx_self : 0.5f);
+                touched += n;
+                if (n > 0) acc = acc + v[u][q] * wt;
+                if (n > 1) acc = acc + v2[u][q] * wt;
+                if (n > 2) {
+                    const Cover &cv = cov[q >> 1][p + (q & 1)];
+                    for (int s = 2; s < n; ++s)
+                        acc = acc + io<TG>::ld4(dout + ((size_t)cv.id[s] * L + cv.tok[s]) * ldg + c) * wt;
+                }
+            }
+            TO *dst = drow + (size_t)p * C + c;
+            if constexpr (ACC) {
+                if (touched) io<TO>::st4(dst, old[u] + acc);
+            } else {
+                io<TO>::st4(dst, acc);
+            }
         }
     }
 }
@@ -214,41 +288,75 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
     const int b = bid / (tiles_per_row * H);
     const int x0 = tile * TILE_PIX;
     const int npix = min(TILE_PIX, W - x0);
+    const int CV = C >> 2, total = npix * CV;
+    const float wy_self = (y < H - 1) ? 0.5f : 1.0f;
+    const TG *gimg = dy + (size_t)b * H * W * C;
+    const TG *grow = gimg + (size_t)y * W * C;                     // image row y
+    const TG *gup = gimg + (size_t)(y > 0 ? y - 1 : 0) * W * C;    // row y - 1 (its factors are 0 when y == 0)
+    TO *drow = dx + (((size_t)b * H + y) * W) * C;
+    // A thread takes SB_U items (pixel, 4 channels) per trip.  Their own dy values (and the destination when
+    // accumulating) are asked for together one trip ahead - the first trip's before the covering windows are
+    // looked up, so that the lookup's two memory latencies pass under them - and an item with a covered sample
+    // position among (y-1, x-1), (y-1, x), (y, x-1) asks for those three together (clamped addresses, factor 0
+    // where there is nothing).  The fourth sample position is the pixel itself.  The terms are subtracted in a
+    // fixed order with the factors (weight * f); a term whose f is 0 leaves the value as it is.
+    constexpr int SB_U = 3;
+    struct Trip {
+        float4 ctr[SB_U], old[SB_U];
+        int p[SB_U], c[SB_U];
+    };
+    auto issue = [&](int base, Trip &t) {
+#pragma unroll
+        for (int u = 0; u < SB_U; ++u) {
+            const int it = min(base + u * GS_THREADS, total - 1);  // past the end: a valid item, dropped later
+            const int p = it / CV, c = (it - p * CV) << 2;
+            t.p[u] = p;
+            t.c[u] = c;
+            t.ctr[u] = io<TG>::ld4(grow + (size_t)(x0 + p) * C + c);
+            if constexpr (ACC) t.old[u] = io<TO>::ld4(drow + (size_t)(x0 + p) * C + c);
+        }
+    };
+    Trip cur;
+    issue(threadIdx.x, cur);
     for (int t = threadIdx.x; t < 2 * (TILE_PIX + 1); t += GS_THREADS) {
         const int row = t / (TILE_PIX + 1), col = t - row * (TILE_PIX + 1);
         const int yy = y - 1 + row, xx = x0 - 1 + col;
         float f = 0.f;
         if (yy >= 0 && xx >= 0 && xx < W) {
-            const Cover cv = find_cover(cellmap, win_h1, win_w1, b, yy, xx, Hw, Ww, w);
-            for (int s = 0; s < cv.n; ++s) f += scores_delta[cv.id[s]] * gates_delta[cv.id[s]];
+            float sg[4];
+            const Cover cv = find_cover_sg<true>(cellmap, win_h1, win_w1, scores_delta, gates_delta, b, yy, xx, Hw, Ww, w, sg);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < cv.n) f += sg[s];
             if (cv.n > 0) f = f / (float)cv.n;
         }
         fac[row][col] = f;
     }
     __syncthreads();
-    const int CV = C >> 2;
-    const float wy_self = (y < H - 1) ? 0.5f : 1.0f;
-    const TG *gimg = dy + (size_t)b * H * W * C;
-    for (int it = threadIdx.x; it < npix * CV; it += GS_THREADS) {
-        const int p = it / CV, c = (it - p * CV) << 2;
-        const int x = x0 + p;
-        const float wx_self = (x < W - 1) ? 0.5f : 1.0f;
-        float4 acc = io<TG>::ld4(gimg + ((size_t)y * W + x) * C + c);
+    for (int base = threadIdx.x; base < total; base += SB_U * GS_THREADS) {
+        Trip nxt;
+        issue(base + SB_U * GS_THREADS, nxt);
 #pragma unroll
-        for (int row = 0; row < 2; ++row) {
-#pragma unroll
-            for (int col = 0; col < 2; ++col) {
-                const float f = fac[row][p + col];
-                if (f != 0.f) {
-                    const float wt = (row ? wy_self : 0.5f) * (col ? wx_self : 0.5f);
-                    const int yy = y - 1 + row, xx = x - 1 + col;
-                    acc = acc - io<TG>::ld4(gimg + ((size_t)yy * W + xx) * C + c) * (wt * f);
-                }
+        for (int u = 0; u < SB_U; ++u) {
+            if (base + u * GS_THREADS >= total) break;
+            const int p = cur.p[u], c = cur.c[u], x = x0 + p;
+            const float wx_self = (x < W - 1) ? 0.5f : 1.0f;
+            const float f00 = fac[0][p], f01 = fac[0][p + 1], f10 = fac[1][p], f11 = fac[1][p + 1];
+            float4 acc = cur.ctr[u];
+            if (f00 != 0.f || f01 != 0.f || f10 != 0.f) {
+                const int xm = x > 0 ? x - 1 : 0;
+                const float4 n00 = io<TG>::ld4(gup + (size_t)xm * C + c);
+                const float4 n01 = io<TG>::ld4(gup + (size_t)x * C + c);
+                const float4 n10 = io<TG>::ld4(grow + (size_t)xm * C + c);
+                if (f00 != 0.f) acc = acc - n00 * ((0.5f * 0.5f) * f00);
+                if (f01 != 0.f) acc = acc - n01 * ((0.5f * wx_self) * f01);
+                if (f10 != 0.f) acc = acc - n10 * ((wy_self * 0.5f) * f10);
             }
+            if (f11 != 0.f) acc = acc - cur.ctr[u] * ((wy_self * wx_self) * f11);
+            if constexpr (ACC) acc = acc + cur.old[u];
+            io<TO>::st4(drow + (size_t)x * C + c, acc);
         }
-        TO *dst = dx + (((size_t)b * H + y) * W + x) * C + c;
-        if constexpr (ACC) acc = acc + io<TO>::ld4(dst);
-        io<TO>::st4(dst, acc);
+        cur = nxt;
     }
 }
 
@@ -316,10 +424,23 @@ __global__ void scatter_bwd_reduce_kernel(const float *__restrict__ partial, int
                                           float *__restrict__ d_gates_delta, float *__restrict__ d_scores_delta) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_win) return;
+    // row order, eight rows' partials asked for at a time
+    const float2 *row = reinterpret_cast<const float2 *>(partial) + (size_t)n * w;
     float tg = 0.f, ts = 0.f;
-    for (int i = 0; i < w; ++i) {
-        tg += partial[((size_t)n * w + i) * 2 + 0];
-        ts += partial[((size_t)n * w + i) * 2 + 1];
+    int i = 0;
+    for (; i + 8 <= w; i += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = row[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            tg += v[j].x;
+            ts += v[j].y;
+        }
+    }
+    for (; i < w; ++i) {
+        tg += row[i].x;
+        ts += row[i].y;
     }
     d_gates_delta[n] = tg;
     d_scores_delta[n] = ts;
@@ -422,6 +543,7 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
     DSW_REQUIRE(n_win == 0 || (x && after && gates_delta && scores_delta && win_b && win_h1 && win_w1 && d_after &&
                                d_gates_delta && d_scores_delta && partial),
                 "dsw_scatter_mean_bwd: null window arrays");
+    DSW_REQUIRE((reinterpret_cast<uintptr_t>(partial) & 7) == 0, "dsw_scatter_mean_bwd: partial must be 8-byte aligned");
     DSW_REQUIRE(x_dtype == dy_dtype || true, "unused");
     const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
     hipStream_t st = as_stream(stream);
@@ -454,7 +576,7 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
     })));
     rc = check_launch("scatter_bwd_win_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(scatter_bwd_reduce_kernel, dim3((n_win + 255) / 256), dim3(256), 0, st, partial, n_win, w,
+    hipLaunchKernelGGL(scatter_bwd_reduce_kernel, dim3((n_win + 63) / 64), dim3(64), 0, st, partial, n_win, w,
                        d_gates_delta, d_scores_delta);
     return check_launch("scatter_bwd_reduce_kernel");
 }
