@@ -104,8 +104,10 @@ __global__ __launch_bounds__(512, (DP == 32 ? 4 : 2)) void win_attn_bwd_w16_kern
     };
     auto locate = [&](int item) -> Where {
         Where w;
+        // (integer division runs on the vector unit: its wave-uniform quotients are handed back to the scalar
+        // registers, so that everything derived from them - offsets, base addresses - stays out of the VGPRs)
         const int id = xcd_remap(item, total);
-        w.win = id / g.heads;
+        w.win = __builtin_amdgcn_readfirstlane(id / g.heads);
         w.head = id - w.win * g.heads;
         qkv_offsets(g, w.head, w.qoff, w.koff, w.voff);
         if (g.H == 0) {
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(512, (DP == 32 ? 4 : 2)) void win_attn_bwd_w16_kern
             w.pitch = WS;
         } else {
             const int per = g.nWh * g.nWw;
-            const int b = w.win / per, r = w.win - b * per;
-            const int wr = r / g.nWw, wc = r - wr * g.nWw;
+            const int b = __builtin_amdgcn_readfirstlane(w.win / per), r = w.win - b * per;
+            const int wr = __builtin_amdgcn_readfirstlane(r / g.nWw), wc = r - wr * g.nWw;
             w.origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
             w.pitch = g.W;
         }

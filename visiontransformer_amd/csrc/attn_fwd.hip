@@ -36,7 +36,7 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
 
     const int tid = threadIdx.x;
     const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
-    const int win = id / g.heads, head = id - win * g.heads;
+    const int win = __builtin_amdgcn_readfirstlane(id / g.heads), head = id - win * g.heads;  // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
     const int d = g.d, C3 = g.ldq;  // C3: row stride of qkv
     int qoff, koff, voff;
     qkv_offsets(g, head, qoff, koff, voff);
@@ -48,8 +48,8 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
         pitch = WS;
     } else {
         const int per = g.nWh * g.nWw;
-        const int b = win / per, r = win - b * per;
-        const int wr = r / g.nWw, wc = r - wr * g.nWw;
+        const int b = __builtin_amdgcn_readfirstlane(win / per), r = win - b * per;
+        const int wr = __builtin_amdgcn_readfirstlane(r / g.nWw), wc = r - wr * g.nWw;
         origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
         pitch = g.W;
     }

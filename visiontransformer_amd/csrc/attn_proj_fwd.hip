@@ -48,7 +48,7 @@ __global__ __launch_bounds__((ProjCfg<WS>::THREADS), (ProjCfg<WS>::F::MIN_WAVES)
 
     const int tid = threadIdx.x;
     const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
-    const int win = id / g.heads, head = id - win * g.heads;
+    const int win = __builtin_amdgcn_readfirstlane(id / g.heads), head = id - win * g.heads;  // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
     const int d = g.d;
     int qoff, koff, voff;
     qkv_offsets(g, head, qoff, koff, voff);
@@ -59,8 +59,8 @@ __global__ __launch_bounds__((ProjCfg<WS>::THREADS), (ProjCfg<WS>::F::MIN_WAVES)
         pitch = WS;
     } else {
         const int per = g.nWh * g.nWw;
-        const int b = win / per, r = win - b * per;
-        const int wr = r / g.nWw, wc = r - wr * g.nWw;
+        const int b = __builtin_amdgcn_readfirstlane(win / per), r = win - b * per;
+        const int wr = __builtin_amdgcn_readfirstlane(r / g.nWw), wc = r - wr * g.nWw;
         origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
         pitch = g.W;
     }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_fwd_kernel(
     const int *__restrict__ win_w1, int H, int W, int C, int w, int ldo, TO *__restrict__ out) {
     // out rows are ldo >= C elements apart; the columns C..ldo-1 are set to zero
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the rows of a window on one XCD: they share x rows
-    const int n = bid / w, i = bid - n * w;
+    const int n = __builtin_amdgcn_readfirstlane(bid / w), i = bid - n * w;
     const int b = win_b[n], y = win_h1[n] + i, x0 = win_w1[n];
     const TI *img = x + (size_t)b * H * W * C;
     TO *dst = out + ((size_t)n * w * w + (size_t)i * w) * ldo;
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
     __shared__ Cover cov[2][TILE_PIX + 1];
     const int Hw = H / w, Ww = W / w;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
-    const int tile = bid % tiles_per_row;
-    const int y = (bid / tiles_per_row) % H;
-    const int b = bid / (tiles_per_row * H);
+    // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
+    const int trow = __builtin_amdgcn_readfirstlane(bid / tiles_per_row), tile = bid - trow * tiles_per_row;
+    const int b = __builtin_amdgcn_readfirstlane(trow / H), y = trow - b * H;
     const int x0 = tile * TILE_PIX;
     const int npix = min(TILE_PIX, W - x0);
     int many = 0;
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_fwd_kernel(
     __shared__ Cover cov[TILE_PIX];
     const int Hw = H / w, Ww = W / w;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
-    const int tile = bid % tiles_per_row;
-    const int y = (bid / tiles_per_row) % H;
-    const int b = bid / (tiles_per_row * H);
+    // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
+    const int trow = __builtin_amdgcn_readfirstlane(bid / tiles_per_row), tile = bid - trow * tiles_per_row;
+    const int b = __builtin_amdgcn_readfirstlane(trow / H), y = trow - b * H;
     const int x0 = tile * TILE_PIX;
     const int npix = min(TILE_PIX, W - x0);
     if (threadIdx.x < npix) cov[threadIdx.x] = find_cover(cellmap, win_h1, win_w1, b, y, x0 + threadIdx.x, Hw, Ww, w);
@@ -283,9 +283,9 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
     __shared__ float fac[2][TILE_PIX + 1];  // sum_n(s_n*g_n)/count at the sample position, 0 if uncovered
     const int Hw = H / w, Ww = W / w;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
-    const int tile = bid % tiles_per_row;
-    const int y = (bid / tiles_per_row) % H;
-    const int b = bid / (tiles_per_row * H);
+    // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
+    const int trow = __builtin_amdgcn_readfirstlane(bid / tiles_per_row), tile = bid - trow * tiles_per_row;
+    const int b = __builtin_amdgcn_readfirstlane(trow / H), y = trow - b * H;
     const int x0 = tile * TILE_PIX;
     const int npix = min(TILE_PIX, W - x0);
     const int CV = C >> 2, total = npix * CV;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_win_kernel(
     __shared__ float red[GS_THREADS / 64];
     const int Hw = H / w, Ww = W / w;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n = bid / w, i = bid - n * w;
+    const int n = __builtin_amdgcn_readfirstlane(bid / w), i = bid - n * w;
     if (n_live != nullptr && n >= *n_live) {
         // a window slot behind the passing ones (callers that never read the count on the host hand over all
         // B*k slots): nothing was written back from it, so its gradients are zero
