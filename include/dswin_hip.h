@@ -448,6 +448,13 @@ int dsw_gelu_fwd(const void *x, int dtype, long long ldx, int C, long long M, vo
 int dsw_gelu_bwd(const void *dy, long long ld_dy, const void *x, int dtype, long long ldx, int C, long long M, void *dx,
                  long long ld_dx, void *stream);
 
+/* One up-sampling stage of the reference's reconstruction tail (DSwinT_arch.py:426-437: Conv2d(f, 4f, 3) ->
+ * PixelShuffle(2) -> GELU) on NHWC tensors: x [B][H][W][4c] is the convolution's result with its output channels
+ * ordered (r1, r2, channel) - nn.PixelShuffle's channel index channel*4 + r1*2 + r2 re-ordered, which the caller does
+ * on the weight rows - and y [B][2H][2W][c] = gelu(erf form) of the shuffled tensor.  One dtype (fp32 or bf16); c is a
+ * multiple of 4, both tensors dense. */
+int dsw_shuffle2_gelu_nhwc(const void *x, int dtype, int B, int H, int W, int c, void *y, void *stream);
+
 /* The ReZero residual of the reference's ViTBlock (DSwinT_arch.py:355-357), y = x + r * branch, in one
  * pass: x, y fp32 [M][C]; branch fp32 or bf16 with row stride ldb; r one fp32 value on the device.
  * Backward (dx = dy needs no kernel): d_branch = r * dy in branch's dtype with row stride ld_db (columns

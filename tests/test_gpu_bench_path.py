@@ -244,3 +244,56 @@ def test_fp16_autocast_of_the_reference_trainer(cuda0):
             outs.append((y.float().detach(), xin.grad.clone(), [str(w_.message) for w_ in rec]))
         assert rel_err(outs[1][0], outs[0][0]) < 1e-2 and rel_err(outs[1][1], outs[0][1]) < 2e-2
     assert K._FP16_WARNED[0]
+
+
+def test_shuffle2_gelu_nhwc_kernel(cuda0):
+    """PixelShuffle(2) + GELU on NHWC with the channels in sub-pixel order against nn.PixelShuffle + nn.GELU on the
+    NCHW tensor with torch's channel order (DSwinT_arch.py:426-437)"""
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(5)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        B, H, W, c = 2, 5, 7, 8
+        x = torch.randn(B, 4 * c, H, W, device=cuda0).to(dtype)                       # NCHW, channel = ch*4 + r1*2 + r2
+        ref = torch.nn.functional.gelu(torch.nn.functional.pixel_shuffle(x.float(), 2))   # [B, c, 2H, 2W]
+        xn = x.view(B, c, 4, H, W).permute(0, 3, 4, 2, 1).reshape(B, H, W, 4 * c).contiguous()   # NHWC, (r1 r2, ch)
+        y = K.shuffle2_gelu_nhwc(xn)
+        assert y.shape == (B, 2 * H, 2 * W, c) and y.dtype == dtype
+        assert rel_err(y.float().permute(0, 3, 1, 2), ref) < tol
+
+
+def test_nhwc_stem_and_reconstruction_tail_against_the_stock_convolutions(cuda0):
+    """Inference under bf16 autocast: the default DSWT network with its stem and reconstruction tail on the NHWC
+    kernels (models.NHWC_ENDS) against the same network with those two ends as stock NCHW convolutions.  The trunk in
+    between is the same code on both sides; its input differs by the stem's rounding (the NHWC stem writes the fp32
+    stream directly, the stock one hands over bf16), so the bar is the bf16 one for a network this deep."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd import models
+    g, m = load_golden("model_dswt_default")
+    net = models.DSWTransformer(**m["cfg"])
+    fill_parameters(net, m["seed"])
+    net = net.to(cuda0).eval()
+    x = g["x"].to(cuda0)
+    # the two ends alone, on the same input: stem, then the tail on a random stream
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        xs = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 1))
+        stem = K.conv3x3_nhwc_infer(xs, net.feature_extractor, "pad_in4", out_dtype=torch.float32)
+        stem_ref = net.feature_extractor(x).permute(0, 2, 3, 1).float()
+        assert rel_err(stem, stem_ref) < 1e-2
+        s = torch.randn(1, 32, 48, m["cfg"]["dim"], device=cuda0)
+        steps = models._tail_plan(net.img_reconstruction, s)
+        assert steps is not None and [k for k, _, _ in steps].count("shuffle_gelu") == 2
+        tail = models._tail_nhwc(net.img_reconstruction, s, steps)
+        tail_ref = net.img_reconstruction(s.permute(0, 3, 1, 2).contiguous())
+        assert tail.shape == tail_ref.shape == (1, 3, 128, 192)
+        assert rel_err(tail.float(), tail_ref.float()) < BF16_TOL
+    # whole network, both ways
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y_new = net(x)
+        models.NHWC_ENDS = False
+        try:
+            y_old = net(x)
+        finally:
+            models.NHWC_ENDS = True
+    assert y_new.shape == y_old.shape == g["y"].shape
+    assert torch.isfinite(y_new).all()
+    assert rel_err(y_new.float(), g["y"]) < 0.15 and rel_err(y_old.float(), g["y"]) < 0.15

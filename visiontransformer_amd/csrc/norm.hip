@@ -313,6 +313,42 @@ extern "C" int dsw_gelu_bwd(const void *dy, long long ld_dy, const void *x, int 
     return check_launch("gelu_bwd_kernel");
 }
 
+// ---- up-sampling stage of the reconstruction tail on NHWC (DSwinT_arch.py:426-437: Conv2d -> PixelShuffle(2) -> GELU) ----
+// x [B][H][W][4c] holds, per pixel, its four sub-pixels (r1, r2) as runs of c channels - the convolution that
+// produced it had its output channels ordered (r1, r2, channel) - and y [B][2H][2W][c] receives
+// y[b][2h + r1][2w + r2][:] = gelu(x[b][h][w][(2 r1 + r2) c : (2 r1 + r2 + 1) c]): the shuffle is the addressing of
+// the activation's pass, both sides move whole runs of c elements.
+namespace dsw {
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void shuffle2_gelu_kernel(const T *__restrict__ x, int H, int W, int c, long long items, T *__restrict__ y) {
+    const int cq = c >> 2;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int j = (int)(it % cq);
+        long long t = it / cq;
+        const int ow = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int oh = (int)(t % (2 * H));
+        const long long b = t / (2 * H);
+        const long long src = ((((b * H + (oh >> 1)) * W + (ow >> 1)) * 4 + (oh & 1) * 2 + (ow & 1)) * (long long)c) + 4 * j;
+        const float4 v = io<T>::ld4(x + src);
+        io<T>::st4(y + it * 4, make_float4(gelu_value(v.x), gelu_value(v.y), gelu_value(v.z), gelu_value(v.w)));
+    }
+}
+}  // namespace
+}  // namespace dsw
+
+extern "C" int dsw_shuffle2_gelu_nhwc(const void *x, int dtype, int B, int H, int W, int c, void *y, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || c <= 0) return fail(DSW_EINVAL, "dsw_shuffle2_gelu_nhwc: bad sizes B=%d H=%d W=%d c=%d", B, H, W, c);
+    if (c % 4) return fail(DSW_EUNSUPPORTED, "dsw_shuffle2_gelu_nhwc: c=%d must be a multiple of 4", c);
+    DSW_REQUIRE(x && y, "dsw_shuffle2_gelu_nhwc: null pointer");
+    const long long items = (long long)B * H * W * c;  // 4 sub-pixels x c / 4 groups of four
+    DSW_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL(shuffle2_gelu_kernel<T>, dim3(gs_blocks(items)), dim3(256), 0, as_stream(stream), (const T *)x, H, W, c, items, (T *)y);
+    });
+    return check_launch("shuffle2_gelu_kernel");
+}
+
 // ---- ReZero residual of the reference's ViTBlock (DSwinT_arch.py:355-357): y = x + r * branch -------
 // x, y: the fp32 stream [M][C]; branch: fp32 or bf16 rows with their own stride (the padded views the
 // attention modules and the MLP return); r: one fp32 parameter on the device.

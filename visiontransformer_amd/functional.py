@@ -1511,6 +1511,76 @@ def conv3x3_nhwc(x, conv):
     return _run(_Conv3x3Fn, x.contiguous(), conv.weight, conv.bias, act)
 
 
+_CONV_VARIANTS = ("plain", "shuffle2", "pad_in4", "pad_out4")
+
+
+def _conv3x3_variant(conv, variant):
+    """(operand, fp32 bias, Co, Ci) of a transformed copy of a 3x3 Conv2d's parameters, kept per parameter like the
+    plain operands: "shuffle2" orders the output channels (r1, r2, channel) instead of nn.PixelShuffle(2)'s
+    channel*4 + r1*2 + r2, "pad_in4" / "pad_out4" add zero input / output channels up to a multiple of 4."""
+    weight, bias = conv.weight, conv.bias
+    caching = _may_keep_operands()
+    key = ("conv3x3", variant, id(weight))
+    sig = (weight._version, weight.data_ptr(), None if bias is None else bias._version, None if bias is None else bias.data_ptr())
+    if caching:
+        e = _PREP_CACHE.get(key)
+        if e is not None and e[0]() is weight and e[1] == sig:
+            return e[2]
+    w = weight.detach().float()
+    b = None if bias is None else bias.detach().float()
+    if variant == "shuffle2":
+        Co = w.shape[0]
+        w = w.view(Co // 4, 4, *w.shape[1:]).transpose(0, 1).reshape(Co, *w.shape[1:])
+        b = None if b is None else b.view(Co // 4, 4).t().reshape(Co)
+    elif variant == "pad_in4":
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, -w.shape[1] % 4))
+    elif variant == "pad_out4":
+        extra = -w.shape[0] % 4
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, extra))
+        b = None if b is None else torch.nn.functional.pad(b, (0, extra))
+    w = w.contiguous()
+    out = (_taps_operand(w), None if b is None else b.contiguous(), w.shape[0], w.shape[1])
+    if caching:
+        _PREP_CACHE[key] = (weakref.ref(weight), sig, out)
+    return out
+
+
+def conv3x3_nhwc_infer_ok(shape, dtype, conv, variant="plain"):
+    """whether conv3x3_nhwc_infer takes a CUDA tensor of this NHWC shape and dtype (geometry of `conv`, channel
+    counts after `variant`, sizes)"""
+    B, H, W, Ci = shape
+    Co = conv.out_channels + (-conv.out_channels % 4 if variant == "pad_out4" else 0)
+    Cin = conv.in_channels + (-conv.in_channels % 4 if variant == "pad_in4" else 0)
+    esize = 4 if dtype == torch.float32 else 2
+    return (dtype in (torch.float32, torch.bfloat16) and Cin == Ci and Ci % 4 == 0 and Co % 4 == 0
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and (variant != "shuffle2" or conv.out_channels % 16 == 0)
+            and 0 < B * H * W < 2 ** 31 - 256 and B * H * W * Ci * esize < 2 ** 31)
+
+
+def conv3x3_nhwc_infer(x, conv, variant="plain", out_dtype=torch.bfloat16):
+    """Without autograd: `conv` (3x3, stride 1, padding 1) applied to the NHWC tensor x [B, H, W, Ci] on the matrix
+    cores (bf16 operands, fp32 accumulation) -> [B, H, W, Co] in out_dtype, with the parameters transformed as
+    `variant` says (_conv3x3_variant)."""
+    assert variant in _CONV_VARIANTS and not torch.is_grad_enabled()
+    B, H, W, Ci = x.shape
+    x = x.contiguous()
+    w_p, b32, Co, Cin = _conv3x3_variant(conv, variant)
+    out = torch.empty(B, H, W, Co, dtype=out_dtype, device=x.device)
+    _conv3x3_call(x.view(B * H * W, Ci), B, H, W, Ci, w_p, b32, Co, out, None)
+    return out
+
+
+def shuffle2_gelu_nhwc(x):
+    """nn.PixelShuffle(2) followed by nn.GELU() on an NHWC tensor whose channels are ordered (r1, r2, channel):
+    [B, H, W, 4c] -> [B, 2H, 2W, c] (dsw_shuffle2_gelu_nhwc)"""
+    B, H, W, C4 = x.shape
+    x = x.contiguous()
+    y = torch.empty(B, 2 * H, 2 * W, C4 // 4, dtype=x.dtype, device=x.device)
+    call("dsw_shuffle2_gelu_nhwc", ptr(x), dtype_code(x.dtype), B, H, W, C4 // 4, ptr(y), stream(x.device))
+    return y
+
+
 # ---------------------------------------------------------------------------------------------
 # LayerNorm of msft's ViTBlock (msft_arch.py:152-153, :163-165)
 # ---------------------------------------------------------------------------------------------

@@ -166,6 +166,50 @@ def _reconstruction_tail(dim, feature_dim, scale_factor, last_div):
     return nn.Sequential(*layers)
 
 
+def _tail_plan(seq, x):
+    """How the reconstruction tail runs on an NHWC tensor without autograd: a list of steps, or None when some
+    module or size is not one the NHWC kernels take."""
+    mods, steps, i = list(seq), [], 0
+    B, H, W, C = x.shape
+    dtype = x.dtype
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            up = (i + 2 < len(mods) and isinstance(mods[i + 1], nn.PixelShuffle) and mods[i + 1].upscale_factor == 2
+                  and isinstance(mods[i + 2], nn.GELU))
+            variant = "shuffle2" if up else ("pad_out4" if m.out_channels % 4 else "plain")
+            if not K.conv3x3_nhwc_infer_ok((B, H, W, C), dtype, m, variant):
+                return None
+            steps.append(("conv", m, variant))
+            C, dtype = m.out_channels + (-m.out_channels % 4), torch.bfloat16
+            if up:
+                steps.append(("shuffle_gelu", None, None))
+                H, W, C = 2 * H, 2 * W, C // 4
+                i += 2
+        elif isinstance(m, nn.GELU) and m.approximate == "none":
+            steps.append(("gelu", None, None))
+        else:
+            return None
+        i += 1
+    return steps
+
+
+def _tail_nhwc(seq, x, steps):
+    """The reconstruction tail (DSwinT_arch.py:426-437) on the NHWC stream without autograd: every convolution on the
+    matrix cores through the NHWC kernel, PixelShuffle as the addressing of the GELU pass that follows it (the
+    convolution before it emits its channels in sub-pixel order), no NCHW copy before the last step.  Returns NCHW."""
+    y = x
+    for kind, m, variant in steps:
+        if kind == "conv":
+            y = K.conv3x3_nhwc_infer(y, m, variant)
+        elif kind == "shuffle_gelu":
+            y = K.shuffle2_gelu_nhwc(y)
+        else:
+            y = K.gelu(y)
+    last = [m for m in seq if isinstance(m, nn.Conv2d)][-1]
+    return y[..., :last.out_channels].permute(0, 3, 1, 2)
+
+
 def _reflect_pad_to(x, divisor):
     _, _, h, w = x.shape
     ph = (divisor - h % divisor) % divisor
@@ -232,21 +276,42 @@ class DSWTransformer(nn.Module):
         # (toolkit/model_helper2.py:115): the step has been counted already
         if self.training and torch._C._current_graph_task_id() == -1:
             self.update_temperature()
-        x = self.feature_extractor(self.padding(x))
-        x = x.permute(0, 2, 3, 1).contiguous()
-        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16):
-            # under autocast the stem hands over bf16; the residual stream between the blocks is kept in
-            # fp32 (what it becomes after the first ReZero residual anyway, DSwinT_arch.py:355), so every
-            # norm and residual of every block runs in its kernel and no gradient is cast at a block boundary
-            x = x.float()
+        x = self.padding(x)
+        # Without autograd under bf16 autocast the stem and the reconstruction tail stay on NHWC tensors and on the
+        # package's convolution kernel (NHWC_ENDS): no NCHW <-> NHWC copies around them, the stem writes the fp32
+        # stream directly (3 input channels padded to 4), the tail never materialises an NCHW tensor.
+        nhwc_ends = (NHWC_ENDS and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+                     and K.autocast_dtype(x.dtype) == torch.bfloat16)
+        xs = None
+        if nhwc_ends:
+            xs = F.pad(x.permute(0, 2, 3, 1), (0, -x.shape[1] % 4))
+            if K.conv3x3_nhwc_infer_ok(xs.shape, xs.dtype, self.feature_extractor, "pad_in4"):
+                xs = K.conv3x3_nhwc_infer(xs, self.feature_extractor, "pad_in4", out_dtype=torch.float32)
+            else:
+                xs = None
+        if xs is None:
+            x = self.feature_extractor(x)
+            x = x.permute(0, 2, 3, 1).contiguous()
+            if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16):
+                # under autocast the stem hands over bf16; the residual stream between the blocks is kept in
+                # fp32 (what it becomes after the first ReZero residual anyway, DSwinT_arch.py:355), so every
+                # norm and residual of every block runs in its kernel and no gradient is cast at a block boundary
+                x = x.float()
+        else:
+            x = xs
         x = self.feature_transition(self.layers(x)) + x
-        x = self.img_reconstruction(x.permute(0, 3, 1, 2).contiguous())
+        steps = _tail_plan(self.img_reconstruction, x) if nhwc_ends else None
+        if steps is not None:
+            x = _tail_nhwc(self.img_reconstruction, x, steps)
+        else:
+            x = self.img_reconstruction(x.permute(0, 3, 1, 2).contiguous())
         return x[:, :, :H * self.scale_factor, :W * self.scale_factor]
 
 
 # ------------------------------------------------------------------------------------------------
 # MSFT
 # ------------------------------------------------------------------------------------------------
+NHWC_ENDS = True     # False: DSWTransformer's stem and reconstruction tail always run as stock NCHW convolutions
 NHWC_STREAM = True   # False: MSFTransformer runs its trunk module by module on NCHW tensors, as the reference does
 
 
