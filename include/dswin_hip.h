@@ -246,6 +246,13 @@ int dsw_unshuffle_nhwc_fwd(const void *x, int dtype, int B, int c, int H, int W,
  */
 int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B,
                       int H, int W, int C, void *y, int y_dtype, const int *identity_if_zero, void *stream);
+
+/* Inference: the same convolution with the ReZero residual of the block around DS-MSA (DSwinT_arch.py:356,
+ * x + rezero3 * sdwa(ln3(x))) taken in its pass: y = resid + *rscale * dwconv(x) (or resid + *rscale * x when
+ * *identity_if_zero == 0), fp32 [B][H][W][C]; resid and y 16-byte aligned, rscale one fp32 value on the device. */
+int dsw_dwconv3x3_residual_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
+                               int C, const float *resid, const float *rscale, float *y, const int *identity_if_zero,
+                               void *stream);
 int dsw_dwconv3x3_bwd_blocks(int B, int H, int W);
 int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype, const float *weight,
                       int B, int H, int W, int C, void *dx, int dx_dtype, float *d_weight,
@@ -496,6 +503,12 @@ int dsw_rezero_dropout_seeded_bwd(const float *dy, const void *branch, int b_dty
 int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p,
                      int wrows, int ldw, const float *bias, int N, void *out, int out_dtype, long long ldo,
                      int ncols, void *x_copy, long long ld_copy, void *stream);
+
+/* The same convolution with the residual add behind it (DSwinT_arch.py:373-374, out_layer(layers(x)) + x; :501) in its
+ * epilogue: out = resid + conv(x) + bias as fp32; resid rows ld_resid >= ncols floats apart, 16-byte aligned. */
+int dsw_conv3x3_nhwc_residual(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows,
+                              int ldw, const float *bias, int N, const float *resid, long long ld_resid, float *out,
+                              long long ldo, int ncols, void *stream);
 /* Its weight and bias gradient: dw[co][t][ci] = sum_px dy[px][co] x[px + off(t)][ci] (tap-major, fp32
  * [Co][9][Ci]), db[co] = sum_px dy[px][co]; dy, x bf16 in zero-padded rows as for dsw_linear_wgrad (x_copy
  * of the forward call has that form).  The input gradient is the same convolution applied to dy with the

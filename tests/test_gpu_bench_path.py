@@ -297,3 +297,46 @@ def test_nhwc_stem_and_reconstruction_tail_against_the_stock_convolutions(cuda0)
     assert y_new.shape == y_old.shape == g["y"].shape
     assert torch.isfinite(y_new).all()
     assert rel_err(y_new.float(), g["y"]) < 0.15 and rel_err(y_old.float(), g["y"]) < 0.15
+
+
+@pytest.mark.parametrize("gates_open", [True, False])
+def test_dsmsa_inference_residual_in_the_closing_convolution(cuda0, gates_open):
+    """DS-MSA called with residual=(stream, r) without autograd: stream + r * DS-MSA(x) with the residual taken in the
+    depthwise convolution's pass (dsw_dwconv3x3_residual_fwd), against the module's plain result and the residual
+    formed in fp32; with the gates shut the module returns its input (DSwinT_arch.py:291-292) and the sum is
+    stream + r * x."""
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    torch.manual_seed(3)
+    m = DeformableSparseWindowAttention(16, 180, 6).to(cuda0).eval()
+    with torch.no_grad():
+        m.sparse_discriminator[4].bias[1] += 4.0 if gates_open else -20.0
+    x = torch.randn(2, 64, 64, 180, device=cuda0)
+    stream = torch.randn_like(x)
+    r = torch.tensor([0.37], device=cuda0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y0 = m(x)
+        n_pass = int(m.last_selection.n_dev.item())
+        y1 = m(x, residual=(stream, r))
+    assert (n_pass > 0) == gates_open
+    assert y1.dtype == torch.float32 and y1.shape == x.shape
+    ref = stream + r * y0.float()
+    assert rel_err(y1, ref) < 5e-3     # y0 was rounded to bf16 on its way out, the fused sum is not
+    if not gates_open:
+        assert rel_err(y1, stream + r * x) < 1e-6
+
+
+def test_closing_convolution_with_the_skip_connection_in_its_epilogue(cuda0):
+    """LastChannelConv2D(x, residual=s) without autograd under bf16 autocast (dsw_conv3x3_nhwc_residual) against the
+    stock convolution in fp32 on the bf16-rounded operands plus s (DSwinT_arch.py:373-374)"""
+    from visiontransformer_amd import models
+    torch.manual_seed(9)
+    conv = models.LastChannelConv2D(180, 180, 3, 1, 1).to(cuda0)
+    x = torch.randn(2, 40, 56, 180, device=cuda0)
+    s = torch.randn_like(x)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(x, residual=s)
+    assert y.dtype == torch.float32
+    xr = x.to(torch.bfloat16).float().permute(0, 3, 1, 2)
+    with torch.no_grad():
+        ref = torch.nn.functional.conv2d(xr, conv.conv.weight.to(torch.bfloat16).float(), conv.conv.bias, padding=1).permute(0, 2, 3, 1) + s
+    assert rel_err(y, ref) < 1e-3

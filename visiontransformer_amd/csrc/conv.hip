@@ -42,10 +42,14 @@ __device__ __forceinline__ float4 fma4s(float4 a, float s, float4 c) {
 // load instruction of a wave is one contiguous run, a row is fetched (CW_ROWS + 2) / CW_ROWS times,
 // and the left / right neighbours come from the vector cache.  The 9 tap vectors stay in registers.
 constexpr int CW_ROWS = 8;
-template <typename TI, typename TO, bool FLIP>
+// RES (forward, fp32 result): y = resid + *rscale * conv(x), the ReZero residual of the caller's block
+// (DSwinT_arch.py:356) taken in the same pass.
+template <typename TI, typename TO, bool FLIP, bool RES = false>
 __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__restrict__ x, const float *__restrict__ wgt,
                                                                    const float *__restrict__ bias, int H, int W, int C,
-                                                                   int segs, TO *__restrict__ y, const int *__restrict__ identity_if_zero) {
+                                                                   int segs, TO *__restrict__ y, const int *__restrict__ identity_if_zero,
+                                                                   const float *__restrict__ resid = nullptr,
+                                                                   const float *__restrict__ rscale = nullptr) {
     // identity_if_zero: a device counter; when it holds 0 the kernel copies its input instead of convolving
     // (DS-MSA returns its input untouched when no window passed the gate, DSwinT_arch.py:291-292, and this
     // lets a caller that never reads the count on the host keep that behaviour)
@@ -83,11 +87,19 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
             r[2] = has_r ? io<TI>::ld4(pr + C) : f4zero();
         }
     };
+    float rsv = 1.f;
+    const float *res = nullptr;
+    if constexpr (RES) {
+        rsv = *rscale;
+        res = resid + (size_t)b * H * rs + (size_t)i * 4;
+    }
     load_row(h0 - 1, r0);
     load_row(h0, r1);
 #pragma unroll 2
     for (int h = h0; h < h1; ++h) {
         load_row(h + 1, r2);
+        float4 rv = f4zero();
+        if constexpr (RES) rv = *reinterpret_cast<const float4 *>(res + (size_t)h * rs);
         float4 acc = bq;
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb) {
@@ -95,7 +107,9 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
             acc = fma4(r1[bb], wq[3 + bb], acc);
             acc = fma4(r2[bb], wq[6 + bb], acc);
         }
-        io<TO>::st4(dst + (size_t)h * rs, ident ? r1[1] : acc);
+        float4 v = ident ? r1[1] : acc;
+        if constexpr (RES) v = rv + v * rsv;
+        io<TO>::st4(dst + (size_t)h * rs, v);
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb) r0[bb] = r1[bb], r1[bb] = r2[bb];
     }
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
 // weight / bias gradient partials: one block per DW_ROWS image rows.  Thread = (pixel part, channel
 // quad, tap row a): walking along an image row the three tap columns are a sliding window of x, so a
 // pixel costs one x load and one dy load.  The parts are summed through LDS in part order.
-constexpr int DW_ROWS = 4;
+constexpr int DW_ROWS = 2;
 constexpr int WG_THREADS = 448;  // 3 parts x (45 quads x 3 tap rows) at C = 180
 template <typename TG, typename TX>
 __global__ __launch_bounds__(WG_THREADS) void dwconv_wgrad_kernel(const TG *__restrict__ dy, const TX *__restrict__ x, int H,
@@ -717,6 +731,22 @@ extern "C" int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight
                            as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, (TO *)y, identity_if_zero);
     }));
     return check_launch("dwconv_stream_kernel");
+}
+
+extern "C" int dsw_dwconv3x3_residual_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
+                                          int C, const float *resid, const float *rscale, float *y, const int *identity_if_zero,
+                                          void *stream) {
+    int rc = check_conv("dsw_dwconv3x3_residual_fwd", B, H, W, C);
+    if (rc) return rc;
+    DSW_REQUIRE(x && weight && y && resid && rscale, "dsw_dwconv3x3_residual_fwd: null pointer");
+    if (((uintptr_t)resid | (uintptr_t)y) & 15) return fail(DSW_EUNSUPPORTED, "dsw_dwconv3x3_residual_fwd: resid and y must be 16-byte aligned");
+    const size_t lds = (size_t)C * 10 * sizeof(float);
+    const int segs = walk_segs(W, C);
+    DSW_DISPATCH_DTYPE(x_dtype, TI, {
+        hipLaunchKernelGGL((dwconv_stream_kernel<TI, float, false, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds,
+                           as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, y, identity_if_zero, resid, rscale);
+    });
+    return check_launch("dwconv_stream_kernel<residual>");
 }
 
 extern "C" int dsw_dwconv3x3_bwd_blocks(int B, int H, int W) {

@@ -720,9 +720,9 @@ extern "C" int dsw_linear_gated_silu(const void *a, int a_dtype, long long lda, 
                        stream, 1);
 }
 
-extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,
-                                const float *bias, int N, void *out, int out_dtype, long long ldo, int ncols, void *x_copy,
-                                long long ld_copy, void *stream) {
+static int conv3x3_impl(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,
+                        const float *bias, int N, void *out, int out_dtype, long long ldo, int ncols, void *x_copy,
+                        long long ld_copy, const float *resid, long long ld_resid, void *stream) {
     const long long M = (long long)B * H * W;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_conv3x3_nhwc: bad sizes B=%d H=%d W=%d C=%d ncols=%d", B, H, W, C, ncols);
@@ -747,13 +747,28 @@ extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B
     int rc = DSW_OK;
 #define DSW_CONV_KS(KSV)                                                                                                          \
     DSW_DISPATCH_DTYPE(x_dtype, TA, DSW_DISPATCH_DTYPE(out_dtype, TC, {                                                           \
-        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, nullptr, 0, nullptr, H, W, 0, nullptr, 0, st); \
+        rc = launch_linear<TA, TC, KSV>(x, ldx, (int)M, C, w_p, ldw, wrows, nslab, bias, N, out, ldo, ncols, x_copy, ld_copy, resid, ld_resid, nullptr, H, W, 0, nullptr, 0, st); \
     }))
     if (KS == 192) DSW_CONV_KS(192);
     else if (KS == 128) DSW_CONV_KS(128);
     else DSW_CONV_KS(64);
 #undef DSW_CONV_KS
     return rc;
+}
+
+extern "C" int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,
+                                const float *bias, int N, void *out, int out_dtype, long long ldo, int ncols, void *x_copy,
+                                long long ld_copy, void *stream) {
+    return conv3x3_impl(x, x_dtype, ldx, B, H, W, C, w_p, wrows, ldw, bias, N, out, out_dtype, ldo, ncols, x_copy, ld_copy, nullptr, 0, stream);
+}
+
+extern "C" int dsw_conv3x3_nhwc_residual(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows,
+                                         int ldw, const float *bias, int N, const float *resid, long long ld_resid, float *out,
+                                         long long ldo, int ncols, void *stream) {
+    DSW_REQUIRE(resid, "dsw_conv3x3_nhwc_residual: null pointer");
+    if (ld_resid < ncols || ld_resid % 4 || ((uintptr_t)resid & 15))
+        return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc_residual: the residual needs rows of >= %d floats, a multiple of 4, 16-byte aligned", ncols);
+    return conv3x3_impl(x, x_dtype, ldx, B, H, W, C, w_p, wrows, ldw, bias, N, out, DSW_F32, ldo, ncols, nullptr, 0, resid, ld_resid, stream);
 }
 
 static void wgrad_split(long long M, int Np, int Kp, int ntap, int *rows_per_block, int *S) {

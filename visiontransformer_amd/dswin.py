@@ -214,7 +214,17 @@ class DeformableSparseWindowAttention(WindowedAttention):
             return self.gumbel_noise.to(scores_flat.device)
         return -torch.empty_like(scores_flat, memory_format=torch.legacy_contiguous_format).exponential_().log()
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual = (stream, r), inference only: returns stream + r * attention(x) - the caller's ReZero residual
+        (DSwinT_arch.py:356) - taken inside the closing convolution's kernel where that is the last step."""
+        if residual is None:
+            return self._forward(x, None)
+        y = self._forward(x, residual)
+        if isinstance(y, tuple):     # (result, True): the residual is in already
+            return y[0]
+        return K.rezero_residual(residual[0], residual[1], y)
+
+    def _forward(self, x, residual):
         B, H, W, C = x.shape
         w = self.w
         x = K.supported_input(x).contiguous()
@@ -252,6 +262,11 @@ class DeformableSparseWindowAttention(WindowedAttention):
             after = K.linear(z, self.out_proj, pad_out=True, live=live)
             y = K.scatter_mean_residual(x, after, sel, w, sink=sink)
             # no window passed (DSwinT_arch.py:291-292: return x): the last kernel copies instead of convolving
+            if residual is not None:
+                out = K.dwconv3x3_residual_nhwc(y, self.out_conv.weight, self.out_conv.bias, residual[0], residual[1],
+                                                identity_if_zero=sel.n_dev)
+                if out is not None:
+                    return out, True
             return K.dwconv3x3_nhwc(y, self.out_conv.weight, self.out_conv.bias, out_dtype=act, identity_if_zero=sel.n_dev)
         sel = K.select_windows(sd, None, noise, self.temperature, k, w, H, W)  # sigmoids taken in the kernels
         self.last_selection = sel.detached()

@@ -683,6 +683,25 @@ def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None, identity_if_zero=None):
     return _run(_DWConvFn, x, weight, bias, out_dtype or x.dtype, identity_if_zero)
 
 
+def dwconv3x3_residual_nhwc(x, weight, bias, resid, r, identity_if_zero=None):
+    """resid + r * dwconv3x3(x) as fp32 in one kernel (dsw_dwconv3x3_residual_fwd): DS-MSA's closing convolution with
+    the ReZero residual of the block around it (DSwinT_arch.py:317 with :356).  Without autograd only; returns None
+    when the call is not one the kernel takes, and the caller then composes dwconv3x3_nhwc() and rezero_residual()."""
+    if torch.is_grad_enabled() or not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and resid.is_cuda
+                                       and resid.dtype == torch.float32 and resid.is_contiguous() and resid.shape == x.shape
+                                       and r.numel() == 1 and x.shape[-1] % 4 == 0 and resid.data_ptr() % 16 == 0):
+        return None
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    w32 = weight.detach().to(torch.float32).reshape(C, 9).contiguous()
+    b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    r32 = r.detach().float().reshape(1).contiguous()
+    y = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+    call("dsw_dwconv3x3_residual_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(resid), ptr(r32), ptr(y),
+         None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
+    return y
+
+
 class _SparseDiscFn(torch.autograd.Function):
     """The sparse discriminator.  fp32 runs: NHWC fp32 kernels for all three convolutions.  bf16 runs:
     the first convolution (C -> 4, 3x3: nearly all of the arithmetic and traffic) goes to the matrix
@@ -1568,6 +1587,24 @@ def conv3x3_nhwc_infer(x, conv, variant="plain", out_dtype=torch.bfloat16):
     w_p, b32, Co, Cin = _conv3x3_variant(conv, variant)
     out = torch.empty(B, H, W, Co, dtype=out_dtype, device=x.device)
     _conv3x3_call(x.view(B * H * W, Ci), B, H, W, Ci, w_p, b32, Co, out, None)
+    return out
+
+
+def conv3x3_nhwc_residual(x, conv, resid):
+    """Without autograd under bf16 autocast: resid + conv(x) as fp32 in one kernel (dsw_conv3x3_nhwc_residual), the
+    closing convolution of a residual block with the block's skip connection (DSwinT_arch.py:373-374, :501); None
+    when the call is not one the kernel takes."""
+    if torch.is_grad_enabled() or autocast_dtype(None) != torch.bfloat16 or not x.is_cuda:
+        return None
+    B, H, W, Ci = x.shape
+    if not (conv3x3_nhwc_infer_ok(x.shape, x.dtype, conv) and resid.is_cuda and resid.dtype == torch.float32 and resid.is_contiguous()
+            and resid.shape == (B, H, W, conv.out_channels) and resid.data_ptr() % 16 == 0):
+        return None
+    x = x.contiguous()
+    w_p, b32, Co, _ = _conv3x3_variant(conv, "plain")
+    out = torch.empty(B, H, W, Co, dtype=torch.float32, device=x.device)
+    call("dsw_conv3x3_nhwc_residual", _dptr(x), dtype_code(x.dtype), Ci, B, H, W, Ci, ptr(w_p), w_p.shape[0], w_p.shape[1],
+         None if b32 is None else ptr(b32), Co, ptr(resid), Co, ptr(out), Co, Co, stream(x.device))
     return out
 
 

@@ -27,7 +27,12 @@ class LastChannelConv2D(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, groups=groups)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual: a tensor to add to the result (the skip connection of the block this convolution closes);
+        without autograd the addition happens in the convolution's epilogue"""
+        if residual is not None:
+            y = K.conv3x3_nhwc_residual(x, self.conv, residual)
+            return y if y is not None else self.forward(x) + residual
         y = K.conv3x3_nhwc(x, self.conv)  # bf16 autocast: NHWC kernels (fwd and bwd), no layout copies
         if y is not None:
             return y
@@ -129,10 +134,10 @@ class DSWTViTBlock(nn.Module):
                 and isinstance(self.mlp1.act, nn.SiLU) and self.mlp1.drop.p == 0)
         for norm, rz, branch, proj in ((self.ln1, self.rezero1, self.wmsa, True), (self.ln3, self.rezero3, self.sdwa, False),
                                        (self.ln2, self.rezero2, self.mlp1, True)):
-            if fuse and proj:
-                # inference: the branch's closing projection adds the residual itself (no bf16 round trip of the
-                # branch, no residual pass)
-                x = branch(K.rms_norm(x, norm, for_projection=True), residual=(x, rz))
+            if fuse:
+                # inference: the branch's closing step (projection; DS-MSA's depthwise convolution) adds the residual
+                # itself (no bf16 round trip of the branch, no residual pass)
+                x = branch(K.rms_norm(x, norm, for_projection=proj), residual=(x, rz))
                 continue
             sink = K.prenorm_sink(x, norm, rz)
             b = branch(K.rms_norm(x, norm, for_projection=proj, sink=sink))
@@ -154,7 +159,7 @@ class DSWTResidualBlock(nn.Module):
         self.out_layer = LastChannelConv2D(dim, dim, 3, 1, 1)
 
     def forward(self, x):
-        return self.out_layer(self.layers(x)) + x
+        return self.out_layer(self.layers(x), residual=x)
 
 
 def _reconstruction_tail(dim, feature_dim, scale_factor, last_div):
@@ -299,7 +304,7 @@ class DSWTransformer(nn.Module):
                 x = x.float()
         else:
             x = xs
-        x = self.feature_transition(self.layers(x)) + x
+        x = self.feature_transition(self.layers(x), residual=x)
         steps = _tail_plan(self.img_reconstruction, x) if nhwc_ends else None
         if steps is not None:
             x = _tail_nhwc(self.img_reconstruction, x, steps)
