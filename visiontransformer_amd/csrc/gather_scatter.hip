@@ -140,98 +140,105 @@ __global__ __launch_bounds__(GS_THREADS) void gather_fwd_kernel(
 // dx(y,x) = sum over the sample positions (y',x') in {y-1,y} x {x-1,x} whose taps include (y,x) of
 //           weight * sum over windows covering (y',x') of dout[window, token(y',x')].
 // ACC: add into an existing dx (pixels no window touches are left alone) instead of writing all of it.
+//
+// The windows that can reach the tile are few (they start from the <= 3 x 4 grid cells around it at w = 16) and
+// the same for every thread of the block: they are looked up once (one thread per candidate cell, both rounds
+// of reads as groups), sorted by id into a list in LDS, and the streaming phase walks that list - a uniform loop -
+// with each thread testing its own four sample positions against the window's corner by arithmetic.  A tile no
+// window reaches is a plain zero fill (or nothing at all when accumulating).  The terms of a pixel are added
+// window by window in ascending id, sample positions (row, column) in order within a window.
+constexpr int GB_TILE = 32;   // pixels of one image row handled by a block of the gather backward
+constexpr int GB_MAXC = 128;  // candidate cells of a tile: <= 3 rows x (GB_TILE / w + 2) columns, w >= 1
 template <typename TG, typename TO, bool ACC>
 __global__ __launch_bounds__(GS_THREADS) void gather_bwd_kernel(
     const TG *__restrict__ dout, const int *__restrict__ cellmap, const int *__restrict__ win_h1,
     const int *__restrict__ win_w1, int H, int W, int C, int w, int ldg, int tiles_per_row, TO *__restrict__ dx) {
-    __shared__ Cover cov[2][TILE_PIX + 1];
+    __shared__ int cand_id[GB_MAXC];
+    __shared__ int wl_id[GB_MAXC], wl_h1[GB_MAXC], wl_w1[GB_MAXC];
     const int Hw = H / w, Ww = W / w;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
     // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
     const int trow = __builtin_amdgcn_readfirstlane(bid / tiles_per_row), tile = bid - trow * tiles_per_row;
     const int b = __builtin_amdgcn_readfirstlane(trow / H), y = trow - b * H;
-    const int x0 = tile * TILE_PIX;
-    const int npix = min(TILE_PIX, W - x0);
-    int many = 0;
-    for (int t = threadIdx.x; t < 2 * (TILE_PIX + 1); t += GS_THREADS) {
-        const int row = t / (TILE_PIX + 1), col = t - row * (TILE_PIX + 1);
-        const int yy = y - 1 + row, xx = x0 - 1 + col;
-        Cover cv;
-        cv.n = 0;
-        if (yy >= 0 && xx >= 0 && xx < W) cv = find_cover(cellmap, win_h1, win_w1, b, yy, xx, Hw, Ww, w);
-        cov[row][col] = cv;
-        many |= cv.n > 1;
-    }
-    const int overlap = __syncthreads_or(many);  // some sample position of the tile lies in two or more windows
-    const int CV = C >> 2, L = w * w, total = npix * CV;
-    const float wy_self = (y < H - 1) ? 0.5f : 1.0f;
-    TO *drow = dx + (((size_t)b * H + y) * W + x0) * C;
-    // A thread takes GB_U items (pixel, 4 channels) per trip and asks for everything they need before it uses
-    // any of it: the first covering window's row of each of the 4 sample positions, the second one's where the
-    // tile has overlapping windows at all, and the destination when accumulating - one memory latency per trip
-    // instead of one per load.  A slot with no window reads row 0 of dout (a valid address: some window exists
-    // when any position is covered) and is not added; third and fourth covering windows are fetched one by one
-    // afterwards.  The sums run in the order (row, col), then window id ascending.
-    constexpr int GB_U = 1;
-    for (int base = threadIdx.x; base < total; base += GB_U * GS_THREADS) {
-        float4 v[GB_U][4], v2[GB_U][4], old[GB_U];
-        int pp[GB_U], cc[GB_U], cnt[GB_U][4];
-#pragma unroll
-        for (int u = 0; u < GB_U; ++u) {
-            const int it = min(base + u * GS_THREADS, total - 1);  // past the end: a valid item, dropped below
-            const int p = it / CV, c = (it - p * CV) << 2;
-            pp[u] = p;
-            cc[u] = c;
-            int any = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                cnt[u][q] = cov[q >> 1][p + (q & 1)].n;
-                any |= cnt[u][q];
-            }
-            if (any) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const Cover &cv = cov[q >> 1][p + (q & 1)];
-                    const size_t row = cnt[u][q] > 0 ? (size_t)cv.id[0] * L + cv.tok[0] : 0;
-                    v[u][q] = io<TG>::ld4(dout + row * ldg + c);
-                }
-                if (overlap) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const Cover &cv = cov[q >> 1][p + (q & 1)];
-                        const size_t row = cnt[u][q] > 1 ? (size_t)cv.id[1] * L + cv.tok[1] : 0;
-                        v2[u][q] = io<TG>::ld4(dout + row * ldg + c);
-                    }
-                }
-                if constexpr (ACC) old[u] = io<TO>::ld4(drow + (size_t)p * C + c);
+    const int x0 = tile * GB_TILE;
+    const int npix = min(GB_TILE, W - x0);
+    // candidate cells: a window that covers sample position (yy, xx) starts from cell row r_hi(yy) - 1 or r_hi(yy),
+    // r_hi(v) = min((v + w/2) / w, Hw - 1), and likewise per column
+    const int hw2 = w >> 1;
+    const int rmin = max(min((max(y - 1, 0) + hw2) / w, Hw - 1) - 1, 0), rmax = min((y + hw2) / w, Hw - 1);
+    const int cmin = max(min((max(x0 - 1, 0) + hw2) / w, Ww - 1) - 1, 0), cmax = min((x0 + npix - 1 + hw2) / w, Ww - 1);
+    const int ncols = cmax - cmin + 1, ncell = (rmax - rmin + 1) * ncols;  // <= GB_MAXC
+    int my_id = 0x7fffffff, my_h1 = 0, my_w1 = 0;
+    if ((int)threadIdx.x < ncell) {
+        const int r = rmin + (int)threadIdx.x / ncols, c = cmin + (int)threadIdx.x % ncols;
+        const int id = cellmap[((size_t)b * Hw + r) * Ww + c];
+        if (id >= 0) {
+            const int h1 = win_h1[id], w1 = win_w1[id];
+            // reaches the tile: a sample row among {y-1, y} and a sample column among x0-1 .. x0+npix-1 inside it
+            if (h1 <= y && y <= h1 + w && w1 <= x0 + npix - 1 && x0 - 1 < w1 + w) {
+                my_id = id;
+                my_h1 = h1;
+                my_w1 = w1;
             }
         }
-#pragma unroll
-        for (int u = 0; u < GB_U; ++u) {
-            if (base + u * GS_THREADS >= total) break;
-            const int p = pp[u], c = cc[u];
-            const float wx_self = (x0 + p < W - 1) ? 0.5f : 1.0f;
-            float4 acc = f4zero();
-            int touched = 0;
+    }
+    if (threadIdx.x < GB_MAXC) cand_id[threadIdx.x] = my_id;
+    const int nwin = __syncthreads_count(my_id != 0x7fffffff);
+    const int CV = C >> 2, L = w * w, total = npix * CV;
+    TO *drow = dx + (((size_t)b * H + y) * W + x0) * C;
+    if (nwin == 0) {  // uniform
+        if constexpr (!ACC) {
+            for (int i = threadIdx.x; i < total; i += GS_THREADS) io<TO>::st4(drow + (size_t)i * 4, f4zero());
+        }
+        return;
+    }
+    if (my_id != 0x7fffffff) {  // position in the ascending list = number of smaller ids (ids are distinct)
+        int rank = 0;
+        for (int u = 0; u < ncell; ++u) rank += cand_id[u] < my_id;
+        wl_id[rank] = my_id;
+        wl_h1[rank] = my_h1;
+        wl_w1[rank] = my_w1;
+    }
+    __syncthreads();
+    const float wy_self = (y < H - 1) ? 0.5f : 1.0f;
+    for (int it = threadIdx.x; it < total; it += GS_THREADS) {
+        const int p = it / CV, c = (it - p * CV) << 2;
+        const int x = x0 + p;
+        const float wx_self = (x < W - 1) ? 0.5f : 1.0f;
+        float4 acc = f4zero();
+        bool touched = false;
+        float4 old = f4zero();
+        if constexpr (ACC) {
+            // whether any listed window holds one of this pixel's sample positions: decides the read of dx up front
+            for (int k = 0; k < nwin; ++k) {
+                const int ly = y - wl_h1[k], lx = x - wl_w1[k];
+                touched |= ly >= 0 && ly <= w && lx >= 0 && lx <= w;
+            }
+            if (touched) old = io<TO>::ld4(drow + (size_t)p * C + c);
+        }
+        for (int k = 0; k < nwin; ++k) {
+            const int ly1 = y - wl_h1[k], lx1 = x - wl_w1[k];  // sample position (y, x) inside the window; (y-1, x-1) is one less
+            if (ly1 < 0 || ly1 > w || lx1 < 0 || lx1 > w) continue;
+            const TG *wbase = dout + (size_t)wl_id[k] * L * ldg + c;
+            float4 v[4];
+            bool ok[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = cnt[u][q];
+                const int ly = ly1 - 1 + (q >> 1), lx = lx1 - 1 + (q & 1);
+                ok[q] = ly >= 0 && ly < w && lx >= 0 && lx < w;
+                v[q] = io<TG>::ld4(wbase + (size_t)(ok[q] ? ly * w + lx : 0) * ldg);  // token 0 of the window when outside: not added
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
                 const float wt = ((q >> 1) ? wy_self : 0.5f) * ((q & 1) ? wx_self : 0.5f);
-                touched += n;
-                if (n > 0) acc = acc + v[u][q] * wt;
-                if (n > 1) acc = acc + v2[u][q] * wt;
-                if (n > 2) {
-                    const Cover &cv = cov[q >> 1][p + (q & 1)];
-                    for (int s = 2; s < n; ++s)
-                        acc = acc + io<TG>::ld4(dout + ((size_t)cv.id[s] * L + cv.tok[s]) * ldg + c) * wt;
-                }
+                if (ok[q]) acc = acc + v[q] * wt;
             }
-            TO *dst = drow + (size_t)p * C + c;
-            if constexpr (ACC) {
-                if (touched) io<TO>::st4(dst, old[u] + acc);
-            } else {
-                io<TO>::st4(dst, acc);
-            }
+        }
+        TO *dst = drow + (size_t)p * C + c;
+        if constexpr (ACC) {
+            if (touched) io<TO>::st4(dst, old + acc);
+        } else {
+            io<TO>::st4(dst, acc);
         }
     }
 }
@@ -491,7 +498,7 @@ extern "C" int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellm
     rc = check_ld("dsw_gather_bwd", ld_dout, C);
     if (rc) return rc;
     DSW_REQUIRE(cellmap && dx && (n_win == 0 || (dout && win_h1 && win_w1)), "dsw_gather_bwd: null pointer");
-    const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
+    const int tiles = (W + GB_TILE - 1) / GB_TILE;
     DSW_DISPATCH_DTYPE(dout_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
         if (accumulate)
             hipLaunchKernelGGL((gather_bwd_kernel<TG, TO, true>), dim3(B * H * tiles), dim3(GS_THREADS), 0, as_stream(stream),
