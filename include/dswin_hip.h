@@ -461,6 +461,8 @@ int dsw_gelu_bwd(const void *dy, long long ld_dy, const void *x, int dtype, long
  * on the weight rows - and y [B][2H][2W][c] = gelu(erf form) of the shuffled tensor.  One dtype (fp32 or bf16); c is a
  * multiple of 4, both tensors dense. */
 int dsw_shuffle2_gelu_nhwc(const void *x, int dtype, int B, int H, int W, int c, void *y, void *stream);
+/* its backward: dx [B][H][W][4c] from dy [B][2H][2W][c] and the forward's input x (same dtype for all three) */
+int dsw_shuffle2_gelu_nhwc_bwd(const void *dy, const void *x, int dtype, int B, int H, int W, int c, void *dx, void *stream);
 
 /* The ReZero residual of the reference's ViTBlock (DSwinT_arch.py:355-357), y = x + r * branch, in one
  * pass: x, y fp32 [M][C]; branch fp32 or bf16 with row stride ldb; r one fp32 value on the device.

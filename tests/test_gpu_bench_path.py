@@ -340,3 +340,33 @@ def test_closing_convolution_with_the_skip_connection_in_its_epilogue(cuda0):
     with torch.no_grad():
         ref = torch.nn.functional.conv2d(xr, conv.conv.weight.to(torch.bfloat16).float(), conv.conv.bias, padding=1).permute(0, 2, 3, 1) + s
     assert rel_err(y, ref) < 1e-3
+
+
+def test_nhwc_reconstruction_tail_gradients_against_the_stock_convolutions(cuda0):
+    """Training under bf16 autocast: the reconstruction tail on the NHWC kernels (convolutions with re-ordered / padded
+    weights inside autograd, dsw_shuffle2_gelu_nhwc and its backward) against the stock NCHW modules: output, input
+    gradient and every parameter gradient.  Both sides round to bf16 between layers, at different points."""
+    from visiontransformer_amd import models
+    torch.manual_seed(11)
+    tail = models._reconstruction_tail(180, 64, 4, last_div=4).to(cuda0)
+    s0 = torch.randn(2, 16, 24, 180, device=cuda0)
+    dy = torch.randn(2, 3, 64, 96, device=cuda0)
+    outs = []
+    for nhwc in (True, False):
+        s = s0.clone().requires_grad_()
+        tail.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if nhwc:
+                steps = models._tail_plan(tail, s)
+                assert steps is not None
+                y = models._tail_nhwc(tail, s, steps)
+            else:
+                y = tail(s.permute(0, 3, 1, 2).contiguous())
+        (y.float() * dy).sum().backward()
+        outs.append((y.detach().float(), s.grad.clone(), {n: p.grad.clone() for n, p in tail.named_parameters()}))
+    (y1, dx1, g1), (y0, dx0, g0) = outs
+    assert rel_err(y1, y0) < BF16_TOL
+    assert rel_err(dx1, dx0) < 3e-2
+    for n in g0:
+        assert g1[n].shape == g0[n].shape
+        assert rel_err(g1[n], g0[n]) < 3e-2, n

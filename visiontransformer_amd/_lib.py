@@ -65,6 +65,7 @@ SIGNATURES = {
     "dsw_gated_silu_bwd": (_I, [_P, _I, ctypes.c_longlong, _P, _I, ctypes.c_longlong, _I, ctypes.c_longlong, _P, _P]),
     "dsw_gelu_fwd": (_I, [_P, _I, ctypes.c_longlong, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P]),
     "dsw_shuffle2_gelu_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "dsw_shuffle2_gelu_nhwc_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "dsw_gelu_bwd": (_I, [_P, ctypes.c_longlong, _P, _I, ctypes.c_longlong, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P]),
     "dsw_rezero_blocks": (_I, [ctypes.c_longlong, ctypes.c_longlong]),
     "dsw_rezero_fwd": (_I, [_P, _P, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _I, _P, _P]),

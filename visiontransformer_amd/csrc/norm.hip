@@ -338,6 +338,41 @@ __global__ __launch_bounds__(256) void shuffle2_gelu_kernel(const T *__restrict_
 }  // namespace
 }  // namespace dsw
 
+namespace dsw {
+namespace {
+// backward of the stage above: dx[b][h][w][(2 r1 + r2) c + j] = dy[b][2h + r1][2w + r2][j] * gelu'(x[...]); the item
+// index runs over dy / y, as in the forward
+template <typename T>
+__global__ __launch_bounds__(256) void shuffle2_gelu_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ x, int H, int W, int c,
+                                                                long long items, T *__restrict__ dx) {
+    const int cq = c >> 2;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int j = (int)(it % cq);
+        long long t = it / cq;
+        const int ow = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int oh = (int)(t % (2 * H));
+        const long long b = t / (2 * H);
+        const long long src = ((((b * H + (oh >> 1)) * W + (ow >> 1)) * 4 + (oh & 1) * 2 + (ow & 1)) * (long long)c) + 4 * j;
+        const float4 v = io<T>::ld4(x + src), g = io<T>::ld4(dy + it * 4);
+        io<T>::st4(dx + src, make_float4(g.x * gelu_slope(v.x), g.y * gelu_slope(v.y), g.z * gelu_slope(v.z), g.w * gelu_slope(v.w)));
+    }
+}
+}  // namespace
+}  // namespace dsw
+
+extern "C" int dsw_shuffle2_gelu_nhwc_bwd(const void *dy, const void *x, int dtype, int B, int H, int W, int c, void *dx, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || c <= 0) return fail(DSW_EINVAL, "dsw_shuffle2_gelu_nhwc_bwd: bad sizes B=%d H=%d W=%d c=%d", B, H, W, c);
+    if (c % 4) return fail(DSW_EUNSUPPORTED, "dsw_shuffle2_gelu_nhwc_bwd: c=%d must be a multiple of 4", c);
+    DSW_REQUIRE(dy && x && dx, "dsw_shuffle2_gelu_nhwc_bwd: null pointer");
+    const long long items = (long long)B * H * W * c;
+    DSW_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL(shuffle2_gelu_bwd_kernel<T>, dim3(gs_blocks(items)), dim3(256), 0, as_stream(stream), (const T *)dy, (const T *)x, H, W, c,
+                           items, (T *)dx);
+    });
+    return check_launch("shuffle2_gelu_bwd_kernel");
+}
+
 extern "C" int dsw_shuffle2_gelu_nhwc(const void *x, int dtype, int B, int H, int W, int c, void *y, void *stream) {
     if (B <= 0 || H <= 0 || W <= 0 || c <= 0) return fail(DSW_EINVAL, "dsw_shuffle2_gelu_nhwc: bad sizes B=%d H=%d W=%d c=%d", B, H, W, c);
     if (c % 4) return fail(DSW_EUNSUPPORTED, "dsw_shuffle2_gelu_nhwc: c=%d must be a multiple of 4", c);

@@ -1608,14 +1608,51 @@ def conv3x3_nhwc_residual(x, conv, resid):
     return out
 
 
+class _Shuffle2GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C4 = x.shape
+        x = x.contiguous()
+        y = torch.empty(B, 2 * H, 2 * W, C4 // 4, dtype=x.dtype, device=x.device)
+        call("dsw_shuffle2_gelu_nhwc", ptr(x), dtype_code(x.dtype), B, H, W, C4 // 4, ptr(y), stream(x.device))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        B, H, W, C4 = x.shape
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        call("dsw_shuffle2_gelu_nhwc_bwd", ptr(dy), ptr(x), dtype_code(x.dtype), B, H, W, C4 // 4, ptr(dx), stream(x.device))
+        return dx
+
+
 def shuffle2_gelu_nhwc(x):
     """nn.PixelShuffle(2) followed by nn.GELU() on an NHWC tensor whose channels are ordered (r1, r2, channel):
-    [B, H, W, 4c] -> [B, 2H, 2W, c] (dsw_shuffle2_gelu_nhwc)"""
-    B, H, W, C4 = x.shape
-    x = x.contiguous()
-    y = torch.empty(B, 2 * H, 2 * W, C4 // 4, dtype=x.dtype, device=x.device)
-    call("dsw_shuffle2_gelu_nhwc", ptr(x), dtype_code(x.dtype), B, H, W, C4 // 4, ptr(y), stream(x.device))
-    return y
+    [B, H, W, 4c] -> [B, 2H, 2W, c] (dsw_shuffle2_gelu_nhwc and its backward)"""
+    return _run(_Shuffle2GeluFn, x)
+
+
+def conv3x3_nhwc_variant(x, conv, variant="plain"):
+    """`conv` (3x3, stride 1, padding 1) applied to the NHWC tensor x [B, H, W, Ci] under bf16 autocast with its
+    parameters transformed as `variant` says (see _conv3x3_variant), with or without autograd: without, the kept
+    operands of conv3x3_nhwc_infer; with, the transformation is done by differentiable torch ops on the parameters
+    and the convolution by the NHWC kernels' autograd function, so the gradients land on `conv`'s own parameters."""
+    if not torch.is_grad_enabled():
+        return conv3x3_nhwc_infer(x, conv, variant)
+    weight, bias = conv.weight, conv.bias
+    if variant == "shuffle2":
+        Co = weight.shape[0]
+        weight = weight.view(Co // 4, 4, *weight.shape[1:]).transpose(0, 1).reshape(Co, *weight.shape[1:])
+        bias = None if bias is None else bias.view(Co // 4, 4).t().reshape(Co)
+    elif variant == "pad_in4":
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, -weight.shape[1] % 4))
+    elif variant == "pad_out4":
+        extra = -weight.shape[0] % 4
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, extra))
+        bias = None if bias is None else torch.nn.functional.pad(bias, (0, extra))
+    return _Conv3x3Fn.apply(x.contiguous(), weight, bias, torch.bfloat16)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -172,7 +172,7 @@ def _reconstruction_tail(dim, feature_dim, scale_factor, last_div):
 
 
 def _tail_plan(seq, x):
-    """How the reconstruction tail runs on an NHWC tensor without autograd: a list of steps, or None when some
+    """How the reconstruction tail runs on an NHWC tensor: a list of steps, or None when some
     module or size is not one the NHWC kernels take."""
     mods, steps, i = list(seq), [], 0
     B, H, W, C = x.shape
@@ -200,13 +200,13 @@ def _tail_plan(seq, x):
 
 
 def _tail_nhwc(seq, x, steps):
-    """The reconstruction tail (DSwinT_arch.py:426-437) on the NHWC stream without autograd: every convolution on the
+    """The reconstruction tail (DSwinT_arch.py:426-437) on the NHWC stream, with or without autograd: every convolution on the
     matrix cores through the NHWC kernel, PixelShuffle as the addressing of the GELU pass that follows it (the
     convolution before it emits its channels in sub-pixel order), no NCHW copy before the last step.  Returns NCHW."""
     y = x
     for kind, m, variant in steps:
         if kind == "conv":
-            y = K.conv3x3_nhwc_infer(y, m, variant)
+            y = K.conv3x3_nhwc_variant(y, m, variant)
         elif kind == "shuffle_gelu":
             y = K.shuffle2_gelu_nhwc(y)
         else:
@@ -284,16 +284,20 @@ class DSWTransformer(nn.Module):
         x = self.padding(x)
         # Without autograd under bf16 autocast the stem and the reconstruction tail stay on NHWC tensors and on the
         # package's convolution kernel (NHWC_ENDS): no NCHW <-> NHWC copies around them, the stem writes the fp32
-        # stream directly (3 input channels padded to 4), the tail never materialises an NCHW tensor.
-        nhwc_ends = (NHWC_ENDS and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+        # stream directly (3 input channels padded to 4), the tail never materialises an NCHW tensor.  With autograd
+        # the same path works (NHWC_ENDS_TRAINING) but is off: the weight-gradient kernel, built for 192-wide blocks,
+        # is slower than MIOpen on the tail's 16- to 64-channel layers (training step 65.4 -> 69.6 ms with it on).
+        nhwc_ends = (NHWC_ENDS and (NHWC_ENDS_TRAINING or not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
                      and K.autocast_dtype(x.dtype) == torch.bfloat16)
         xs = None
         if nhwc_ends:
             xs = F.pad(x.permute(0, 2, 3, 1), (0, -x.shape[1] % 4))
-            if K.conv3x3_nhwc_infer_ok(xs.shape, xs.dtype, self.feature_extractor, "pad_in4"):
-                xs = K.conv3x3_nhwc_infer(xs, self.feature_extractor, "pad_in4", out_dtype=torch.float32)
-            else:
+            if not K.conv3x3_nhwc_infer_ok(xs.shape, xs.dtype, self.feature_extractor, "pad_in4"):
                 xs = None
+            elif torch.is_grad_enabled():
+                xs = K.conv3x3_nhwc_variant(xs, self.feature_extractor, "pad_in4").float()
+            else:
+                xs = K.conv3x3_nhwc_infer(xs, self.feature_extractor, "pad_in4", out_dtype=torch.float32)
         if xs is None:
             x = self.feature_extractor(x)
             x = x.permute(0, 2, 3, 1).contiguous()
@@ -317,6 +321,7 @@ class DSWTransformer(nn.Module):
 # MSFT
 # ------------------------------------------------------------------------------------------------
 NHWC_ENDS = True     # False: DSWTransformer's stem and reconstruction tail always run as stock NCHW convolutions
+NHWC_ENDS_TRAINING = False   # True: the NHWC ends with autograd as well (see DSWTransformer.forward)
 NHWC_STREAM = True   # False: MSFTransformer runs its trunk module by module on NCHW tensors, as the reference does
 
 
