@@ -74,18 +74,29 @@ __global__ __launch_bounds__((FwdCfg<T, WS, DP>::THREADS), (FwdCfg<T, WS, DP>::M
             constexpr int DW = DP / 2, RS = THREADS / DW, ITER = L / RS, BATCH = ITER < 8 ? ITER : 8;
             const int r0 = tid / DW, e = (tid - r0 * DW) * 2;
             const bool ok = e < d;
-            const T *src0 = qkv + origin * C3 + min(e, d - 2);  // clamped: padding lanes re-read a valid pair
+            // a wave-uniform 64-bit base and 32-bit lane offsets (the rows of a window span at most WS image rows):
+            // the address arithmetic of a load is one 32-bit add instead of a 64-bit multiply-add
+            const T *src0 = qkv + origin * C3;
+            const unsigned ecol = (unsigned)min(e, d - 2);  // clamped: padding lanes re-read a valid pair
+            static_assert(RS % WS == 0 || WS % RS == 0, "a sweep is a whole number of window rows or a part of one");
+            const unsigned rel0 = ((unsigned)(r0 / WS) * pitch + (unsigned)(r0 % WS)) * C3 + ecol;
+            const unsigned step = RS >= WS ? (unsigned)(RS / WS) * pitch * C3 : 0u;
             T *qdst = Qs + r0 * QS + e, *kdst = Ks + r0 * QS + e, *vdst = Vt + r0 * QS + e;
             const uint32_t vpad = e == d ? 0x3f80u : 0u;  // bf16 1.0 in the low half
             for (int i0 = 0; i0 < ITER; i0 += BATCH) {
                 uint32_t qv[BATCH], kv[BATCH], vv[BATCH];
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
-                    const int tok = (i0 + i) * RS + r0;
-                    const T *src = src0 + ((size_t)(tok / WS) * pitch + (tok % WS)) * C3;
-                    qv[i] = *reinterpret_cast<const uint32_t *>(src + qoff);
-                    kv[i] = *reinterpret_cast<const uint32_t *>(src + koff);
-                    vv[i] = *reinterpret_cast<const uint32_t *>(src + voff);
+                    unsigned rel;
+                    if constexpr (RS >= WS) {
+                        rel = rel0 + (unsigned)(i0 + i) * step;
+                    } else {
+                        const int tok = (i0 + i) * RS + r0;
+                        rel = ((unsigned)(tok / WS) * pitch + (unsigned)(tok % WS)) * C3 + ecol;
+                    }
+                    qv[i] = *reinterpret_cast<const uint32_t *>(src0 + (rel + qoff));
+                    kv[i] = *reinterpret_cast<const uint32_t *>(src0 + (rel + koff));
+                    vv[i] = *reinterpret_cast<const uint32_t *>(src0 + (rel + voff));
                 }
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {

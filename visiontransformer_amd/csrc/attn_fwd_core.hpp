@@ -320,12 +320,14 @@ __device__ __forceinline__ void win_attn_fwd_core(const AttnGeom &g, T *Qs, T *K
                 // a wave's LDS accesses complete in order, and only this wave touches these rows
                 constexpr int DWR = DP / 2, RPI = 64 / DWR;  // dwords per row, rows per store instruction
                 const int dw = lane % DWR, rsub = lane / DWR;
+                // a wave-uniform 64-bit base and 32-bit lane offsets (a window spans at most WS image rows)
+                T *obase = out + origin * C + head * d;
 #pragma unroll
                 for (int i = 0; i < 32 / RPI; ++i) {
                     const int qq = qb * 32 + i * RPI + rsub;
                     const uint32_t v = *reinterpret_cast<const uint32_t *>(Qs + qq * QS + 2 * dw);
-                    if (2 * dw < d)
-                        *reinterpret_cast<uint32_t *>(out + (origin + (size_t)(qq / WS) * pitch + (qq % WS)) * C + head * d + 2 * dw) = v;
+                    const unsigned off = ((unsigned)(qq / WS) * pitch + (unsigned)(qq % WS)) * C + 2 * dw;
+                    if (2 * dw < d) *reinterpret_cast<uint32_t *>(obase + off) = v;
                 }
             }
         }
