@@ -54,23 +54,30 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
     // (DS-MSA returns its input untouched when no window passed the gate, DSwinT_arch.py:291-292, and this
     // lets a caller that never reads the count on the host keep that behaviour)
     const bool ident = identity_if_zero != nullptr && *identity_if_zero == 0;
-    extern __shared__ __attribute__((aligned(16))) float ws[];  // [9][C] + [C]
-    for (int i = threadIdx.x; i < C * 9; i += CV_THREADS) {
-        const int c = i / 9, t = i - c * 9;
-        ws[(FLIP ? 8 - t : t) * C + c] = wgt[i];
-    }
-    for (int i = threadIdx.x; i < C; i += CV_THREADS) ws[9 * C + i] = (bias != nullptr && !FLIP) ? bias[i] : 0.f;
-    __syncthreads();
     const int CV = C >> 2, rowq = W * CV, hblocks = (H + CW_ROWS - 1) / CW_ROWS;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: the halo rows of vertical neighbours are L2 hits
-    const int seg = bid % segs, hb = (bid / segs) % hblocks, b = bid / (segs * hblocks);
+    // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
+    const int bh = __builtin_amdgcn_readfirstlane(bid / segs), seg = bid - bh * segs;
+    const int b = __builtin_amdgcn_readfirstlane(bh / hblocks), hb = bh - b * hblocks;
     const int i = seg * CV_THREADS + threadIdx.x;
     if (i >= rowq) return;
     const int xx = i / CV, c = (i - xx * CV) << 2;
+    // The 9 taps of the thread's four channels are 36 consecutive floats of the [C][9] weight (144 bytes, 16-byte
+    // aligned): nine 16-byte loads straight into registers and a transposition by register naming - no LDS copy of the
+    // weight, no barrier in front of the stream.
+    float wr[36];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(wgt + (size_t)c * 9 + 4 * q);
+        wr[4 * q] = v.x, wr[4 * q + 1] = v.y, wr[4 * q + 2] = v.z, wr[4 * q + 3] = v.w;
+    }
     float4 wq[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const float4 *>(ws + t * C + c);
-    const float4 bq = *reinterpret_cast<const float4 *>(ws + 9 * C + c);
+    for (int t = 0; t < 9; ++t) {
+        const int tt = FLIP ? 8 - t : t;
+        wq[t] = make_float4(wr[tt], wr[9 + tt], wr[18 + tt], wr[27 + tt]);
+    }
+    const float4 bq = (bias != nullptr && !FLIP) ? *reinterpret_cast<const float4 *>(bias + c) : f4zero();
     const size_t rs = (size_t)W * C;
     const TI *src = x + (size_t)b * H * rs + (size_t)i * 4;
     TO *dst = y + (size_t)b * H * rs + (size_t)i * 4;
@@ -653,6 +660,13 @@ __global__ void copy2_kernel(const float *__restrict__ packed, int n0, int n1, f
     else if (i < n0 + n1) b[i - n0] = packed[i];
 }
 
+// the depthwise kernels read the [C][9] weight and the bias 16 bytes at a time
+static int check_conv_params(const char *who, const float *weight, const float *bias) {
+    if (((uintptr_t)weight & 15) || (bias != nullptr && ((uintptr_t)bias & 15)))
+        return fail(DSW_EUNSUPPORTED, "%s: weight and bias must be 16-byte aligned", who);
+    return DSW_OK;
+}
+
 static int check_conv(const char *who, int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(DSW_EINVAL, "%s: bad sizes B=%d H=%d W=%d C=%d", who, B, H, W, C);
     if (C % 4) return fail(DSW_EUNSUPPORTED, "%s: channel count %d must be a multiple of 4", who, C);
@@ -724,10 +738,10 @@ extern "C" int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight
     int rc = check_conv("dsw_dwconv3x3_fwd", B, H, W, C);
     if (rc) return rc;
     DSW_REQUIRE(x && weight && y, "dsw_dwconv3x3_fwd: null pointer");
-    const size_t lds = (size_t)C * 10 * sizeof(float);
+    if ((rc = check_conv_params("dsw_dwconv3x3_fwd", weight, bias))) return rc;
     const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(x_dtype, TI, DSW_DISPATCH_DTYPE(y_dtype, TO, {
-        hipLaunchKernelGGL((dwconv_stream_kernel<TI, TO, false>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds,
+        hipLaunchKernelGGL((dwconv_stream_kernel<TI, TO, false>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), 0,
                            as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, (TO *)y, identity_if_zero);
     }));
     return check_launch("dwconv_stream_kernel");
@@ -740,10 +754,10 @@ extern "C" int dsw_dwconv3x3_residual_fwd(const void *x, int x_dtype, const floa
     if (rc) return rc;
     DSW_REQUIRE(x && weight && y && resid && rscale, "dsw_dwconv3x3_residual_fwd: null pointer");
     if (((uintptr_t)resid | (uintptr_t)y) & 15) return fail(DSW_EUNSUPPORTED, "dsw_dwconv3x3_residual_fwd: resid and y must be 16-byte aligned");
-    const size_t lds = (size_t)C * 10 * sizeof(float);
+    if ((rc = check_conv_params("dsw_dwconv3x3_residual_fwd", weight, bias))) return rc;
     const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(x_dtype, TI, {
-        hipLaunchKernelGGL((dwconv_stream_kernel<TI, float, false, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds,
+        hipLaunchKernelGGL((dwconv_stream_kernel<TI, float, false, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), 0,
                            as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, y, identity_if_zero, resid, rscale);
     });
     return check_launch("dwconv_stream_kernel<residual>");
@@ -761,10 +775,10 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
     if (rc) return rc;
     DSW_REQUIRE(dy && x && weight && dx && d_weight && d_bias && partial, "dsw_dwconv3x3_bwd: null pointer");
     hipStream_t st = as_stream(stream);
-    const size_t lds = (size_t)C * 10 * sizeof(float);
+    if ((rc = check_conv_params("dsw_dwconv3x3_bwd", weight, nullptr))) return rc;
     const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
-        hipLaunchKernelGGL((dwconv_stream_kernel<TG, TO, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), lds, st,
+        hipLaunchKernelGGL((dwconv_stream_kernel<TG, TO, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), 0, st,
                            (const TG *)dy, weight, (const float *)nullptr, H, W, C, segs, (TO *)dx, identity_if_zero);
     }));
     rc = check_launch("dwconv_stream_kernel<flip>");
