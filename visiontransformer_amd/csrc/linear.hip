@@ -468,8 +468,11 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_wgrad_kernel(const bf1
     const unsigned x_off = (unsigned)(((size_t)xrow * ldx + k0 + xpc * 8) * sizeof(bf16_t));
     const unsigned y_step = (unsigned)(Cfg::YROWS * ldy * sizeof(bf16_t)), x_step = (unsigned)(Cfg::XROWS * ldx * sizeof(bf16_t));
 
-    uint4 yr[Cfg::YN], xr[Cfg::XN];
-    auto load_stage = [&](int st) {
+    // two stages of both operands are in flight in registers (a CU needs ~40 KB on the way to keep its share of the
+    // HBM stream going, and one stage of one workgroup is 49 KB at best): stage st + 2 is requested as soon as stage
+    // st has gone to LDS
+    uint4 yrA[Cfg::YN], xrA[Cfg::XN], yrB[Cfg::YN], xrB[Cfg::XN];
+    auto load_stage = [&](int st, uint4 (&yr)[Cfg::YN], uint4 (&xr)[Cfg::XN]) {
         const unsigned ys = (unsigned)((size_t)st * WG_BM * ldy * sizeof(bf16_t)), xs = (unsigned)((size_t)st * WG_BM * ldx * sizeof(bf16_t));
 #pragma unroll
         for (int i = 0; i < Cfg::YN; ++i) yr[i] = buf_load16(rs_y, y_off + i * y_step, ys);
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_wgrad_kernel(const bf1
             }
         }
     };
-    auto write_stage = [&](int st) {
+    auto write_stage = [&](int st, const uint4 (&yr)[Cfg::YN], const uint4 (&xr)[Cfg::XN]) {
 #pragma unroll
         for (int i = 0; i < Cfg::YN; ++i) {
             uint4 y = yr[i];
@@ -521,12 +524,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_wgrad_kernel(const bf1
     const bf16_t *ytr = Ys + (4 * hh + trq) * LSY + wn * (32 * AT) + 16 * trg + 4 * trp;
     const bf16_t *xtr = Xs + (4 * hh + trq) * LSX + wk * (32 * BT) + 16 * trg + 4 * trp;
 
-    if (nst > 0) load_stage(0);
-    for (int st = 0; st < nst; ++st) {
-        if (st > 0) lds_barrier();  // the previous stage's reads are over
-        write_stage(st);
-        lds_barrier();
-        if (st + 1 < nst) load_stage(st + 1);
+    auto products = [&]() {
 #pragma unroll
         for (int ks = 0; ks < WG_BM / 16; ++ks) {
             bf16x8 a[AT], b[BT];
@@ -544,6 +542,22 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_wgrad_kernel(const bf1
             for (int ta = 0; ta < AT; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < BT; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+    };
+    if (nst > 0) load_stage(0, yrA, xrA);
+    if (nst > 1) load_stage(1, yrB, xrB);
+    for (int st = 0; st < nst; st += 2) {
+        if (st > 0) lds_barrier();  // the previous stage's reads are over
+        write_stage(st, yrA, xrA);
+        lds_barrier();
+        if (st + 2 < nst) load_stage(st + 2, yrA, xrA);
+        products();
+        if (st + 1 < nst) {
+            lds_barrier();
+            write_stage(st + 1, yrB, xrB);
+            lds_barrier();
+            if (st + 3 < nst) load_stage(st + 3, yrB, xrB);
+            products();
         }
     }
     // lane = output column k, registers = rows n: 128-byte runs per row
