@@ -6,6 +6,7 @@
 namespace dsw {
 
 constexpr int SEL_THREADS = 256;
+constexpr int SEL_SPLIT = 4;  // lanes that rank one window together (a power of two)
 constexpr int SEL_MAX_WINDOWS = 36864;  // z[] must fit LDS: 36864 * 4 B = 144 KiB
 
 // the reference's per-op rounding in the activation dtype
@@ -48,14 +49,21 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rank_kernel(
     float lsum = 0.f;
     for (int j = tid; j < n; j += SEL_THREADS) lsum += expf(z[j] - zmax);
     const float zsum = block_sum(lsum, red);
-    const int i = blockIdx.x * SEL_THREADS + tid;
-    if (i >= n) return;
-    const float zi = z[i];
+    // SEL_SPLIT neighbouring lanes rank one window together, each counting over its share of the windows (a frame
+    // has thousands of cells per image and one image: the count is the whole kernel there); the shares are
+    // contiguous ranges, summed over the lanes of the group
+    const int i = (blockIdx.x * SEL_THREADS + tid) / SEL_SPLIT, part = tid % SEL_SPLIT;
+    const int ic = min(i, n - 1);  // lanes past the end count along (the group sum needs them) and drop out below
+    const float zi = z[ic];
+    const int per = (n + SEL_SPLIT - 1) / SEL_SPLIT, j0 = part * per, j1 = min(j0 + per, n);
     int rank = 0;
-    for (int j = 0; j < n; ++j) {
+    for (int j = j0; j < j1; ++j) {
         const float zj = z[j];
-        rank += (zj > zi || (zj == zi && j < i)) ? 1 : 0;
+        rank += (zj > zi || (zj == zi && j < ic)) ? 1 : 0;
     }
+#pragma unroll
+    for (int o = 1; o < SEL_SPLIT; o <<= 1) rank += __shfl_xor(rank, o, 64);
+    if (i >= n || part != 0) return;
     const float p = expf(zi - zmax) / zsum;
     probs[(size_t)b * n + i] = p;
     if (rank < k) {
@@ -227,7 +235,7 @@ extern "C" int dsw_select_fwd(const void *sd, const void *sig, int sd_dtype, con
     if (n > SEL_MAX_WINDOWS) return fail(DSW_EUNSUPPORTED, "dsw_select_fwd: %d windows per image exceeds %d", n, SEL_MAX_WINDOWS);
     hipStream_t st = as_stream(stream);
     const size_t lds = (size_t)(n + 8) * sizeof(float);
-    dim3 gridA((n + SEL_THREADS - 1) / SEL_THREADS, B);
+    dim3 gridA((n * SEL_SPLIT + SEL_THREADS - 1) / SEL_THREADS, B);
     DSW_DISPATCH_DTYPE(sd_dtype, T, {
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)select_rank_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
