@@ -1239,17 +1239,20 @@ def _norm_kernel_ok(x, norm):
             and norm.weight is not None and tuple(norm.normalized_shape) == (C,))
 
 
-def rms_norm(x, norm, for_projection=False, sink=None):
+def rms_norm(x, norm, for_projection=False, sink=None, dense_act=False):
     """`norm(x)` for an nn.RMSNorm over the last dimension of the fp32 stream.  for_projection: the
     result feeds a projection - under bf16 autocast it is produced in bf16 rows padded to 64
     elements (what autocast's cast in front of the Linear would make of it, without the fp32 round
-    trip) and returned as a view of the first C columns."""
+    trip) and returned as a view of the first C columns.  dense_act: under bf16 autocast the result is a dense
+    bf16 tensor (for a consumer whose kernels round their input to bf16 anyway and want NHWC rows of C)."""
     if not _norm_kernel_ok(x, norm):
         assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
         return norm(x)
     eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
     act = autocast_dtype(x.dtype)
     to_act = for_projection and act == torch.bfloat16
+    if dense_act and not to_act and act == torch.bfloat16:
+        return _run(_RMSNormFn, x, norm.weight, eps, act, False, sink)
     return _run(_RMSNormFn, x, norm.weight, eps, act if to_act else torch.float32, to_act, sink)
 
 

@@ -137,7 +137,9 @@ class DSWTViTBlock(nn.Module):
             if fuse:
                 # inference: the branch's closing step (projection; DS-MSA's depthwise convolution) adds the residual
                 # itself (no bf16 round trip of the branch, no residual pass)
-                x = branch(K.rms_norm(x, norm, for_projection=proj), residual=(x, rz))
+                # (DS-MSA's input in bf16: its convolutions and its gather round it to bf16 as their first step, and
+                # the map it writes back into is rounded to bf16 on its way into out_conv; half the bytes on every pass)
+                x = branch(K.rms_norm(x, norm, for_projection=proj, dense_act=DSMSA_BF16_INPUT and not proj), residual=(x, rz))
                 continue
             sink = K.prenorm_sink(x, norm, rz)
             b = branch(K.rms_norm(x, norm, for_projection=proj, sink=sink))
@@ -320,6 +322,7 @@ class DSWTransformer(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # MSFT
 # ------------------------------------------------------------------------------------------------
+DSMSA_BF16_INPUT = True   # inference under bf16 autocast: the norm in front of DS-MSA writes bf16 (False: fp32, as the reference's norm does)
 NHWC_ENDS = True     # False: DSWTransformer's stem and reconstruction tail always run as stock NCHW convolutions
 NHWC_ENDS_TRAINING = False   # True: the NHWC ends with autograd as well (see DSWTransformer.forward)
 NHWC_STREAM = True   # False: MSFTransformer runs its trunk module by module on NCHW tensors, as the reference does
