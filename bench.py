@@ -11,7 +11,7 @@ that the selected windows pass), explicit Gumbel noise.
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, the pair wrapped in DistributedDataParallel over RCCL
+N > 1: one process per GPU, the pair in a data-parallel wrapper over RCCL (one flat gradient all-reduce per step)
 (backend "nccl"), per-GPU batch fixed (weak scaling).
 
 The JSON line also carries
@@ -369,10 +369,15 @@ def main():
         return
     model = build_pair(device)
     if grouped:
-        # the module's buffers are index tables fixed at construction: nothing to broadcast per forward; gradients
-        # live in the all-reduce buckets, so no copy into and out of them around the collective
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
-                                                          gradient_as_bucket_view=True)
+        # 0.4 MB of gradients: one flat buffer, one all-reduce queued for the end of the backward pass
+        # (BENCH_DDP=1: torch's DistributedDataParallel instead, gradients as views of its buckets, no broadcast of
+        # the buffers - index tables fixed at construction)
+        if os.environ.get("BENCH_DDP") == "1":
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
+                                                              gradient_as_bucket_view=True)
+        else:
+            from visiontransformer_amd.parallel import FlatDataParallel
+            model = FlatDataParallel(model)
     pair = model.module if grouped else model
     gen = torch.Generator(device=device).manual_seed(100 + rank)
     x = torch.randn(B_PER_GPU, HW, HW, C, device=device, generator=gen).requires_grad_()

@@ -133,7 +133,42 @@ def _worker(rank, world, port, q):
     xs = torch.cat([torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(100 + i)) for i in range(w)])
     single(xs).square().mean().backward()
     ok_grad = torch.allclose(g_ddp, single.a.weight.grad, atol=1e-6)
-    q.put((rank, ok_tiles, ok_grad))
+    # (3) the flat-buffer wrapper: same averaged gradients for every parameter, over three steps - .grad dropped
+    # between steps, kept (accumulating into the buffer's views), and a step inside no_sync followed by a synced one
+    start = _ToySR()
+    if r != 0:                   # a different start on the other ranks: the constructor must bring rank 0's values
+        with torch.no_grad():
+            for prm in start.parameters():
+                prm.add_(1.0)
+    flat = parallel.data_parallel(start, dev, flat=True)
+    twin = _ToySR()
+    ok_flat = isinstance(flat, parallel.FlatDataParallel)
+    ok_flat = ok_flat and all(torch.equal(a, b) for a, b in zip(flat.module.state_dict().values(), twin.state_dict().values()))
+
+    def grads(m):
+        return [p.grad.clone() for p in m.parameters()]
+
+    def same(m):
+        return all(torch.allclose(a, b, atol=1e-6) for a, b in zip(grads(m), grads(twin)))
+    flat(x).square().mean().backward()
+    twin(xs).square().mean().backward()
+    ok_flat = ok_flat and same(flat.module)
+    flat.zero_grad(set_to_none=True)
+    twin.zero_grad(set_to_none=True)
+    flat(x).square().mean().backward()
+    twin(xs).square().mean().backward()
+    ok_flat = ok_flat and same(flat.module)
+    # gradients kept: the next pass accumulates into the views; the reduced sum is avg(g1 + local g2 ...) - compare
+    # the no_sync + sync pair instead, whose result is defined: avg over ranks of (g + g) = 2 * avg g
+    flat.zero_grad(set_to_none=True)
+    twin.zero_grad(set_to_none=True)
+    with flat.no_sync():
+        flat(x).square().mean().backward()
+    flat(x).square().mean().backward()
+    twin(xs).square().mean().backward()
+    twin(xs).square().mean().backward()
+    ok_flat = ok_flat and same(flat.module)
+    q.put((rank, ok_tiles, ok_grad and ok_flat))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -40,7 +40,7 @@ def init_distributed(backend=None):
     return rank, world, device
 
 
-def data_parallel(model, device, find_unused_parameters=False, broadcast_buffers=True):
+def data_parallel(model, device, find_unused_parameters=False, broadcast_buffers=True, flat=False):
     """Wrap for data-parallel training when a process group exists (gradient all-reduce in buckets,
     overlapped with backward).  The kernel-backed modules give every parameter a gradient on every
     step: DS-MSA's default path (static_training) never returns early - when no window passes the gate
@@ -51,12 +51,107 @@ def data_parallel(model, device, find_unused_parameters=False, broadcast_buffers
     buckets (gradient_as_bucket_view): no copy into and out of them around the all-reduce - 0.24 ms of a 1.8 ms
     step of the attention pair.  broadcast_buffers=False skips the per-forward broadcast of the buffers when
     they are the index tables fixed at construction (the whole DSWT also counts its iterations in a buffer:
-    the same on every rank when the ranks step together)."""
+    the same on every rank when the ranks step together).  flat=True: FlatDataParallel, for modules whose gradients
+    fit one short all-reduce."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
+    if flat:
+        return FlatDataParallel(model)
     ids = [device.index] if device.type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters,
                                                      broadcast_buffers=broadcast_buffers, gradient_as_bucket_view=True)
+
+
+class FlatDataParallel(torch.nn.Module):
+    """Data-parallel wrapper for a module whose gradients fit one collective (the attention pair: 0.4 MB).
+
+    Every gradient lives in one flat buffer per dtype.  The module's output carries a hook that, when the backward
+    pass reaches it, queues one callback for the end of that pass; the callback gathers the gradients that are not
+    in the buffer yet with ONE multi-tensor copy, runs ONE all-reduce (average) over the buffer and leaves each
+    parameter's .grad as a view of it.  Against DistributedDataParallel's reducer - a hook per parameter on the
+    autograd thread, a copy per parameter into the bucket after zero_grad(set_to_none=True) - that is three
+    launches per step instead of two per parameter; nothing overlaps with the backward pass, which is the right
+    trade only while the all-reduce is short (use data_parallel(..., flat=False) for the whole networks).
+    A parameter without a gradient in some pass contributes zeros, so early returns need no search for unused
+    parameters.  The module must return one tensor.  `module` keeps the reference's attribute name for the
+    wrapped model (toolkit/init.py:131 wraps with DistributedDataParallel)."""
+
+    def __init__(self, module, process_group=None):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self._sync = True
+        self._armed = False
+        params = [p for p in module.parameters() if p.requires_grad]
+        with torch.no_grad():       # same start on every rank, as DistributedDataParallel's constructor does
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t, 0, group=process_group)
+        self._sets = []            # per (dtype, device): (flat buffer, parameters, views)
+        by_kind = {}
+        for p in params:
+            by_kind.setdefault((p.dtype, p.device), []).append(p)
+        for (dtype, device), ps in by_kind.items():
+            # every view starts on a 128-byte boundary of the buffer
+            step = max(1, 128 // torch.empty((), dtype=dtype).element_size())
+            offs, total = [], 0
+            for p in ps:
+                offs.append(total)
+                total += -(-p.numel() // step) * step
+            flat = torch.zeros(total, dtype=dtype, device=device)
+            views = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, ps)]
+            self._sets.append((flat, ps, views))
+        backend = dist.get_backend(process_group)
+        self._avg = dist.ReduceOp.AVG if backend == "nccl" else None
+
+    def no_sync(self):
+        """context: backward passes inside accumulate locally (gradient accumulation), no all-reduce"""
+        outer = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.old, outer._sync = outer._sync, False
+
+            def __exit__(self, *exc):
+                outer._sync = self.old
+        return _NoSync()
+
+    def forward(self, *args, **kwargs):
+        out = self.module(*args, **kwargs)
+        if torch.is_grad_enabled() and self._sync:
+            if not isinstance(out, torch.Tensor):
+                raise TypeError("FlatDataParallel needs a module that returns one tensor, got %s" % type(out).__name__)
+            if out.requires_grad:
+                out.register_hook(self._arm)
+        return out
+
+    def _arm(self, grad):
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._reduce)
+        return None
+
+    @torch.no_grad()
+    def _reduce(self):
+        self._armed = False
+        for flat, ps, views in self._sets:
+            dst, src = [], []
+            for p, v in zip(ps, views):
+                g = p.grad
+                if g is None:
+                    v.zero_()
+                elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+                    dst.append(v)
+                    src.append(g)
+            if dst:
+                torch._foreach_copy_(dst, src)
+            if self._avg is not None:
+                dist.all_reduce(flat, op=self._avg, group=self.group)
+            else:
+                dist.all_reduce(flat, group=self.group)
+                flat.div_(self.world)
+            for p, v in zip(ps, views):
+                p.grad = v
 
 
 @dataclass
