@@ -168,6 +168,19 @@ def _worker(rank, world, port, q):
     twin(xs).square().mean().backward()
     twin(xs).square().mean().backward()
     ok_flat = ok_flat and same(flat.module)
+    # a parameter no pass reaches (an early return) contributes zeros and does not hold the collective up
+    class _Spare(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = _ToySR()
+            self.spare = torch.nn.Parameter(torch.ones(5))
+
+        def forward(self, t):
+            return self.net(t)
+    sp = parallel.FlatDataParallel(_Spare())
+    sp(x).square().mean().backward()
+    ok_flat = ok_flat and torch.equal(sp.module.spare.grad, torch.zeros(5)) \
+        and torch.allclose(sp.module.net.a.weight.grad, single.a.weight.grad, atol=1e-6)
     q.put((rank, ok_tiles, ok_grad and ok_flat))
     dist.barrier()
     dist.destroy_process_group()
