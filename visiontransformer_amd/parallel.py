@@ -86,7 +86,12 @@ class FlatDataParallel(torch.nn.Module):
         params = [p for p in module.parameters() if p.requires_grad]
         with torch.no_grad():       # same start on every rank, as DistributedDataParallel's constructor does
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t, 0, group=process_group)
+                if t.is_contiguous():
+                    dist.broadcast(t, 0, group=process_group)
+                else:                  # e.g. channels-last convolution weights: collectives take dense tensors
+                    dense = t.contiguous()
+                    dist.broadcast(dense, 0, group=process_group)
+                    t.copy_(dense)
         self._sets = []            # per (dtype, device): (flat buffer, parameters, views)
         by_kind = {}
         for p in params:
