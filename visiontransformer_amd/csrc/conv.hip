@@ -122,66 +122,90 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
     }
 }
 
-// weight / bias gradient partials: one block per DW_ROWS image rows.  Thread = (pixel part, channel
-// quad, tap row a): walking along an image row the three tap columns are a sliding window of x, so a
-// pixel costs one x load and one dy load.  The parts are summed through LDS in part order.
+// weight / bias gradient partials of the depthwise convolution: one block per DW_ROWS image rows, summed over the
+// blocks by partial_reduce_kernel.
 constexpr int DW_ROWS = 2;
-constexpr int WG_THREADS = 448;  // 3 parts x (45 quads x 3 tap rows) at C = 180
+constexpr int WG_THREADS = 448;  // sd_bwd_w0_kernel: 3 parts x (45 quads x 3 tap rows) at C = 180
+// Thread = (pixel part, channel quad), all nine taps in registers: walking along the block's two image rows the
+// three tap columns are a sliding window of x, so a pixel costs four x loads (the rows above, of and below the pair)
+// and two dy loads.  The parts are summed through LDS in part order.  Measured at 32 x 64 x 64 x 180: 36 us with 16
+// pixels per thread (192 threads) and the pixel loop not unrolled (about 100 registers); 45 us unrolled by two,
+// 53 us with 8 pixels per thread, 41 / 39 us with 128 / 256 threads; a thread per tap row (half the registers,
+// twice the loads) 53 us.
+constexpr int WR_THREADS = 192;  // 4 parts x 45 quads at C = 180: 16 pixels of the row pair per thread
 template <typename TG, typename TX>
-__global__ __launch_bounds__(WG_THREADS) void dwconv_wgrad_kernel(const TG *__restrict__ dy, const TX *__restrict__ x, int H,
-                                                                  int W, int C, float *__restrict__ partial,
-                                                                  const int *__restrict__ identity_if_zero) {
-    // the forward was the identity (no window passed the gate): the gradients are zero, and split10_kernel, which
-    // reads the same counter, writes the zeros without looking at the partial sums
+__global__ __launch_bounds__(WR_THREADS) void dwconv_wgrad_rows_kernel(const TG *__restrict__ dy, const TX *__restrict__ x,
+                                                                       int H, int W, int C, float *__restrict__ partial,
+                                                                       const int *__restrict__ identity_if_zero) {
+    static_assert(DW_ROWS == 2, "the row pair is written out below");
     if (identity_if_zero != nullptr && *identity_if_zero == 0) return;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [CV*3][16]: 3 tap columns + dy sum, x 4 channels
-    const int CV = C >> 2, NI = CV * 3, PP = max(1, WG_THREADS / NI);
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [CV][10] float4: nine taps + dy sum, x 4 channels
+    const int CV = C >> 2, PP = max(1, min(WR_THREADS / CV, W));
     const int rows_per_img = (H + DW_ROWS - 1) / DW_ROWS;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // row groups of one image on one XCD: they share their halo rows
-    const int b = bid / rows_per_img, h0 = (bid - b * rows_per_img) * DW_ROWS;
-    const int item = threadIdx.x % NI, part = threadIdx.x / NI;
-    const int cv = item / 3, a = item - cv * 3, c = cv << 2;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = __builtin_amdgcn_readfirstlane(bid / rows_per_img), h0 = (bid - b * rows_per_img) * DW_ROWS;
+    const int cv = threadIdx.x % CV, part = threadIdx.x / CV, c = cv << 2;
     const int chunk = (W + PP - 1) / PP, p0 = part * chunk, p1 = min(p0 + chunk, W);
-    float4 acc[3] = {f4zero(), f4zero(), f4zero()}, gsum = f4zero();
+    float4 acc[3][3], gsum = f4zero();
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) acc[a][bb] = f4zero();
     if (part < PP && p0 < p1) {
         const TG *gimg = dy + (size_t)b * H * W * C + c;
         const TX *ximg = x + (size_t)b * H * W * C + c;
-        for (int h = h0; h < min(h0 + DW_ROWS, H); ++h) {
-            const int yy = h + a - 1;
-            if (yy < 0 || yy >= H) continue;
-            const TX *xrow = ximg + (size_t)yy * W * C;
-            const TG *grow = gimg + (size_t)h * W * C;
-            float4 xm = p0 > 0 ? io<TX>::ld4(xrow + (size_t)(p0 - 1) * C) : f4zero();
-            float4 xc = io<TX>::ld4(xrow + (size_t)p0 * C);
-#pragma unroll 4
-            for (int p = p0; p < p1; ++p) {
-                const float4 xp = (p + 1 < W) ? io<TX>::ld4(xrow + (size_t)(p + 1) * C) : f4zero();
-                const float4 g = io<TG>::ld4(grow + (size_t)p * C);
-                acc[0] = fma4(g, xm, acc[0]);
-                acc[1] = fma4(g, xc, acc[1]);
-                acc[2] = fma4(g, xp, acc[2]);
-                gsum = gsum + g;
-                xm = xc;
-                xc = xp;
+        const TX *xrow[4];
+        bool xok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int yy = h0 - 1 + j;
+            xok[j] = yy >= 0 && yy < H;
+            xrow[j] = ximg + (size_t)(xok[j] ? yy : 0) * W * C;
+        }
+        const bool g1ok = h0 + 1 < H;
+        const TG *grow0 = gimg + (size_t)h0 * W * C, *grow1 = gimg + (size_t)(g1ok ? h0 + 1 : h0) * W * C;
+        float4 xm[4], xc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xm[j] = (p0 > 0 && xok[j]) ? io<TX>::ld4(xrow[j] + (size_t)(p0 - 1) * C) : f4zero();
+            xc[j] = xok[j] ? io<TX>::ld4(xrow[j] + (size_t)p0 * C) : f4zero();
+        }
+#pragma unroll 1
+        for (int p = p0; p < p1; ++p) {
+            float4 xp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xp[j] = (p + 1 < W && xok[j]) ? io<TX>::ld4(xrow[j] + (size_t)(p + 1) * C) : f4zero();
+            const float4 g0 = io<TG>::ld4(grow0 + (size_t)p * C);
+            const float4 g1 = g1ok ? io<TG>::ld4(grow1 + (size_t)p * C) : f4zero();
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                acc[a][0] = fma4(g0, xm[a], acc[a][0]);
+                acc[a][1] = fma4(g0, xc[a], acc[a][1]);
+                acc[a][2] = fma4(g0, xp[a], acc[a][2]);
+                acc[a][0] = fma4(g1, xm[a + 1], acc[a][0]);
+                acc[a][1] = fma4(g1, xc[a + 1], acc[a][1]);
+                acc[a][2] = fma4(g1, xp[a + 1], acc[a][2]);
             }
+            gsum = gsum + g0 + g1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xm[j] = xc[j], xc[j] = xp[j];
         }
     }
     for (int pt = 0; pt < PP; ++pt) {
         if (part == pt) {
-            float4 *dst = reinterpret_cast<float4 *>(red + (size_t)item * 16);
-            if (pt == 0) {
-                dst[0] = acc[0], dst[1] = acc[1], dst[2] = acc[2], dst[3] = gsum;
-            } else {
-                dst[0] = dst[0] + acc[0], dst[1] = dst[1] + acc[1], dst[2] = dst[2] + acc[2], dst[3] = dst[3] + gsum;
-            }
+            float4 *dst = reinterpret_cast<float4 *>(red) + (size_t)cv * 10;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) dst[a * 3 + bb] = pt == 0 ? acc[a][bb] : dst[a * 3 + bb] + acc[a][bb];
+            dst[9] = pt == 0 ? gsum : dst[9] + gsum;
         }
         __syncthreads();
     }
-    // partial[blk][c][k]: k = a*3 + bb, k = 9: bias (the dy sum of the a = 1 thread, whose rows are all valid)
-    for (int i = threadIdx.x; i < C * 10; i += WG_THREADS) {
+    // partial[blk][c][k]: k = a*3 + bb, k = 9: bias
+    for (int i = threadIdx.x; i < C * 10; i += WR_THREADS) {
         const int ch = i / 10, k = i - ch * 10;
-        const int a2 = k < 9 ? k / 3 : 1, slot = k < 9 ? k - a2 * 3 : 3;
-        partial[(size_t)bid * C * 10 + i] = red[((size_t)((ch >> 2) * 3 + a2) * 4 + slot) * 4 + (ch & 3)];
+        partial[(size_t)bid * C * 10 + i] = red[((size_t)(ch >> 2) * 10 + k) * 4 + (ch & 3)];
     }
 }
 
@@ -783,17 +807,17 @@ extern "C" int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, in
     }));
     rc = check_launch("dwconv_stream_kernel<flip>");
     if (rc) return rc;
-    const int NI = C / 4 * 3;
-    if (NI > WG_THREADS) return fail(DSW_EUNSUPPORTED, "dsw_dwconv3x3_bwd: %d channels > %d", C, WG_THREADS / 3 * 4);
+    const int CVq = C / 4;
+    if (CVq > WR_THREADS) return fail(DSW_EUNSUPPORTED, "dsw_dwconv3x3_bwd: %d channels > %d", C, WR_THREADS * 4);
     const int nblocks = dsw_dwconv3x3_bwd_blocks(B, H, W);
-    const size_t lds2 = (size_t)NI * 16 * sizeof(float);
+    const size_t lds2 = (size_t)CVq * 10 * 4 * sizeof(float);
     DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(x_dtype, TX, {
-        auto kern = dwconv_wgrad_kernel<TG, TX>;
+        auto kern = dwconv_wgrad_rows_kernel<TG, TX>;
         rc = set_lds_attr(kern, lds2, "dsw_dwconv3x3_bwd");
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WG_THREADS), lds2, st, (const TG *)dy, (const TX *)x, H, W, C, partial, identity_if_zero);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WR_THREADS), lds2, st, (const TG *)dy, (const TX *)x, H, W, C, partial, identity_if_zero);
     }));
-    rc = check_launch("dwconv_wgrad_kernel");
+    rc = check_launch("dwconv_wgrad_rows_kernel");
     if (rc) return rc;
     // partial rows are [C][10] = 9 taps + bias; reduce into a packed [C*10] staging area at the
     // end of `partial`, then split (the split is a strided copy done by the caller's view)
