@@ -375,6 +375,79 @@ def test_window_attention_backward_kernels_agree(cuda0, monkeypatch, bias, C, he
         assert rel_err(res[0][1], res[1][1]) < 1e-2
 
 
+@pytest.mark.parametrize("bias", [True, False])
+@pytest.mark.parametrize("C,heads,layout,grid", [(180, 6, "interleaved", (2, 32, 48)), (180, 6, "chunked", 7), (48, 3, "chunked", 3),
+                                                 (84, 3, "interleaved", (1, 16, 32))])
+def test_window_attention_forward_kernels_agree(cuda0, monkeypatch, bias, C, heads, layout, grid):
+    """16x16 windows in bf16 with an even head dim <= 30 have two forward kernels: the one that keeps Q in registers
+    and the softmax reference in the head dim's padding (attn_fwd_w16.hip) and the general one
+    (DSW_ATTN_FWD_GENERAL=1).  Same output and log-sum-exp within bf16 rounding, on dense rows and on padded ones."""
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED, QKV_INTERLEAVED
+    w = 16
+    gen = torch.Generator().manual_seed(3 * C + len(layout))
+    lead = (grid[0], grid[1], grid[2]) if isinstance(grid, tuple) else (grid, w * w)
+    qkv = (torch.randn(lead + (3 * C,), generator=gen) * 1.5).to(torch.bfloat16)
+    table = (torch.randn((2 * w - 1) ** 2, heads, generator=gen) * 0.5) if bias else None
+    g = grid if isinstance(grid, tuple) else None
+    ref = D.window_attention_core(qkv.float(), table, w, heads, layout, grid=g).reshape(lead + (C,))
+    code = QKV_CHUNKED if layout == "chunked" else QKV_INTERLEAVED
+    t_g = None if table is None else table.to(cuda0)
+    rows = qkv.numel() // (3 * C)
+    buf = K._mark_padded(torch.zeros(rows, K._ceil_pad(3 * C), dtype=torch.bfloat16, device=cuda0))
+    buf[:, :3 * C] = qkv.to(cuda0).reshape(rows, 3 * C)
+    res = []
+    for general in ("0", "1"):
+        monkeypatch.setenv("DSW_ATTN_FWD_GENERAL", general)
+        with torch.no_grad():
+            dense = K.window_attention(qkv.to(cuda0), t_g, w, heads, code, grid=g)
+            padded = K.window_attention(buf[:, :3 * C].view(lead + (3 * C,)), t_g, w, heads, code, grid=g, pad_out=True)
+        assert rel_err(dense, ref) < TOL[torch.bfloat16]
+        assert torch.equal(dense, padded)
+        if C % 64:
+            assert float(padded._base[:, C:].abs().max()) == 0.0
+        res.append(dense)
+    assert rel_err(res[0], res[1]) < 6e-3
+
+
+@pytest.mark.parametrize("pattern", ["rising", "falling", "spike", "huge", "negative"])
+def test_window_attention_w16_softmax_reference(cuda0, pattern):
+    """The forward kernel for 16x16 windows raises its softmax reference only when a key tile exceeds it by 2^8:
+    logits that grow from tile to tile, fall, spike in one late key, are huge everywhere or are all very negative
+    must give the oracle's softmax, finite, and a backward that agrees with it (log-sum-exp saved by the forward)."""
+    K = _K()
+    from visiontransformer_amd._lib import QKV_CHUNKED
+    w, C, heads = 16, 60, 2
+    gen = torch.Generator().manual_seed(11)
+    qkv = torch.randn(3, w * w, 3 * C, generator=gen)
+    ramp = torch.linspace(0.0, 1.0, w * w).view(1, -1, 1)
+    k = qkv[..., C:2 * C]
+    if pattern == "rising":
+        k *= 1.0 + 14.0 * ramp
+    elif pattern == "falling":
+        k *= 15.0 - 14.0 * ramp
+    elif pattern == "spike":
+        k[:, 201] *= 40.0
+    elif pattern == "huge":
+        qkv[..., :2 * C] *= 9.0
+    else:
+        qkv[..., :C] = qkv[..., :C].abs() * 6.0
+        k.copy_(-k.abs() * 6.0)
+    qkv = qkv.to(torch.bfloat16)
+    r = torch.randn(3, w * w, C, generator=gen)
+    q_ref = qkv.float().clone().requires_grad_()
+    ref = D.window_attention_core(q_ref, None, w, heads, "chunked")
+    (ref.reshape(r.shape) * r).sum().backward()
+    q_g = qkv.to(cuda0).requires_grad_()
+    out = K.window_attention(q_g, None, w, heads, QKV_CHUNKED)
+    (out.float() * r.to(cuda0)).sum().backward()
+    assert torch.isfinite(out).all() and torch.isfinite(q_g.grad).all()
+    assert rel_err(out, ref.reshape(r.shape)) < TOL[torch.bfloat16]
+    # ("huge": logits of several hundred, rows all but one-hot; the gradient that is left is the difference of nearly
+    # equal bf16-rounded terms, in either forward kernel)
+    assert rel_err(q_g.grad, q_ref.grad) < (8e-2 if pattern == "huge" else 3e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("w,C,heads,layout,grid,bias,p", [
     (8, 96, 6, "chunked", (2, 16, 24), False, 0.1),      # msft level block: head dim 16, SDPA's dropout_p

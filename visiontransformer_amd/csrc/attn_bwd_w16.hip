@@ -33,18 +33,6 @@ template <int DP> struct Bwd2Cfg {
     }
 };
 
-// XOR pattern of the 16-byte slots of row `row` of a [rows][DP] bf16 image (64- or 128-byte rows).
-// ds_read_b128 of one slot of 32 consecutive rows, and ds_read_b64_tr_b16 of 4 consecutive rows x 32 columns,
-// then touch every bank exactly once per lane group.
-template <int DP> __device__ __forceinline__ int slot_flip(int row) {
-    if constexpr (DP == 32) return (row >> 2) & 3;
-    else return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-}
-// element offset of (row, col) in such an image; col % 8 stays inside the slot
-template <int DP> __device__ __forceinline__ int img(int row, int col) {
-    return row * DP + (((col >> 3) ^ slot_flip<DP>(row)) << 3) + (col & 7);
-}
-
 template <int CTRL> __device__ __forceinline__ float dpp_zero_fill(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }

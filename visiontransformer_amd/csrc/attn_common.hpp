@@ -151,6 +151,81 @@ __device__ __forceinline__ float upper_half_to_lower(float x) {
     return __uint_as_float(r[1]);
 }
 
+// ---- pieces shared by the kernels for 16 x 16 windows in bf16 (attn_fwd_w16.hip, attn_bwd_w16.hip) -------------
+// XOR pattern of the 16-byte slots of row `row` of a [rows][DP] bf16 image (64- or 128-byte rows).
+// ds_read_b128 of one slot of 32 consecutive rows, and ds_read_b64_tr_b16 of 4 consecutive rows x 32 columns,
+// then touch every bank exactly once per lane group.
+template <int DP> __device__ __forceinline__ int slot_flip(int row) {
+    if constexpr (DP == 32) return (row >> 2) & 3;
+    else return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+}
+// element offset of (row, col) in such an image; col % 8 stays inside the slot
+template <int DP> __device__ __forceinline__ int img(int row, int col) {
+    return row * DP + (((col >> 3) ^ slot_flip<DP>(row)) << 3) + (col & 7);
+}
+
+// A slot = 8 consecutive bf16 (16 bytes) of a head's slice of a token row.  The slice starts on a 4-byte boundary
+// only, and its last slot may be partial: `cnt` (0..4) is the number of dwords of the slot that belong to the
+// slice; nothing outside them is touched (the neighbouring bytes belong to another head, or lie past the buffer).
+struct __attribute__((packed, aligned(4))) u32x4_a4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) u32x3_a4 { uint32_t x, y, z; };
+struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t x, y; };
+__device__ __forceinline__ uint4 load_slot(const bf16_t *p, int cnt) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (cnt >= 4) {
+        const u32x4_a4 t = *reinterpret_cast<const u32x4_a4 *>(p);
+        v = make_uint4(t.x, t.y, t.z, t.w);
+    } else if (cnt == 3) {
+        const u32x3_a4 t = *reinterpret_cast<const u32x3_a4 *>(p);
+        v = make_uint4(t.x, t.y, t.z, 0u);
+    } else if (cnt == 2) {
+        const u32x2_a4 t = *reinterpret_cast<const u32x2_a4 *>(p);
+        v = make_uint4(t.x, t.y, 0u, 0u);
+    } else if (cnt == 1) {
+        v.x = *reinterpret_cast<const uint32_t *>(p);
+    }
+    return v;
+}
+__device__ __forceinline__ void store_slot(bf16_t *p, uint4 v, int cnt) {
+    if (cnt >= 4) {
+        u32x4_a4 t;
+        t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
+        *reinterpret_cast<u32x4_a4 *>(p) = t;
+    } else if (cnt == 3) {
+        u32x3_a4 t;
+        t.x = v.x, t.y = v.y, t.z = v.z;
+        *reinterpret_cast<u32x3_a4 *>(p) = t;
+    } else if (cnt == 2) {
+        u32x2_a4 t;
+        t.x = v.x, t.y = v.y;
+        *reinterpret_cast<u32x2_a4 *>(p) = t;
+    } else if (cnt == 1) {
+        *reinterpret_cast<uint32_t *>(p) = v.x;
+    }
+}
+// dwords of slot c (8 elements each) that lie inside a slice of d elements (d even)
+__device__ __forceinline__ int slot_dwords(int d, int c) {
+    const int n = (d >> 1) - 4 * c;
+    return n < 0 ? 0 : (n > 4 ? 4 : n);
+}
+// both lane halves receive max(x[l], x[l + 32]), l = lane % 32
+__device__ __forceinline__ float max_across_halves(float x) {
+    const unsigned xi = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// x as two bf16 (low half: rounded value, high half: rounded remainder) whose sum carries 16 mantissa bits
+__device__ __forceinline__ uint32_t bf16_hi_lo(float x) {
+    const bf16_t h = f32_to_bf16(x);
+    const bf16_t l = f32_to_bf16(x - bf16_to_f32(h));
+    return (uint32_t)h | ((uint32_t)l << 16);
+}
+
+// forward for 16 x 16 windows in bf16 with an even head dim <= 30, no LePE, no dropout (attn_fwd_w16.hip); returns
+// DSW_OK after launching, or a negative value when the shape is not one it takes (the caller then uses the general
+// kernel)
+int launch_fwd_w16(const AttnGeom &g, const void *qkv, const float *table, float scale, void *out, float *lse, hipStream_t st);
+
 // backward for 16 x 16 windows in bf16 without any exchange of dS between waves (attn_bwd_w16.hip); returns
 // DSW_OK after launching, or a negative value when the shape is not one it takes (the caller then uses
 // the general kernel)

@@ -238,6 +238,12 @@ int make_drop(const char *who, float p, unsigned long long seed, DropArgs &d) {
     return DSW_OK;
 }
 
+// DSW_ATTN_FWD_GENERAL=1 in the environment sends every shape to the general kernel (tests compare the two)
+bool force_general_fwd() {
+    const char *e = getenv("DSW_ATTN_FWD_GENERAL");
+    return e != nullptr && e[0] == '1';
+}
+
 }  // namespace dsw
 
 using namespace dsw;
@@ -258,6 +264,10 @@ extern "C" int dsw_win_attn_fwd(const void *qkv, int dtype, int layout, int n_im
     DSW_REQUIRE((lepe_w == nullptr) == (lepe_b == nullptr), "dsw_win_attn_fwd: lepe_w and lepe_b go together");
     hipStream_t st = as_stream(stream);
     const bool big = g.d > 32;
+    if (dtype == DSW_BF16 && w == 16 && lepe_w == nullptr && drop.thr == 0 && !force_general_fwd()) {
+        rc = launch_fwd_w16(g, qkv, bias_table, scale, out, lse, st);  // even head dims <= 30 (attn_fwd_w16.hip)
+        if (rc >= 0) return rc;
+    }
     DSW_DISPATCH_DTYPE(dtype, T, {
         if (w == 16) return big ? launch_fwd<T, 16, 64>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, drop, st)
                                 : launch_fwd<T, 16, 32>(g, qkv, bias_table, scale, lepe_w, lepe_b, out, lse, drop, st);

@@ -1,0 +1,299 @@
+// Fused window attention, forward, for 16 x 16 windows in bf16 with an even head dim <= 30 (no LePE, no dropout):
+// softmax(q k^T * scale + bias) v for one (window, head) per workgroup of 8 waves, a wave per 32-query block.
+// Reference: DSwinT_arch.py:122-125, :135-172, :303-308, :333-337.
+//
+// What sets it apart from the general kernel (attn_fwd.hip):
+//  * a head's slice of a token row is read as 16-byte slots (4-byte aligned) instead of dwords;
+//  * Q never enters LDS: a wave reads its own block's fragments from global memory straight into the B operand
+//    registers and scales them there; K and V are XOR-swizzled images (slot_flip) whose 16-byte row reads and
+//    transposing reads are bank-conflict-free; 39 KB of LDS per workgroup, several workgroups per CU;
+//  * the row reference r of the softmax (what is subtracted from the logits before the exponential) rides in the
+//    two last padding columns of the head dimension: Q' holds -r split into two bf16 (hi + lo) there against ones
+//    in K, so the matrix core delivers S - r and the exponential follows without a subtraction.  r starts as the
+//    row maximum of the first key tile and is raised only when a later tile exceeds it by more than 2^8 (one
+//    wave-uniform branch per tile, almost never taken after the first tile): no per-tile rescaling of the running
+//    output, and the result is the exact softmax whatever r is, since numerator and denominator share it;
+//  * the denominator is row 31 of O^T (a column of ones in V's padding), computed by the matrix core;
+//  * the output leaves from registers: the two lane halves of a query exchange half of their columns
+//    (v_permlane32_swap) so that every lane stores two 16-byte slots of its token row.
+#include "attn_common.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace dsw {
+
+struct FwdW16Cfg {
+    static constexpr int WS = 16, L = 256, DP = 32, NT = 8, THREADS = 512;
+    static constexpr int N_IMG = L * DP;  // elements of one operand image
+    static constexpr int TBF = bias_lds<16>::FLOATS;
+    static constexpr size_t lds_bytes(bool bias) { return (size_t)2 * N_IMG * sizeof(bf16_t) + (bias ? (size_t)TBF * sizeof(float) : 0); }
+};
+
+constexpr float FWD_W16_RAISE = 8.f;  // the reference is raised when a logit exceeds it by more than this (base 2)
+
+// 8 consecutive bf16 at a 4-byte-aligned address
+__device__ __forceinline__ uint4 load16_a4(const bf16_t *p) {
+    const u32x4_a4 t = *reinterpret_cast<const u32x4_a4 *>(p);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void store16_a4(bf16_t *p, uint4 v) {
+    u32x4_a4 t;
+    t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
+    *reinterpret_cast<u32x4_a4 *>(p) = t;
+}
+// The head dim is 30: a head's slice of a token row is three whole 16-byte slots and one of 12 bytes.  The last
+// slot is read (and written) as the 16 bytes that END with the slice - one dword early, so that no byte outside the
+// slice is touched - and shifted in registers; its fourth dword, columns 30 and 31 of the padded head dim, is ours.
+template <bool BIAS>
+__global__ __launch_bounds__(512, 8) void win_attn_fwd_w16_kernel(AttnGeom g, const bf16_t *__restrict__ qkv,
+                                                                  const float *__restrict__ table, float scale,
+                                                                  bf16_t *__restrict__ out, float *__restrict__ lse) {
+    using Cfg = FwdW16Cfg;
+    using T = bf16_t;
+    constexpr int WS = 16, L = Cfg::L, DP = Cfg::DP, NT = Cfg::NT, THREADS = Cfg::THREADS, D = 30;
+    constexpr int TS = bias_lds<WS>::TS, TR = bias_lds<WS>::ROWS, TMAX = (2 * WS - 2) * (TS + 1);
+    constexpr int BLK = 32 * DP;  // elements of a 32-row block of an image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *Ki = reinterpret_cast<T *>(smem);
+    T *Vi = Ki + Cfg::N_IMG;
+    float *tb = reinterpret_cast<float *>(Vi + Cfg::N_IMG);  // BIAS: mirrored table, entry e at TMAX - e
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int C = g.ldo, C3 = g.ldq;
+    const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
+    // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
+    const int win = __builtin_amdgcn_readfirstlane(id / g.heads), head = id - win * g.heads;
+    int qoff, koff, voff;
+    qkv_offsets(g, head, qoff, koff, voff);
+    size_t origin;  // token (i, j) of this window sits at row origin + i*pitch + j
+    int pitch;
+    if (g.H == 0) {
+        origin = (size_t)win * L;
+        pitch = WS;
+    } else {
+        const int per = g.nWh * g.nWw;
+        const int b = __builtin_amdgcn_readfirstlane(win / per), r = win - b * per;
+        const int wr = __builtin_amdgcn_readfirstlane(r / g.nWw), wc = r - wr * g.nWw;
+        origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
+        pitch = g.W;
+    }
+    if (window_is_off(g, win)) {  // uniform over the workgroup
+        zero_window_slice<T>(out, g.ldo, origin, pitch, WS, head * D, D, head == g.heads - 1, g.C, tid, THREADS);
+        for (int l = tid; l < L; l += THREADS) lse[((size_t)win * g.heads + head) * L + l] = 0.f;
+        return;
+    }
+    auto rel_row = [&](int l) -> unsigned { return (unsigned)((l >> 4) * pitch + (l & 15)); };
+    const T *qkv0 = qkv + origin * C3;  // wave-uniform 64-bit base, 32-bit lane offsets
+
+    // ---- loads: this wave's Q fragments (slots hh and 2 + hh of row 32 wave + l31), then K and V --------------
+    const int qrow = 32 * wave + l31;
+    const unsigned qrel = rel_row(qrow) * C3 + qoff + 8 * hh;
+    uint4 qraw[2];
+    qraw[0] = load16_a4(qkv0 + qrel);
+    qraw[1] = load16_a4(qkv0 + (qrel + 16 - 2 * hh));
+    {
+        const int c = tid & 3;
+        const bool last = c == 3;
+        uint4 kv[2], vv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned rel = rel_row((tid >> 2) + 128 * i) * C3 + 8 * c - (last ? 2 : 0);
+            kv[i] = load16_a4(qkv0 + (rel + koff));
+            vv[i] = load16_a4(qkv0 + (rel + voff));
+        }
+        if constexpr (BIAS) {
+            for (int it = tid; it < TR * TR; it += THREADS) {
+                const int di = it / TR, dj = it - di * TR;
+                tb[TMAX - (di * TS + dj)] = table[(size_t)it * g.heads + head] * LOG2E;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 2) + 128 * i;
+            if (last) {  // columns 30, 31: ones in K (they pick up -r from Q'), V's column 31 the denominator
+                kv[i] = make_uint4(kv[i].y, kv[i].z, kv[i].w, 0x3F803F80u);
+                vv[i] = make_uint4(vv[i].y, vv[i].z, vv[i].w, 0x3F800000u);
+            }
+            *reinterpret_cast<uint4 *>(Ki + img<DP>(row, 8 * c)) = kv[i];
+            *reinterpret_cast<uint4 *>(Vi + img<DP>(row, 8 * c)) = vv[i];
+        }
+    }
+    // Q' = bf16(q * scale * log2 e): the B operand of S^T = K Q'^T, kept for the whole block
+    const float sc2 = scale * LOG2E;
+    uint4 qfb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t in[4] = {qraw[s].x, qraw[s].y, qraw[s].z, qraw[s].w};
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_bf16(__uint_as_float(in[i] << 16) * sc2, __uint_as_float(in[i] & 0xffff0000u) * sc2);
+        qfb[s] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    if (hh) qfb[1] = make_uint4(qfb[1].y, qfb[1].z, qfb[1].w, 0u);
+    // per-lane LDS offsets (elements) inside a 32-row block of an image
+    int a_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a_off[s] = img<DP>(l31, 16 * s + 8 * hh);
+    // transposing reads: lane 4q+p of a 16-lane group passes row q, columns 4p..4p+3
+    const int trq = (lane >> 2) & 3, trp = lane & 3, trg = (lane >> 4) & 1;
+    int t_off[2];  // rows +0 / +8 of a 16-row step (a step further down is 16 whole rows on: the slot pattern repeats)
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) t_off[h8] = img<DP>(4 * hh + trq + 8 * h8, 16 * trg + 4 * trp);
+    const int lane_base = TMAX - ((qrow >> 4) * TS + (qrow & 15) + (WS - 1) * (TS + 1) - 4 * hh);
+    __syncthreads();
+
+    f32x16 oacc;
+    float rref;  // the row reference: always the sum of two bf16, so that Q' carries it exactly
+    // S^T - r for key tile t: the accumulators start from the bias, the matrix core adds K Q'^T and -r
+    // the bias of key tile t against this lane's query: register r of lane half hh is key 32t + rho(r) + 4hh, four
+    // consecutive registers are four ascending words of the mirrored table
+    auto seeds = [&](int t, f32x16 &sacc) {
+        // (the tile's base goes through an empty asm: one address register for the whole pass instead of one per
+        // reach of the reads' 8-bit offsets, all of them computed up front and kept alive)
+        int tile_base = lane_base + 2 * TS * t;
+        asm volatile("" : "+v"(tile_base));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (BIAS) sacc[r] = tb[tile_base + ((rho(r) >> 4) * TS + (rho(r) & 15))];
+            else sacc[r] = 0.f;
+        }
+    };
+    // S^T - r for key tile t: the accumulators start from the bias, the matrix core adds K Q'^T and -r
+    auto products = [&](int t, f32x16 &sacc) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint4 kf = *reinterpret_cast<const uint4 *>(Ki + t * BLK + a_off[s]);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf), as_bf16x8(qfb[s]), sacc, 0, 0, 0);
+        }
+    };
+    auto scores = [&](int t, f32x16 &sacc) {
+        seeds(t, sacc);
+        products(t, sacc);
+    };
+    auto row_max = [&](const f32x16 &sacc) -> float {
+        // (plain fmaxf: an instruction inside inline asm that reads what a matrix instruction has just written is not
+        // given the wait states it needs)
+        float tm = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) tm = fmaxf(fmaxf(tm, sacc[r]), sacc[r + 1]);
+        return max_across_halves(fmaxf(tm, sacc[15]));
+    };
+    // moves the reference to (about) rnew_wish; returns by how much it moved
+    auto set_reference = [&](float wish) -> float {
+        const uint32_t hl = bf16_hi_lo(wish);
+        const float rnew = __uint_as_float(hl << 16) + __uint_as_float(hl & 0xffff0000u), sh = rnew - rref;
+        rref = rnew;
+        if (hh) qfb[1].w = hl ^ 0x80008000u;  // columns 30, 31 of Q': -hi, -lo
+        return sh;
+    };
+    // P^T = exp2(S^T - r), as it stands the B operand of O^T += V^T P^T
+    auto accumulate = [&](int t, f32x16 &sacc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint4 pb = make_uint4(pack_bf16(sacc[8 * s + 0], sacc[8 * s + 1]), pack_bf16(sacc[8 * s + 2], sacc[8 * s + 3]),
+                                        pack_bf16(sacc[8 * s + 4], sacc[8 * s + 5]), pack_bf16(sacc[8 * s + 6], sacc[8 * s + 7]));
+            // A operand = V^T (row = head dim l31): element j of this lane is key 32t + 16s + 8(j>>2) + 4hh + (j&3)
+            const uint2 lo = lds_read_tr16(Vi + t * BLK + 16 * s * DP + t_off[0]), hi = lds_read_tr16(Vi + t * BLK + 16 * s * DP + t_off[1]);
+            oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y)), as_bf16x8(pb), oacc, 0, 0, 0);
+        }
+    };
+    // the denominator is row 31 of O^T: register 15 of the upper lane half, handed to both halves
+    auto denominator = [&]() -> float {
+        const unsigned si = __float_as_uint(oacc[15]);
+        const auto r = __builtin_amdgcn_permlane32_swap(si, si, false, false);
+        return __uint_as_float(r[1]);
+    };
+
+    // ---- the optimistic pass: r = row maximum of the first key tile, no maximum after that ---------------------
+    // Exact whatever r is as long as nothing overflows: exp2(S - r) reaches 2^100 only when a later logit exceeds
+    // every logit of the first tile by 100 (base 2), which the check on the denominator below catches.
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    rref = 0.f;
+    {
+        f32x16 sacc;
+        scores(0, sacc);
+        const float sh = set_reference(row_max(sacc));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] -= sh;
+        accumulate(0, sacc);
+    }
+#pragma unroll
+    for (int t = 1; t < NT; ++t) {
+        f32x16 sacc;
+        scores(t, sacc);
+        accumulate(t, sacc);
+    }
+    float sum = denominator();
+    if (__builtin_amdgcn_ballot_w64(!(sum < 0x1p100f)) != 0) {  // uniform; not taken on ordinary logits
+        // ---- the careful pass: the reference follows the running maximum (raised when a tile exceeds it by 2^8) ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+        rref = 0.f;
+        if (hh) qfb[1].w = 0u;
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            f32x16 sacc;
+            scores(t, sacc);
+            const float tm = row_max(sacc);
+            if (t == 0 || __builtin_amdgcn_ballot_w64(tm > FWD_W16_RAISE) != 0) {
+                const float sh = set_reference(rref + (t == 0 ? tm : fmaxf(tm, 0.f)));
+                const float alpha = __builtin_amdgcn_exp2f(-sh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] -= sh;
+                    oacc[r] *= alpha;
+                }
+            }
+            accumulate(t, sacc);
+        }
+        sum = denominator();
+    }
+
+    // ---- epilogue: normalise, store -----------------------------------------------------------------------------
+    const float inv = 1.0f / sum;
+    if (hh == 0) lse[((size_t)win * g.heads + head) * L + qrow] = (rref + __builtin_amdgcn_logf(sum)) * LN2;
+    // registers 4g..4g+3 are head-dim columns 8g + 4hh ..+3; after the exchange the lower half holds columns
+    // 0-7 and 16-23 of its token, the upper half 8-15 and 24-31
+    uint32_t pk[4][2];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        pk[g4][0] = pack_bf16(oacc[4 * g4] * inv, oacc[4 * g4 + 1] * inv);
+        pk[g4][1] = pack_bf16(oacc[4 * g4 + 2] * inv, oacc[4 * g4 + 3] * inv);
+    }
+    uint4 slot[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p][0], pk[2 * p + 1][0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p][1], pk[2 * p + 1][1], false, false);
+        slot[p] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+    // the upper half's second slot is columns 24-31, of which 30 and 31 are not the token's: it leaves as columns
+    // 22-29, with columns 22 and 23 (this lane's own before the exchange: registers 10, 11) written a second time
+    if (hh) slot[1] = make_uint4(pk[2][1], slot[1].x, slot[1].y, slot[1].z);
+    T *orow = out + origin * C + head * D;
+    const unsigned orel = rel_row(qrow) * C + 8 * hh;
+    store16_a4(orow + orel, slot[0]);
+    store16_a4(orow + (orel + 16 - 2 * hh), slot[1]);
+    if (head == g.heads - 1 && C > g.C) {  // this wave's share of the output rows' padding columns
+        // (C and g.C are even: whole dwords; a lane takes every other dword of its token's padding)
+        const int np2 = (C - g.C) >> 1;
+        T *prow = out + (origin + rel_row(qrow)) * C + g.C;
+        for (int j = hh; j < np2; j += 2) *reinterpret_cast<uint32_t *>(prow + 2 * j) = 0u;
+    }
+}
+
+int launch_fwd_w16(const AttnGeom &g, const void *qkv, const float *table, float scale, void *out, float *lse, hipStream_t st) {
+    // head dim 30 (the two last columns of the padded head dim are taken), 4-byte-aligned rows
+    if (g.d != 30 || ((g.ldq | g.ldo) & 1)) return -1;
+    const bool bias = table != nullptr;
+    const dim3 grid(g.n_win * g.heads), block(FwdW16Cfg::THREADS);
+    const size_t lds = FwdW16Cfg::lds_bytes(bias);
+    if (bias) hipLaunchKernelGGL(win_attn_fwd_w16_kernel<true>, grid, block, lds, st, g, (const bf16_t *)qkv, table, scale, (bf16_t *)out, lse);
+    else hipLaunchKernelGGL(win_attn_fwd_w16_kernel<false>, grid, block, lds, st, g, (const bf16_t *)qkv, table, scale, (bf16_t *)out, lse);
+    return check_launch("win_attn_fwd_w16_kernel");
+}
+
+}  // namespace dsw
