@@ -410,8 +410,382 @@ __global__ __launch_bounds__(512, (DP == 32 ? 4 : 2)) void win_attn_bwd_w16_kern
     }
 }
 
+// ======================================================================================================
+// The same two phases for head dim 30 (the DSWT shape), with less work for the vector unit around them:
+//  * a head's slice of a token row moves as 16-byte slots (the last one read and written as the 16 bytes that END
+//    with the slice and shifted in registers, see attn_fwd_w16.hip), 10 loads per thread instead of 40;
+//  * a wave reads the K and V fragments of its own key tile from global memory straight into the B operand
+//    registers; only Q' and dO' are staged (delta by v_dot2c_f32_bf16 and two quad-wide DPP adds), one barrier;
+//  * the row constants sit in columns 30, 31 of the padded head dim whatever the slice holds;
+//  * both loops are unrolled: every LDS address is a lane constant plus an immediate;
+//  * d(bias table): the diagonal sums of a tile are added to tables in LDS - one per wave and lane half, so that no
+//    two lanes of an instruction meet in an entry - by a read, an add and a write, four of each per tile, instead
+//    of being finished across lanes (45 vector instructions per tile); ds_add_f32 would do it in one instruction
+//    but takes about a hundred LDS cycles;
+//  * phase 2 reads its bias values from a mirrored copy of the table, ascending like phase 1's;
+//  * dK, dV and dQ leave from the accumulators (lane halves exchange columns, two 16-byte stores per lane).
+struct Bwd30Cfg {
+    static constexpr int WS = 16, L = 256, DP = 32, NT = 8, NW = 8, THREADS = 512, D = 30;
+    static constexpr int N_BUF = L * DP;
+    static constexpr int TBF = bias_lds<16>::FLOATS;
+    // per-wave d(table), one for each lane half: [qi - ki_local + 1][column], 32 columns a row with the two halves of
+    // 16 swapped in odd rows (the two key rows of a tile go to neighbouring rows: 16 banks apart)
+    static constexpr int BG_STRIDE = 32, BG_ROWS = 17, BG_HALF = BG_STRIDE * BG_ROWS, BG_FLOATS = 2 * BG_HALF;
+    static constexpr size_t lds_bytes(bool bias) {
+        return (size_t)2 * N_BUF * sizeof(bf16_t) + (bias ? (size_t)(2 * TBF + NW * BG_FLOATS) * sizeof(float) : 0);
+    }
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_add_quad(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, a), __builtin_bit_cast(bf16x2_hw, b), acc, false);
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
+    AttnGeom g, const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out, const bf16_t *__restrict__ dout,
+    const float *__restrict__ table, float scale, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
+    float *__restrict__ ws_table) {
+    using Cfg = Bwd30Cfg;
+    using T = bf16_t;
+    constexpr int WS = 16, L = Cfg::L, NT = Cfg::NT, NW = Cfg::NW, THREADS = Cfg::THREADS, DP = Cfg::DP, D = Cfg::D;
+    constexpr int TS = bias_lds<WS>::TS, TBF = Cfg::TBF, TR = bias_lds<WS>::ROWS, TMAX = (2 * WS - 2) * (TS + 1);
+    constexpr int BGS = Cfg::BG_STRIDE, BGF = Cfg::BG_FLOATS;
+    constexpr int BLK = 32 * DP;  // elements of a 32-row block of an operand image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *bufA = reinterpret_cast<T *>(smem);  // phase 1: Q' (scaled, augmented)   phase 2: K (augmented)
+    T *bufB = bufA + Cfg::N_BUF;            // phase 1: dO' (augmented)          phase 2: V (augmented)
+    float *tb = reinterpret_cast<float *>(bufB + Cfg::N_BUF);  // BIAS: entry e at e
+    float *tbm = tb + TBF;                                     // BIAS: entry e at TMAX - e
+    float *bgw = tbm + TBF;                                    // BIAS: [NW][BGF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int C = g.ldo, CG = g.ldg, C3 = g.ldq;
+    const float sc2 = scale * LOG2E;
+    const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
+    // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
+    const int win = __builtin_amdgcn_readfirstlane(id / g.heads), head = id - win * g.heads;
+    int qoff, koff, voff;
+    qkv_offsets(g, head, qoff, koff, voff);
+    size_t origin;
+    int pitch;
+    if (g.H == 0) {
+        origin = (size_t)win * L;
+        pitch = WS;
+    } else {
+        const int per = g.nWh * g.nWw;
+        const int b = __builtin_amdgcn_readfirstlane(win / per), r = win - b * per;
+        const int wr = __builtin_amdgcn_readfirstlane(r / g.nWw), wc = r - wr * g.nWw;
+        origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
+        pitch = g.W;
+    }
+    if (window_is_off(g, win)) {  // uniform over the workgroup: zero gradients, nothing read
+        zero_window_slice<T>(dqkv, C3, origin, pitch, WS, qoff, D, false, 0, tid, THREADS);
+        zero_window_slice<T>(dqkv, C3, origin, pitch, WS, koff, D, false, 0, tid, THREADS);
+        zero_window_slice<T>(dqkv, C3, origin, pitch, WS, voff, D, head == g.heads - 1, 3 * g.C, tid, THREADS);
+        if constexpr (BIAS)
+            for (int it = tid; it < TR * TR; it += THREADS) ws_table[((size_t)win * g.heads + head) * (TR * TR) + it] = 0.f;
+        return;
+    }
+    auto rel_row = [&](int l) -> unsigned { return (unsigned)((l >> 4) * pitch + (l & 15)); };
+    const T *qkv0 = qkv + origin * C3;  // wave-uniform 64-bit bases, 32-bit lane offsets
+    const T *dout0 = dout + origin * CG + head * D, *out0 = out + origin * C + head * D;
+    const float *lse0 = lse + ((size_t)win * g.heads + head) * L;
+
+    // ---- loads -----------------------------------------------------------------------------------------------
+    // this wave's key tile: K and V fragments (slots hh and 2 + hh of row 32 wave + l31), the B operands of phase 1
+    const int krow = 32 * wave + l31;
+    const unsigned krel = rel_row(krow);
+    uint4 kfb[2], vfb[2];
+    {
+        const unsigned e0 = krel * C3 + 8 * hh;
+        kfb[0] = load16_a4(qkv0 + (e0 + koff));
+        vfb[0] = load16_a4(qkv0 + (e0 + voff));
+        kfb[1] = load16_a4(qkv0 + (e0 + koff + 16 - 2 * hh));
+        vfb[1] = load16_a4(qkv0 + (e0 + voff + 16 - 2 * hh));
+    }
+    // Q, dO, O and lse of two rows per thread, a slot each
+    const int sc = tid & 3;
+    const bool slast = sc == 3;
+    uint4 qv[2], gv[2], ov[2];
+    float lsev[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 128 * i;
+        const unsigned rel = rel_row(row), e0 = 8 * sc - (slast ? 2 : 0);
+        qv[i] = load16_a4(qkv0 + (rel * C3 + qoff + e0));
+        gv[i] = load16_a4(dout0 + (rel * CG + e0));
+        ov[i] = load16_a4(out0 + (rel * C + e0));
+        lsev[i] = lse0[row];
+    }
+    if constexpr (BIAS) {
+        for (int it = tid; it < TR * TR; it += THREADS) {
+            const int di = it / TR, dj = it - di * TR;
+            const float v = table[(size_t)it * g.heads + head] * LOG2E;
+            tb[di * TS + dj] = v;
+            tbm[TMAX - (di * TS + dj)] = v;
+        }
+        // this wave's d(table): zero
+        float4 *z = reinterpret_cast<float4 *>(bgw + wave * BGF);
+        for (int i = lane; i < BGF / 4; i += 64) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (hh) {  // columns 24-31 arrived as 22-29: shift, ones in the two last columns
+        kfb[1] = make_uint4(kfb[1].y, kfb[1].z, kfb[1].w, 0x3F803F80u);
+        vfb[1] = make_uint4(vfb[1].y, vfb[1].z, vfb[1].w, 0x3F803F80u);
+    }
+    // ---- Q' (times scale * log2 e, -lse in columns 30, 31) and dO' (-delta there) into the images -----------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 128 * i;
+        if (slast) {
+            qv[i] = make_uint4(qv[i].y, qv[i].z, qv[i].w, 0u);
+            gv[i] = make_uint4(gv[i].y, gv[i].z, gv[i].w, 0u);
+            ov[i] = make_uint4(ov[i].y, ov[i].z, ov[i].w, 0u);
+        }
+        // delta = rowsum(dO * O): 8 elements here, then the four lanes of the row
+        float part = dot2_bf16(ov[i].x, gv[i].x, 0.f);
+        part = dot2_bf16(ov[i].y, gv[i].y, part);
+        part = dot2_bf16(ov[i].z, gv[i].z, part);
+        part = dot2_bf16(ov[i].w, gv[i].w, part);
+        part = dpp_add_quad<0xB1>(part);  // quad_perm [1,0,3,2]
+        part = dpp_add_quad<0x4E>(part);  // quad_perm [2,3,0,1]
+        const uint32_t in[4] = {qv[i].x, qv[i].y, qv[i].z, qv[i].w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack_bf16(__uint_as_float(in[j] << 16) * sc2, __uint_as_float(in[j] & 0xffff0000u) * sc2);
+        if (slast) {
+            o[3] = bf16_hi_lo(-lsev[i] * LOG2E);
+            gv[i].w = bf16_hi_lo(-part);
+        }
+        const int off = img<DP>(row, 8 * sc);
+        *reinterpret_cast<uint4 *>(bufA + off) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(bufB + off) = gv[i];
+    }
+    // per-lane LDS offsets (elements) inside a 32-row block of an image
+    int a_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a_off[s] = img<DP>(l31, 16 * s + 8 * hh);
+    // transposing reads: lane 4q+p of a 16-lane group passes row q, columns 4p..4p+3; rows +0 / +8 of a 16-row step
+    const int trq = (lane >> 2) & 3, trp = lane & 3, trg = (lane >> 4) & 1;
+    int t_off[2];
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) t_off[h8] = img<DP>(4 * hh + trq + 8 * h8, 16 * trg + 4 * trp);
+
+    f32x16 dKacc, dVacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        dKacc[r] = 0.f;
+        dVacc[r] = 0.f;
+    }
+    lds_barrier();  // Q', dO', the bias tables are in LDS; every wave's d(table) is zero
+
+    // =================== phase 1: key on the lane; dK^T, dV^T, d(bias table) ===================
+    {
+        const int ki = krow >> 4, kj = krow & 15;
+        // table entry of (q, key): (qi-ki+15)*TS + (qj-kj+15); q = qb*32 + rho(r) + 4hh
+        const int seed_base = (WS - 1) * (TS + 1) - ki * TS - kj + 4 * hh;
+        // d(table) entry of this lane's sums: table (wave, hh), row 2qb + G - kip + 1, column 15 - m (sum A: dj = 4hh - m)
+        // or 31 - m (sum B: dj = 16 + 4hh - m); odd rows keep their two column halves swapped.  Two lane addresses
+        // serve all four: x (sum A of G = 0, sum B of G = 1 a row further on) and x ^ 16 (the other two).
+        const int kip = (lane >> 4) & 1;
+        const int x0 = wave * BGF + hh * Cfg::BG_HALF + (1 - kip) * BGS + ((15 - (lane & 15)) ^ ((1 - kip) << 4));
+        float *px = bgw + x0, *py = bgw + (x0 ^ 16);
+#pragma unroll
+        for (int qb = 0; qb < NT; ++qb) {
+            const T *blkA = bufA + qb * BLK, *blkB = bufB + qb * BLK;
+            f32x16 sacc, pacc;
+            if constexpr (BIAS) {
+                // (the tile's first entry, counted from the start of LDS, goes through an empty asm: one address
+                // register per tile and small immediates, instead of one register per read, all computed up front)
+                int tile_base = (int)(tb - reinterpret_cast<float *>(smem)) + seed_base + 2 * qb * TS;
+                asm volatile("" : "+v"(tile_base));
+                const float *tp = reinterpret_cast<const float *>(smem) + tile_base;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = tp[(rho(r) >> 4) * TS + (rho(r) & 15)];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+            // S' = Q' K^T (base 2, lse and bias included), dP' = dO' V^T (delta included)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint4 qa = *reinterpret_cast<const uint4 *>(blkA + a_off[s]);
+                const uint4 ga = *reinterpret_cast<const uint4 *>(blkB + a_off[s]);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(qa), as_bf16x8(kfb[s]), sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ga), as_bf16x8(vfb[s]), pacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sacc[r]);
+                sacc[r] = p;
+                pacc[r] = p * pacc[r];
+            }
+            if constexpr (BIAS) {
+                float sa[2] = {0.f, 0.f}, sb[2] = {0.f, 0.f};
+                diag_sums2(std::make_integer_sequence<int, 16>{}, pacc, sa, sb);
+                px[2 * qb * BGS] += sa[0];
+                py[2 * qb * BGS] += sb[0];
+                py[(2 * qb + 1) * BGS] += sa[1];
+                px[(2 * qb + 1) * BGS] += sb[1];
+            }
+            // dV^T += dO^T P, dK^T += Q^T dS (sum over the accumulator rows = queries).  Registers 8s..8s+7 of
+            // a lane are queries 16s + 8(j>>2) + 4hh + (j&3): the A operands take the same order from two
+            // transposing reads of the row-major images.
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint4 pb = make_uint4(pack_bf16(sacc[8 * s + 0], sacc[8 * s + 1]), pack_bf16(sacc[8 * s + 2], sacc[8 * s + 3]),
+                                            pack_bf16(sacc[8 * s + 4], sacc[8 * s + 5]), pack_bf16(sacc[8 * s + 6], sacc[8 * s + 7]));
+                const uint4 db = make_uint4(pack_bf16(pacc[8 * s + 0], pacc[8 * s + 1]), pack_bf16(pacc[8 * s + 2], pacc[8 * s + 3]),
+                                            pack_bf16(pacc[8 * s + 4], pacc[8 * s + 5]), pack_bf16(pacc[8 * s + 6], pacc[8 * s + 7]));
+                const uint2 g0 = lds_read_tr16(blkB + 16 * s * DP + t_off[0]), g1 = lds_read_tr16(blkB + 16 * s * DP + t_off[1]);
+                const uint2 q0 = lds_read_tr16(blkA + 16 * s * DP + t_off[0]), q1 = lds_read_tr16(blkA + 16 * s * DP + t_off[1]);
+                dVacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(g0.x, g0.y, g1.x, g1.y)), as_bf16x8(pb), dVacc, 0, 0, 0);
+                dKacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(q0.x, q0.y, q1.x, q1.y)), as_bf16x8(db), dKacc, 0, 0, 0);
+            }
+        }
+    }
+    // phase 2's B operands: this wave's own query block, rows of Q' and dO' (column = query on the lane)
+    uint4 qfb[2], gfb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        qfb[s] = *reinterpret_cast<const uint4 *>(bufA + wave * BLK + a_off[s]);
+        gfb[s] = *reinterpret_cast<const uint4 *>(bufB + wave * BLK + a_off[s]);
+    }
+    lds_barrier();  // nobody reads Q' / dO' any more; every wave's d(table) is complete
+
+    // An accumulator (rows = head dim in registers 4g..4g+3 = columns 8g + 4hh ..+3, lane = token 32 wave + l31)
+    // leaves as two 16-byte slots per lane: the lane halves exchange columns so that the lower half holds columns
+    // 0-7 and 16-23, the upper half 8-15 and 24-31; the upper half's second slot, of which columns 30 and 31 are
+    // not the token's, leaves as columns 22-29 (22 and 23, its own before the exchange, written a second time).
+    auto store_acc = [&](const f32x16 &acc, float mul, int col0) {
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            pk[g4][0] = pack_bf16(acc[4 * g4] * mul, acc[4 * g4 + 1] * mul);
+            pk[g4][1] = pack_bf16(acc[4 * g4 + 2] * mul, acc[4 * g4 + 3] * mul);
+        }
+        uint4 slot[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p][0], pk[2 * p + 1][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p][1], pk[2 * p + 1][1], false, false);
+            slot[p] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+        if (hh) slot[1] = make_uint4(pk[2][1], slot[1].x, slot[1].y, slot[1].z);
+        T *dst = dqkv + origin * C3;
+        const unsigned e0 = krel * C3 + col0 + 8 * hh;
+        store16_a4(dst + e0, slot[0]);
+        store16_a4(dst + (e0 + 16 - 2 * hh), slot[1]);
+    };
+    store_acc(dKacc, LN2, koff);  // Q' carries scale * log2(e): dK = Q'^T dS * ln 2
+    store_acc(dVacc, 1.f, voff);
+    // K and V into LDS for phase 2, straight from the B-operand registers (16 bytes = one slot per register)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        *reinterpret_cast<uint4 *>(bufA + wave * BLK + a_off[s]) = kfb[s];
+        *reinterpret_cast<uint4 *>(bufB + wave * BLK + a_off[s]) = vfb[s];
+    }
+    if constexpr (BIAS) {
+        // the table entered the logits times log2(e) inside exp2, so d/dtable is dS itself.  Entry (di, dj):
+        // wave wv holds it in row di + 2*wv + 1 of its table when that row exists.
+        float *dst = ws_table + ((size_t)win * g.heads + head) * (TR * TR);
+        for (int it = tid; it < TR * TR; it += THREADS) {
+            const int di = it / TR - (WS - 1), dj = it - (it / TR) * TR;
+            float acc = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) {
+                const int row = di + 2 * wv + 1;
+                // lower lane half: dj index = column; upper half: its columns are 4 further on in dj
+                if (row >= 0 && row < Cfg::BG_ROWS) {
+                    const float *t0 = bgw + wv * BGF + row * BGS, *t1 = t0 + Cfg::BG_HALF;
+                    const int sw = (row & 1) << 4;
+                    acc += t0[dj ^ sw];  // (dj <= 30)
+                    if (dj >= 4) acc += t1[(dj - 4) ^ sw];
+                }
+            }
+            dst[it] = acc;
+        }
+    }
+    if (head == g.heads - 1 && C3 > 3 * g.C) {  // the padding columns of this window's dqkv rows (an even count)
+        const int np2 = (C3 - 3 * g.C) >> 1;    // dwords per row; two threads share a row
+        T *prow = dqkv + (origin + rel_row(tid >> 1)) * C3 + 3 * g.C;
+        for (int j = tid & 1; j < np2; j += 2) *reinterpret_cast<uint32_t *>(prow + 2 * j) = 0u;
+    }
+    lds_barrier();  // K, V are in LDS
+
+    // =================== phase 2: query on the lane; dQ^T ===================
+    f32x16 dQacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQacc[r] = 0.f;
+    {
+        // key of register r: kt*32 + rho(r) + 4hh  ->  entry e = (qi-ki+15)*TS + (qj-kj+15), read at TMAX - e
+        const int seed_base = TMAX - (((krow >> 4) + WS - 1) * TS + (krow & 15) + (WS - 1) - 4 * hh);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const T *blkA = bufA + kt * BLK, *blkB = bufB + kt * BLK;
+            f32x16 sacc, pacc;
+            if constexpr (BIAS) {
+                int tile_base = (int)(tbm - reinterpret_cast<float *>(smem)) + seed_base + 2 * kt * TS;
+                asm volatile("" : "+v"(tile_base));
+                const float *tp = reinterpret_cast<const float *>(smem) + tile_base;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = tp[(rho(r) >> 4) * TS + (rho(r) & 15)];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint4 ka = *reinterpret_cast<const uint4 *>(blkA + a_off[s]);
+                const uint4 va = *reinterpret_cast<const uint4 *>(blkB + a_off[s]);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka), as_bf16x8(qfb[s]), sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(va), as_bf16x8(gfb[s]), pacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[r] = __builtin_amdgcn_exp2f(sacc[r]) * pacc[r];
+            // dQ^T += K^T dS^T (sum over the accumulator rows = keys)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint4 db = make_uint4(pack_bf16(pacc[8 * s + 0], pacc[8 * s + 1]), pack_bf16(pacc[8 * s + 2], pacc[8 * s + 3]),
+                                            pack_bf16(pacc[8 * s + 4], pacc[8 * s + 5]), pack_bf16(pacc[8 * s + 6], pacc[8 * s + 7]));
+                const uint2 k0 = lds_read_tr16(blkA + 16 * s * DP + t_off[0]), k1 = lds_read_tr16(blkA + 16 * s * DP + t_off[1]);
+                dQacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(k0.x, k0.y, k1.x, k1.y)), as_bf16x8(db), dQacc, 0, 0, 0);
+            }
+        }
+    }
+    store_acc(dQacc, scale, qoff);
+}
+
+// DSW_ATTN_BWD_W16_OLD=1 in the environment keeps head dim 30 on the kernel for any even head dim (tests compare the two)
+static bool force_old_two_phase() {
+    const char *e = getenv("DSW_ATTN_BWD_W16_OLD");
+    return e != nullptr && e[0] == '1';
+}
+
 int launch_bwd_w16_two_phase(const AttnGeom &g, const void *qkv, const void *out, const void *dout, const float *table,
                              float scale, const float *lse, void *dqkv, float *ws_table, hipStream_t st) {
+    if (g.d == 30 && ((g.ldq | g.ldo | g.ldg) & 1) == 0 && !force_old_two_phase()) {
+        const bool bias = table != nullptr;
+        const dim3 grid(g.n_win * g.heads), block(512);
+        const size_t lds = Bwd30Cfg::lds_bytes(bias);
+        if (bias) {
+            auto kern = win_attn_bwd_w16_d30_kernel<true>;
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(DSW_ELAUNCH, "win_attn_bwd: LDS attribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(kern, grid, block, lds, st, g, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, table, scale, lse,
+                               (bf16_t *)dqkv, ws_table);
+        } else {
+            hipLaunchKernelGGL(win_attn_bwd_w16_d30_kernel<false>, grid, block, lds, st, g, (const bf16_t *)qkv, (const bf16_t *)out,
+                               (const bf16_t *)dout, table, scale, lse, (bf16_t *)dqkv, ws_table);
+        }
+        return check_launch("win_attn_bwd_w16_d30_kernel");
+    }
     const int DPv = g.d > 32 ? 64 : 32;
     // pairs of bf16 per lane (even head dim and row strides); two padding columns for the row constants
     if ((g.d & 1) || ((g.ldq | g.ldo | g.ldg) & 1) || g.d > DPv - 2 || g.d < 2) return -1;

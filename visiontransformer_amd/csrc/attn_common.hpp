@@ -203,6 +203,16 @@ __device__ __forceinline__ void store_slot(bf16_t *p, uint4 v, int cnt) {
         *reinterpret_cast<uint32_t *>(p) = v.x;
     }
 }
+// 8 consecutive bf16 at a 4-byte-aligned address
+__device__ __forceinline__ uint4 load16_a4(const bf16_t *p) {
+    const u32x4_a4 t = *reinterpret_cast<const u32x4_a4 *>(p);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void store16_a4(bf16_t *p, uint4 v) {
+    u32x4_a4 t;
+    t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
+    *reinterpret_cast<u32x4_a4 *>(p) = t;
+}
 // dwords of slot c (8 elements each) that lie inside a slice of d elements (d even)
 __device__ __forceinline__ int slot_dwords(int d, int c) {
     const int n = (d >> 1) - 4 * c;

@@ -31,16 +31,6 @@ struct FwdW16Cfg {
 
 constexpr float FWD_W16_RAISE = 8.f;  // the reference is raised when a logit exceeds it by more than this (base 2)
 
-// 8 consecutive bf16 at a 4-byte-aligned address
-__device__ __forceinline__ uint4 load16_a4(const bf16_t *p) {
-    const u32x4_a4 t = *reinterpret_cast<const u32x4_a4 *>(p);
-    return make_uint4(t.x, t.y, t.z, t.w);
-}
-__device__ __forceinline__ void store16_a4(bf16_t *p, uint4 v) {
-    u32x4_a4 t;
-    t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
-    *reinterpret_cast<u32x4_a4 *>(p) = t;
-}
 // The head dim is 30: a head's slice of a token row is three whole 16-byte slots and one of 12 bytes.  The last
 // slot is read (and written) as the 16 bytes that END with the slice - one dword early, so that no byte outside the
 // slice is touched - and shifted in registers; its fourth dword, columns 30 and 31 of the padded head dim, is ours.
@@ -150,11 +140,12 @@ __global__ __launch_bounds__(512, 8) void win_attn_fwd_w16_kernel(AttnGeom g, co
     auto seeds = [&](int t, f32x16 &sacc) {
         // (the tile's base goes through an empty asm: one address register for the whole pass instead of one per
         // reach of the reads' 8-bit offsets, all of them computed up front and kept alive)
-        int tile_base = lane_base + 2 * TS * t;
+        int tile_base = (int)(tb - reinterpret_cast<float *>(smem)) + lane_base + 2 * TS * t;
         asm volatile("" : "+v"(tile_base));
+        const float *tp = reinterpret_cast<const float *>(smem) + tile_base;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if constexpr (BIAS) sacc[r] = tb[tile_base + ((rho(r) >> 4) * TS + (rho(r) & 15))];
+            if constexpr (BIAS) sacc[r] = tp[(rho(r) >> 4) * TS + (rho(r) & 15)];
             else sacc[r] = 0.f;
         }
     };
