@@ -103,6 +103,10 @@ def test_unsupported_options_are_refused():
     w[0].grad = torch.ones(3)
     with pytest.raises(RuntimeError):
         o.step()
+    # beta1 <= 0.5: torch's lerp takes its other form there, which the kernel does not follow
+    o = optim.Adam(w, betas=(0.5, 0.99))
+    with pytest.raises(RuntimeError):
+        o.step()
 
 
 SIZES = [0, 1, 3, 4, 5, 2047, 2048, 2049, 70001] + [17 + 13 * i for i in range(140)]     # more than two launches' worth

@@ -181,6 +181,36 @@ def _worker(rank, world, port, q):
     sp(x).square().mean().backward()
     ok_flat = ok_flat and torch.equal(sp.module.spare.grad, torch.zeros(5)) \
         and torch.allclose(sp.module.net.a.weight.grad, single.a.weight.grad, atol=1e-6)
+    # a backward pass that raises after the output hook has fired (every rank alike, e.g. an out-of-memory error the
+    # trainer catches and skips) never runs its end-of-pass callback; the next pass must still average its gradients
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    class _Fragile(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = _ToySR()
+            self.fail = False
+
+        def forward(self, t):
+            return self.net(_Boom.apply(t) if self.fail else t)
+    fr = parallel.FlatDataParallel(_Fragile())
+    fr.module.fail = True
+    raised = False
+    try:
+        fr(x.clone().requires_grad_()).square().mean().backward()
+    except RuntimeError:
+        raised = True
+    fr.module.fail = False
+    fr.zero_grad(set_to_none=True)
+    fr(x).square().mean().backward()
+    ok_flat = ok_flat and raised and torch.allclose(fr.module.net.a.weight.grad, single.a.weight.grad, atol=1e-6)
     q.put((rank, ok_tiles, ok_grad and ok_flat))
     dist.barrier()
     dist.destroy_process_group()

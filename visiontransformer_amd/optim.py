@@ -106,6 +106,12 @@ class Adam(torch.optim.Adam):
                 or group.get("differentiable") or group.get("fused") or group.get("decoupled_weight_decay"):
             raise RuntimeError("visiontransformer_amd.optim.Adam: a param group asks for weight_decay, amsgrad, maximize, "
                                "capturable, differentiable, fused or decoupled_weight_decay; none is supported")
+        # the kernel's first-moment update is fma(1 - beta1, g - m, m), the form torch's lerp takes for a weight below
+        # 0.5; at 1 - beta1 >= 0.5 torch computes g - (g - m) * beta1 instead and the two are no longer bit-identical
+        if not float(group["betas"][0]) > 0.5:
+            raise RuntimeError("visiontransformer_amd.optim.Adam: beta1 = %r: the fused update follows torch bit for bit only "
+                               "for beta1 > 0.5 (the reference trains with 0.9); use torch.optim.Adam for such a group"
+                               % (group["betas"][0],))
 
     @staticmethod
     def _dense(p):

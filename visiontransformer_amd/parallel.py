@@ -82,7 +82,7 @@ class FlatDataParallel(torch.nn.Module):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self._sync = True
-        self._armed = False
+        self._armed_task = None   # id of the backward pass (graph task) whose end-of-pass callback is queued
         params = [p for p in module.parameters() if p.requires_grad]
         with torch.no_grad():       # same start on every rank, as DistributedDataParallel's constructor does
             for t in list(module.parameters()) + list(module.buffers()):
@@ -131,14 +131,18 @@ class FlatDataParallel(torch.nn.Module):
         return out
 
     def _arm(self, grad):
-        if not self._armed:
-            self._armed = True
+        # One callback per backward pass.  The state is the id of the pass, not a flag: a pass that raises after this
+        # hook has fired never runs its callback, and a flag left set by it would keep every later pass from
+        # queueing one (gradients no longer averaged, no error).
+        task = torch._C._current_graph_task_id()
+        if self._armed_task != task:
+            self._armed_task = task
             torch.autograd.Variable._execution_engine.queue_callback(self._reduce)
         return None
 
     @torch.no_grad()
     def _reduce(self):
-        self._armed = False
+        self._armed_task = None
         for flat, ps, views in self._sets:
             dst, src = [], []
             for p, v in zip(ps, views):
