@@ -40,7 +40,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 B_PER_GPU, HW, C, HEADS, WIN = 32, 64, 180, 6, 16
 # the kernel `roofline` is about, as rocprofv3 names it: window-attention backward at the WindowedMSA shape
-DOMINANT_KERNEL = "win_attn_bwd_w16_kernel<32, true>"
+DOMINANT_KERNEL = "win_attn_bwd_w16_d30_kernel<true>"
 
 
 def build_pair(device, seed=0):
@@ -104,13 +104,21 @@ def _attention_rooflines(device, iters, warm, out):
     T = B_PER_GPU * HW * HW
     bf = torch.bfloat16
     table = torch.randn((2 * WIN - 1) ** 2, HEADS, device=device) * 0.02
-    # windowed MSA shape: all 512 windows, image grid addressing
-    qkv = torch.randn(B_PER_GPU, HW, HW, 3 * C, device=device).to(bf).requires_grad_()
+    # windowed MSA shape: all 512 windows, image grid addressing, on the row pitches the modules hand the kernels
+    # (functional.linear(..., pad_out=True) leaves q|k|v rows of 576 elements, the attention's output and the
+    # gradient coming back from out_proj rows of 192)
+    P3, P1 = K._ceil_pad(3 * C), K._ceil_pad(C)
+    qbuf = K._mark_padded(torch.zeros(T, P3, device=device, dtype=bf))
+    qbuf[:, :3 * C] = torch.randn(T, 3 * C, device=device).to(bf)
+    qkv = qbuf[:, :3 * C].view(B_PER_GPU, HW, HW, 3 * C).requires_grad_()
     tab = table.clone().requires_grad_()
-    o = K.window_attention(qkv, tab, WIN, HEADS, QKV_INTERLEAVED, grid=(B_PER_GPU, HW, HW))
-    do = torch.randn_like(o)
-    t_f = time_calls(lambda: K.window_attention(qkv.detach(), table, WIN, HEADS, QKV_INTERLEAVED,
-                                                grid=(B_PER_GPU, HW, HW)), iters, warm)
+    o = K.window_attention(qkv, tab, WIN, HEADS, QKV_INTERLEAVED, grid=(B_PER_GPU, HW, HW), pad_out=True)
+    gbuf = torch.zeros(T, P1, device=device, dtype=bf)
+    gbuf[:, :C] = torch.randn(T, C, device=device).to(bf)
+    do = gbuf[:, :C].view(B_PER_GPU, HW, HW, C)
+    with torch.no_grad():
+        t_f = time_calls(lambda: K.window_attention(qkv, table, WIN, HEADS, QKV_INTERLEAVED, grid=(B_PER_GPU, HW, HW), pad_out=True),
+                         iters, warm)
     t_b = time_calls(lambda: torch.autograd.grad(o, (qkv, tab), do, retain_graph=True), iters, warm)
     flops_f, flops_b = 4.0 * T * L * C, 8.0 * T * L * C
     # algorithmic HBM bytes (bf16): forward reads qkv, writes out (+ lse); backward reads qkv, out, dout
@@ -121,7 +129,9 @@ def _attention_rooflines(device, iters, warm, out):
     by_b = T * (3 * C + C + C + 3 * C) * 2 + T * HEADS * 4
     for name, t, fl, by in (("win_attn_fwd", t_f, flops_f, by_f), ("win_attn_bwd", t_b, flops_b, by_b)):
         out[name] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t * 1e6, algorithmic=by,
-                         flops=fl, mfma_tflops=fl / t / 1e12, mfma_frac=fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS)
+                         flops=fl, mfma_tflops=fl / t / 1e12, mfma_frac=fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                         row_pitch="q|k|v %d, out / dout %d elements (what the modules use)" % (P3, P1))
+    out["win_attn_bwd"]["note"] = "attention backward kernel + the fixed-order sum of the bias table's partials"
     # inference: q|k|v projection inside the attention kernel (q|k|v never written).  Reads the padded bf16 rows of
     # x, writes out; the projection's 2*T*C*3C flops join the attention's (the kernel itself multiplies the padded
     # 192 x 3*32*heads operands).  Its intensity, (4*L*C + 6*C*C) / (2*C*2) = 346 flop/byte, is above the machine's
@@ -279,6 +289,82 @@ def cpu_baseline(sample_batch=8, budget_s=15.0):
                        "fwd+bwd, batch %d of 64x64x180, %d iters, %.2f s/iter" % (sample_batch, iters, dt))
 
 
+def train_network(device, rank, world, grouped, steps=5, warm=3):
+    """Whole-network x4 training steps, what toolkit/init.py:131 + toolkit/model_helper2.py:105-131 run: the DSWT
+    default network and MSFT at the headline configuration (dim 192, 2 levels, 8x8 windows, attention dropout 0.1),
+    batch 32 of 64x64 LR patches per GPU, bf16 autocast, L1 loss, the package's Adam; at N > 1 under
+    DistributedDataParallel as parallel.data_parallel builds it (RCCL, 25 MB buckets overlapping the backward pass,
+    gradients as views of the buckets).  patches/s over all ranks, time = max over ranks, barriers both sides."""
+    import gc
+    import torch.distributed as dist
+    from visiontransformer_amd import models, optim, parallel
+    res = {}
+    for name, build in (("dswt_default", lambda: models.DSWTransformer(**models.DSWT_DEFAULT)),
+                        ("msft_config_c", lambda: models.MSFTransformer(**models.MSFT_CONFIG_C))):
+        try:
+            torch.manual_seed(0)
+            net = build().to(device).train()
+            n_par = sum(p.numel() for p in net.parameters())
+            model = parallel.data_parallel(net, device) if grouped else net
+            opt = optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.99))
+            gen = torch.Generator(device=device).manual_seed(200 + rank)
+            x = torch.rand(B_PER_GPU, 3, HW, HW, device=device, generator=gen) * 2 - 1
+            target = torch.rand(B_PER_GPU, 3, 4 * HW, 4 * HW, device=device, generator=gen) * 2 - 1
+
+            def step():
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = model(x)
+                torch.nn.functional.l1_loss(y.float(), target).backward()
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+
+            for _ in range(warm):
+                step()
+            torch.cuda.synchronize()
+            gc.collect()
+            if grouped:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            if grouped:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if grouped:
+                t = torch.tensor([dt], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            res[name] = {"metric": "training patches/sec (x4 SR, fwd+bwd+Adam)", "value": world * B_PER_GPU * steps / dt,
+                         "unit": "patches/s", "n_gpus": world, "ms_per_step": dt / steps * 1e3, "scaling": "weak", "dtype": "bf16",
+                         "data": "synthetic", "parameters": n_par, "gradient_bytes_all_reduced_per_step": 4 * n_par if grouped else 0,
+                         "parallelism": ("dp%d: DistributedDataParallel over RCCL, gradient_as_bucket_view" % world) if grouped else "one GPU",
+                         "config": {"workload": "%s, batch %d x 64x64 LR per GPU" % (name, B_PER_GPU)}}
+            del model, net, opt, x, target
+        except Exception as e:  # reported in place of the number
+            res[name] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return res
+
+
+def dswt_flops_per_frame(cfg, H, W, pass_share=0.25):
+    """multiply-add flops (x2) of one forward of the DSWT network on an H x W LR frame (a multiple of the window):
+    projections, attention products, gated MLP, the 3x3 convolutions of the trunk and of the x4 reconstruction tail;
+    DS-MSA attends pass_share of the windows at most (num_win_selected, DSwinT_arch.py:179)."""
+    Cc, w, fd = cfg["dim"], cfg["window_size"], cfg["feature_dim"]
+    L, T = w * w, H * W
+    attn = 8 * Cc * Cc + 4 * L * Cc                      # q|k|v + out projections, q k^T and p v
+    dsmsa = pass_share * attn + 2 * 9 * Cc * 4 + 2 * 9 * Cc   # + sparse discriminator's first convolution, out_conv
+    mlp = 12 * Cc * Cc                                   # gate + content (C -> 2C each), fc2 (2C -> C)
+    block = attn + dsmsa + mlp
+    trunk = cfg["n_blocks"] * (cfg["n_sub_blocks"] * block + 2 * 9 * Cc * Cc) + 2 * 9 * Cc * Cc   # out_layer per block, feature_transition
+    stem = 2 * 9 * 3 * Cc
+    tail = 2 * 9 * (Cc * fd + fd * fd) + 2 * 9 * fd * 4 * fd * (1 + 4) + 16 * 2 * 9 * (fd * (fd // 2) + (fd // 2) * 3)
+    return float(T) * (trunk + stem + tail)
+
+
 SR_LR = (540, 960)  # x4 -> 3840 x 2160
 
 
@@ -304,6 +390,28 @@ def sr_inference(device, rank, world, grouped=False, iters=3):
 
     out = run()
     ok = bool(torch.isfinite(out).all())
+    # one 256 x 256 tile of the frame through the path timed below (fused kernels, replayed from a graph) against the
+    # same tile through the module-by-module path: separate projection and attention kernels, separate gate and
+    # residual passes, stock convolutions at the two ends, DS-MSA reading its pass count on the host
+    tile_err = None
+    if rank == 0:
+        from visiontransformer_amd import functional as K, models as M_
+        from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+        patch = lr[:, :, 128:384, 320:576].contiguous()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            fused = runner(patch).float().clone()
+            saved = (K.FUSE_PROJECTION, K.FUSE_GATED_SILU, M_.NHWC_ENDS, M_.DSMSA_BF16_INPUT)
+            sd = [m_ for m_ in model.modules() if isinstance(m_, DeformableSparseWindowAttention)]
+            try:
+                K.FUSE_PROJECTION = K.FUSE_GATED_SILU = M_.NHWC_ENDS = M_.DSMSA_BF16_INPUT = False
+                for m_ in sd:
+                    m_.static_inference = False
+                plain = model(patch).float()
+            finally:
+                K.FUSE_PROJECTION, K.FUSE_GATED_SILU, M_.NHWC_ENDS, M_.DSMSA_BF16_INPUT = saved
+                for m_ in sd:
+                    m_.static_inference = True
+        tile_err = float((fused - plain).norm() / plain.norm())
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
@@ -319,8 +427,16 @@ def sr_inference(device, rank, world, grouped=False, iters=3):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     grid = balanced_grid(SR_LR[0], SR_LR[1], world)
+    # network-level roofline: the frame padded to whole windows as one tile (the one-rank plan); tiles with halo compute more
+    Hp, Wp = -(-SR_LR[0] // 16) * 16, -(-SR_LR[1] // 16) * 16
+    flops = dswt_flops_per_frame(DSWT_DEFAULT, Hp, Wp)
     return {"metric": "x4 SR output megapixels/sec (fwd)", "value": out.shape[2] * out.shape[3] / 1e6 / dt, "unit": "MP/s",
             "n_gpus": world, "s_per_image": dt, "scaling": "strong", "dtype": "bf16", "data": "synthetic", "finite": ok,
+            "tile_check": {"rel_err_fused_graph_vs_module_by_module": tile_err,
+                           "tile": "256x256 LR at (128, 320) of the frame; both in bf16, window decisions may differ between the two"},
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, "flops_per_frame": flops,
+                         "note": "multiply-add flops of one forward on the %dx%d padded frame (dswt_flops_per_frame) / time per frame" % (Hp, Wp)},
             "config": {"workload": "D: DSWT default (14.6 M params), 960x540 LR -> 3840x2160, %d tile(s) of %dx%d LR + 32 px halo "
                                    "clipped at the frame border, tiles round-robin over %d rank(s), one all-reduce of the image"
                                    % (len(plan_tiles(SR_LR[0], SR_LR[1], grid, 32, True)), grid[0], grid[1], world)}}
@@ -334,6 +450,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
+    ap.add_argument("--no-networks", action="store_true", help="skip the whole-network training steps (train_network)")
     ap.add_argument("--pmc-target", action="store_true",
                     help="launch every kernel of the path twice at the bench shapes and exit (the "
                          "program rocprofv3 --pmc passes run; see tools/pmc_summary.py)")
@@ -426,6 +543,12 @@ def main():
         except Exception as e:  # the training line above stays valid; the failure is reported in its place
             sr = {"metric": "x4 SR output megapixels/sec (fwd)", "value": None, "error": "%s: %s" % (type(e).__name__, e)}
 
+    # whole-network training steps (the workloads a multi-GPU run is about: 58 MB of gradients all-reduced per step
+    # for the DSWT default network), outside the timed region of the line's own value: all ranks take part
+    tn = None
+    if not args.no_networks:
+        tn = train_network(device, rank, world, grouped)
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         line = {
@@ -462,6 +585,8 @@ def main():
             line["kernels"] = ks
         if sr is not None:
             line["sr_inference"] = sr
+        if tn is not None:
+            line["train_network"] = tn
         if world == 1 and not rehearsal and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -98,14 +98,15 @@ def shuffle_nchw(t, scale):
     return F.pixel_shuffle(t.permute(0, 3, 1, 2).contiguous(), scale)
 
 
-def vit_block(P, x, win, num_heads):
-    """msft ViTBlock.forward, dropout off (msft_arch.py:156-167): NCHW in/out,
-    LayerNorm + WindowedMSA residual, LayerNorm + GELU MLP residual."""
+def vit_block(P, x, win, num_heads, attn_drop=0.0, keep=None):
+    """msft ViTBlock.forward, residual dropout off (msft_arch.py:156-167): NCHW in/out,
+    LayerNorm + WindowedMSA residual, LayerNorm + GELU MLP residual.  attn_drop / keep: the
+    attention's own dropout (msft_arch.py:136, :149) with an explicit draw, as in wmsa_forward."""
     B, C, H, W = x.shape
     t = x.view(B, C, H * W).permute(0, 2, 1).contiguous()
     n1 = F.layer_norm(t, (C,), P["ln1.weight"], P["ln1.bias"])
     msa = {k[len("msa."):]: v for k, v in P.items() if k.startswith("msa.")}
-    t = wmsa_forward(msa, n1, H, W, win, num_heads) + t
+    t = wmsa_forward(msa, n1, H, W, win, num_heads, attn_drop=attn_drop, keep=keep) + t
     n2 = F.layer_norm(t, (C,), P["ln2.weight"], P["ln2.bias"])
     m = F.linear(F.gelu(F.linear(n2, P["mlp.mlp.0.weight"], P["mlp.mlp.0.bias"])),
                  P["mlp.mlp.2.weight"], P["mlp.mlp.2.bias"])

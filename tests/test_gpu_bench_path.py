@@ -181,6 +181,64 @@ def test_default_width_dswt_bf16_against_the_reference(cuda0):
     assert rel_err(y.float(), g["y"]) < 0.15   # 48 attention layers of bf16 with discrete window decisions in between
 
 
+def test_default_width_dswt_bf16_every_attention_layer_against_the_oracle(cuda0):
+    """The inference path the benchmark runs (bf16 autocast, DS-MSA without its host read, projection inside the
+    attention kernel, residuals in the closing kernels, DS-MSA fed a bf16 map) on the default-width network, checked
+    LAYER BY LAYER: every WindowedMSA and DS-MSA call of the run hands its actual input to the fp32 oracle - DS-MSA
+    with the oracle forced to the windows the run took (a window decision that bf16 flips is a different function,
+    not an error) - and the branch it added to the stream is held to the bf16 bar.  48 attention layers deep the
+    whole-network comparison above can only be loose; this one cannot hide a layer."""
+    from visiontransformer_amd import dswin, models
+    g, m = load_golden("model_dswt_default")
+    cfg = dict(m["cfg"])
+    cfg.update(n_blocks=3)                      # 9 ViTBlocks = 18 attention layers: what the CPU oracle runs in a minute
+    net = models.DSWTransformer(**cfg)
+    fill_parameters(net, m["seed"])
+    net = net.to(cuda0).eval()
+    records = []
+
+    def hook(mod, args, kwargs, out):
+        res = kwargs.get("residual")
+        assert res is not None, "the fused inference path hands the residual to the branch"
+        stream, rz = res
+        sel = getattr(mod, "last_selection", None)
+        records.append((mod, args[0].detach().float().cpu(), stream.detach().float().cpu(), float(rz), out.detach().float().cpu(),
+                        None if sel is None else sel))
+    hooks = [sub.register_forward_hook(hook, with_kwargs=True) for sub in net.modules()
+             if isinstance(sub, (dswin.WindowedMSA, dswin.DeformableSparseWindowAttention))]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = net(g["x"].to(cuda0))
+    for h in hooks:
+        h.remove()
+    assert torch.isfinite(y).all() and len(records) == 18
+    worst = {}
+    n_attended = 0
+    for mod, x, stream, rz, out, sel in records:
+        # the parameters as the kernels use them: weights of the matrix products rounded to bf16
+        P = {k: (v.detach().float().cpu().bfloat16().float() if v.is_floating_point() and v.dim() >= 2 else v.detach().cpu())
+             for k, v in mod.state_dict().items()}
+        branch = (out - stream) / rz
+        if isinstance(mod, dswin.WindowedMSA):
+            ref = D.wmsa_forward(P, x, mod.win, mod.num_heads)
+            kind = "wmsa"
+        else:
+            kind = "dsmsa"
+            if sel is None:
+                assert float(branch.abs().max()) == 0.0
+                continue
+            n_pass = int(sel.n_dev.item())
+            forced = dict(cand_idx=sel.cand_idx.cpu().long(), pass_mask=sel.cand_pass.cpu().reshape(-1).bool(),
+                          h1=sel.win_h1.cpu()[:n_pass], w1=sel.win_w1.cpu()[:n_pass])
+            ref = D.dsmsa_forward(P, x, mod.w, mod.num_heads, training=False, num_win_selected=mod.num_win_selected, forced=forced)
+            # DS-MSA returns its input plus the attended windows' deltas: the branch proper is what it adds to x
+            if n_pass:
+                n_attended += 1
+        err = rel_err(branch, ref)
+        worst[kind] = max(worst.get(kind, 0.0), err)
+        assert err < BF16_TOL, (kind, err)
+    assert n_attended > 0, "no DS-MSA layer attended: the check would be empty"
+
+
 def test_tiled_inference_with_the_dswt_network(cuda0):
     """tiled_super_resolve with the real network (default width, two residual blocks) on four tiles: every tile
     equals model(tile) and the stitched image is the tiles' cores in place; the two-rank split covers the same tiles."""

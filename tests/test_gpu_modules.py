@@ -290,6 +290,49 @@ def test_dswt_wmsa_attention_dropout_follows_training_mode(cuda0):
     assert rel_err(y_eval, D.wmsa_forward(P, x, w, heads)) < TOL
 
 
+@pytest.mark.parametrize("C,heads,H,W", [(216, 4, 32, 32), (96, 6, 16, 24), (192, 6, 16, 16)])
+def test_msft_vitblock_bf16_autocast_at_config_c_widths_against_the_oracle(cuda0, C, heads, H, W):
+    """The msft ViTBlock in the trainer's mode at the widths of the headline MSFT configuration (dim 192: the fuse
+    block's 216 channels on 4 heads, head dim 54; the level blocks' 96 channels on 6 heads, head dim 16; 8x8
+    windows; msft_arch.py:146-167, :193-196) with the reference's attention dropout of 0.1 made explicit by a seed:
+    bf16 autocast against the fp32 oracle on the same bf16-representable input and parameters - output, input
+    gradient and every parameter gradient within the bf16 bar."""
+    from oracle import dswin_oracle as D, msft_oracle as M
+    from visiontransformer_amd.msft import ViTBlock
+    torch.manual_seed(C + heads)
+    w, B = 8, 2
+    mod = ViTBlock(w, C, n_heads=heads)
+    assert mod.msa.attn_drop == 0.1
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn_like(p) * p[0].numel() ** -0.5)
+            elif n.endswith("weight"):                     # norm scales around one
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            else:
+                p.copy_(0.1 * torch.randn_like(p))
+            p.copy_(p.bfloat16().float())                  # what bf16 autocast computes with, exactly
+    x = torch.randn(B, C, H, W).bfloat16().float()
+    r = torch.randn(B, C, H, W)
+    seed = 20250 + C
+    keep = D.dropout_keep_mask(B * (H // w) * (W // w), heads, w * w, 0.1, seed)
+    P = {k: v.detach().clone().requires_grad_() for k, v in mod.state_dict().items()}
+    x_ref = x.clone().requires_grad_()
+    y_ref = M.vit_block(P, x_ref, w, heads, attn_drop=0.1, keep=keep)
+    (y_ref * r).sum().backward()
+    mod = mod.to(cuda0).eval()                             # residual dropout off; the attention's stays on (msft_arch.py:136)
+    mod.msa.dropout_seed = seed
+    xg = x.to(cuda0).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = mod(xg)
+    (y.float() * r.to(cuda0)).sum().backward()
+    tol = 2e-2
+    assert rel_err(y, y_ref) < tol
+    assert rel_err(xg.grad, x_ref.grad) < tol
+    for n, p in mod.named_parameters():
+        assert rel_err(p.grad, P[n].grad) < tol, n
+
+
 def test_msft_wmsa_bf16(cuda0):
     """bf16 run of the msft attention against its own fp32 run (2e-2)."""
     from visiontransformer_amd.msft import WindowedMSA

@@ -47,22 +47,40 @@ def main():
                 T = 1
                 for n in lead:
                     T *= n
-                if padded:
-                    buf = K._mark_padded(torch.zeros(T, 576, device=dev, dtype=torch.bfloat16))
-                    buf[:, :3 * C] = torch.randn(T, 3 * C, device=dev).bfloat16()
-                    qkv = buf[:, :3 * C].view(lead + (3 * C,)).requires_grad_()
-                    gbuf = torch.zeros(T, 192, device=dev, dtype=torch.bfloat16)
-                    gbuf[:, :C] = torch.randn(T, C, device=dev).bfloat16()
-                    do = gbuf[:, :C].view(lead + (C,))
-                else:
-                    qkv = torch.randn(lead + (3 * C,), device=dev).bfloat16().requires_grad_()
-                    do = torch.randn(lead + (C,), device=dev).bfloat16()
+                # W16_SETS buffer sets taken in turn: with one set (about 200 MB forward, 400 MB backward) the
+                # operands of the next call are what the last one left in the 256 MB Infinity Cache; with three or
+                # more every call reads from HBM, as the kernels do inside a training step
+                nsets = int(os.environ.get("W16_SETS", "1"))
+                sets = []
                 tab = (torch.randn((2 * w - 1) ** 2, heads, device=dev) * 0.02).requires_grad_() if bias else None
-                o = K.window_attention(qkv, tab, w, heads, layout, grid=grid, pad_out=padded)
+                for _ in range(nsets):
+                    if padded:
+                        buf = K._mark_padded(torch.zeros(T, 576, device=dev, dtype=torch.bfloat16))
+                        buf[:, :3 * C] = torch.randn(T, 3 * C, device=dev).bfloat16()
+                        qkv = buf[:, :3 * C].view(lead + (3 * C,)).requires_grad_()
+                        gbuf = torch.zeros(T, 192, device=dev, dtype=torch.bfloat16)
+                        gbuf[:, :C] = torch.randn(T, C, device=dev).bfloat16()
+                        do = gbuf[:, :C].view(lead + (C,))
+                    else:
+                        qkv = torch.randn(lead + (3 * C,), device=dev).bfloat16().requires_grad_()
+                        do = torch.randn(lead + (C,), device=dev).bfloat16()
+                    o = K.window_attention(qkv, tab, w, heads, layout, grid=grid, pad_out=padded)
+                    sets.append((qkv, do, o))
+                turn = [0]
+
+                def fwd():
+                    qkv = sets[turn[0] % nsets][0]
+                    turn[0] += 1
+                    return K.window_attention(qkv, tab, w, heads, layout, grid=grid, pad_out=padded)
+
+                def bwd():
+                    qkv, do, o = sets[turn[0] % nsets]
+                    turn[0] += 1
+                    return torch.autograd.grad(o, (qkv, tab) if bias else (qkv,), do, retain_graph=True)
                 with torch.no_grad():
-                    tf = timeit(lambda: K.window_attention(qkv, tab, w, heads, layout, grid=grid, pad_out=padded))
-                ins = (qkv, tab) if bias else (qkv,)
-                tb = timeit(lambda: torch.autograd.grad(o, ins, do, retain_graph=True))
+                    tf = timeit(fwd)
+                tb = timeit(bwd)
+                del sets
                 fb = (4 * T * C * 2 + T * heads * 4) / 1e6
                 bb = (8 * T * C * 2 + T * heads * 4) / 1e6
                 print("%-6s pitch=%s bias=%d  fwd %7.1f us (%5.2f TB/s, %5.1f TF/s)   bwd %7.1f us (%5.2f TB/s, %5.1f TF/s)" %

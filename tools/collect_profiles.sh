@@ -7,7 +7,7 @@ T=${1:-r1}
 rm -rf gpurun_out/$T
 /usr/local/graft/bin/gpurun --timeout 1200 -- "mkdir -p gpurun_out/$T/kt gpurun_out/$T/f gpurun_out/$T/w gpurun_out/$T/s1 gpurun_out/$T/s2; R=\$GRAFT_REPO_ROOT; O=\$R/gpurun_out/$T; cd /tmp && export TMPDIR=/tmp && \
 timeout -k 10 400 python3 \$R/bench.py > \$O/bench.json 2> \$O/bench.err && \
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d \$O/kt -- python3 \$R/bench.py --no-cpu-baseline --no-inference > \$O/kt/run.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d \$O/kt -- python3 \$R/bench.py --no-cpu-baseline --no-inference --no-networks > \$O/kt/run.log 2>&1 && \
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d \$O/f -- python3 \$R/bench.py --pmc-target > \$O/f/run.log 2>&1 && \
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d \$O/w -- python3 \$R/bench.py --pmc-target > \$O/w/run.log 2>&1 && \
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d \$O/s1 -- python3 \$R/bench.py --pmc-target > \$O/s1/run.log 2>&1 && \

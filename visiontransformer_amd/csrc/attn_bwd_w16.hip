@@ -423,7 +423,8 @@ __global__ __launch_bounds__(512, (DP == 32 ? 4 : 2)) void win_attn_bwd_w16_kern
 //    of being finished across lanes (45 vector instructions per tile); ds_add_f32 would do it in one instruction
 //    but takes about a hundred LDS cycles;
 //  * phase 2 reads its bias values from a mirrored copy of the table, ascending like phase 1's;
-//  * dK, dV and dQ leave from the accumulators (lane halves exchange columns, two 16-byte stores per lane).
+//  * dK, dV and dQ leave through the wave's own rows of the images, complete 60-byte pieces of 16 rows per store
+//    instruction (store_tile_rows_d30).
 struct Bwd30Cfg {
     static constexpr int WS = 16, L = 256, DP = 32, NT = 8, NW = 8, THREADS = 512, D = 30;
     static constexpr int N_BUF = L * DP;
@@ -649,51 +650,41 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
         }
     }
     // phase 2's B operands: this wave's own query block, rows of Q' and dO' (column = query on the lane)
+    // (everything from here on that depends on the lane is computed afresh from a copy of the lane index the
+    // compiler cannot look through: kept alive across phase 1 instead, these values do not fit the 128 registers and
+    // the spills would make the kernel one that uses scratch memory, which costs far more than recomputing them)
+    int lane2 = lane;
+    asm volatile("" : "+v"(lane2));
+    const int l31b = lane2 & 31, hhb = lane2 >> 5, tid2 = wave * 64 + lane2, qrow2 = 32 * wave + l31b;
+    int a_off2[2], t_off2[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a_off2[s] = img<DP>(l31b, 16 * s + 8 * hhb);
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) t_off2[h8] = img<DP>(4 * hhb + ((lane2 >> 2) & 3) + 8 * h8, 16 * ((lane2 >> 4) & 1) + 4 * (lane2 & 3));
     uint4 qfb[2], gfb[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        qfb[s] = *reinterpret_cast<const uint4 *>(bufA + wave * BLK + a_off[s]);
-        gfb[s] = *reinterpret_cast<const uint4 *>(bufB + wave * BLK + a_off[s]);
+        qfb[s] = *reinterpret_cast<const uint4 *>(bufA + wave * BLK + a_off2[s]);
+        gfb[s] = *reinterpret_cast<const uint4 *>(bufB + wave * BLK + a_off2[s]);
     }
     lds_barrier();  // nobody reads Q' / dO' any more; every wave's d(table) is complete
 
-    // An accumulator (rows = head dim in registers 4g..4g+3 = columns 8g + 4hh ..+3, lane = token 32 wave + l31)
-    // leaves as two 16-byte slots per lane: the lane halves exchange columns so that the lower half holds columns
-    // 0-7 and 16-23, the upper half 8-15 and 24-31; the upper half's second slot, of which columns 30 and 31 are
-    // not the token's, leaves as columns 22-29 (22 and 23, its own before the exchange, written a second time).
-    auto store_acc = [&](const f32x16 &acc, float mul, int col0) {
-        uint32_t pk[4][2];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            pk[g4][0] = pack_bf16(acc[4 * g4] * mul, acc[4 * g4 + 1] * mul);
-            pk[g4][1] = pack_bf16(acc[4 * g4 + 2] * mul, acc[4 * g4 + 3] * mul);
-        }
-        uint4 slot[2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p][0], pk[2 * p + 1][0], false, false);
-            const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p][1], pk[2 * p + 1][1], false, false);
-            slot[p] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-        }
-        if (hh) slot[1] = make_uint4(pk[2][1], slot[1].x, slot[1].y, slot[1].z);
-        T *dst = dqkv + origin * C3;
-        const unsigned e0 = krel * C3 + col0 + 8 * hh;
-        store16_a4(dst + e0, slot[0]);
-        store16_a4(dst + (e0 + 16 - 2 * hh), slot[1]);
-    };
-    store_acc(dKacc, LN2, koff);  // Q' carries scale * log2(e): dK = Q'^T dS * ln 2
-    store_acc(dVacc, 1.f, voff);
+    // results leave through this wave's own 32 rows of the images (store_tile_rows_d30): nobody else touches them
+    // between the barriers
+    bf16_t *dq0 = dqkv + origin * C3;
+    store_tile_rows_d30(bufA + wave * BLK, dKacc, LN2, dq0 + koff, C3, pitch, wave, lane2);  // Q' carries scale * log2(e): dK = Q'^T dS * ln 2
+    store_tile_rows_d30(bufB + wave * BLK, dVacc, 1.f, dq0 + voff, C3, pitch, wave, lane2);
     // K and V into LDS for phase 2, straight from the B-operand registers (16 bytes = one slot per register)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        *reinterpret_cast<uint4 *>(bufA + wave * BLK + a_off[s]) = kfb[s];
-        *reinterpret_cast<uint4 *>(bufB + wave * BLK + a_off[s]) = vfb[s];
+        *reinterpret_cast<uint4 *>(bufA + wave * BLK + a_off2[s]) = kfb[s];
+        *reinterpret_cast<uint4 *>(bufB + wave * BLK + a_off2[s]) = vfb[s];
     }
     if constexpr (BIAS) {
         // the table entered the logits times log2(e) inside exp2, so d/dtable is dS itself.  Entry (di, dj):
         // wave wv holds it in row di + 2*wv + 1 of its table when that row exists.
         float *dst = ws_table + ((size_t)win * g.heads + head) * (TR * TR);
-        for (int it = tid; it < TR * TR; it += THREADS) {
+        for (int it = tid2; it < TR * TR; it += THREADS) {
             const int di = it / TR - (WS - 1), dj = it - (it / TR) * TR;
             float acc = 0.f;
 #pragma unroll
@@ -712,8 +703,8 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
     }
     if (head == g.heads - 1 && C3 > 3 * g.C) {  // the padding columns of this window's dqkv rows (an even count)
         const int np2 = (C3 - 3 * g.C) >> 1;    // dwords per row; two threads share a row
-        T *prow = dqkv + (origin + rel_row(tid >> 1)) * C3 + 3 * g.C;
-        for (int j = tid & 1; j < np2; j += 2) *reinterpret_cast<uint32_t *>(prow + 2 * j) = 0u;
+        T *prow = dqkv + (origin + rel_row(tid2 >> 1)) * C3 + 3 * g.C;
+        for (int j = tid2 & 1; j < np2; j += 2) *reinterpret_cast<uint32_t *>(prow + 2 * j) = 0u;
     }
     lds_barrier();  // K, V are in LDS
 
@@ -723,7 +714,7 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
     for (int r = 0; r < 16; ++r) dQacc[r] = 0.f;
     {
         // key of register r: kt*32 + rho(r) + 4hh  ->  entry e = (qi-ki+15)*TS + (qj-kj+15), read at TMAX - e
-        const int seed_base = TMAX - (((krow >> 4) + WS - 1) * TS + (krow & 15) + (WS - 1) - 4 * hh);
+        const int seed_base = TMAX - (((qrow2 >> 4) + WS - 1) * TS + (qrow2 & 15) + (WS - 1) - 4 * hhb);
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             const T *blkA = bufA + kt * BLK, *blkB = bufB + kt * BLK;
@@ -742,8 +733,8 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
             for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const uint4 ka = *reinterpret_cast<const uint4 *>(blkA + a_off[s]);
-                const uint4 va = *reinterpret_cast<const uint4 *>(blkB + a_off[s]);
+                const uint4 ka = *reinterpret_cast<const uint4 *>(blkA + a_off2[s]);
+                const uint4 va = *reinterpret_cast<const uint4 *>(blkB + a_off2[s]);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ka), as_bf16x8(qfb[s]), sacc, 0, 0, 0);
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(va), as_bf16x8(gfb[s]), pacc, 0, 0, 0);
             }
@@ -754,12 +745,13 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
             for (int s = 0; s < 2; ++s) {
                 const uint4 db = make_uint4(pack_bf16(pacc[8 * s + 0], pacc[8 * s + 1]), pack_bf16(pacc[8 * s + 2], pacc[8 * s + 3]),
                                             pack_bf16(pacc[8 * s + 4], pacc[8 * s + 5]), pack_bf16(pacc[8 * s + 6], pacc[8 * s + 7]));
-                const uint2 k0 = lds_read_tr16(blkA + 16 * s * DP + t_off[0]), k1 = lds_read_tr16(blkA + 16 * s * DP + t_off[1]);
+                const uint2 k0 = lds_read_tr16(blkA + 16 * s * DP + t_off2[0]), k1 = lds_read_tr16(blkA + 16 * s * DP + t_off2[1]);
                 dQacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(k0.x, k0.y, k1.x, k1.y)), as_bf16x8(db), dQacc, 0, 0, 0);
             }
         }
     }
-    store_acc(dQacc, scale, qoff);
+    lds_barrier();  // nobody reads K / V any more
+    store_tile_rows_d30(bufA + wave * BLK, dQacc, scale, dq0 + qoff, C3, pitch, wave, lane2);
 }
 
 // DSW_ATTN_BWD_W16_OLD=1 in the environment keeps head dim 30 on the kernel for any even head dim (tests compare the two)

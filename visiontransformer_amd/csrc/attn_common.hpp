@@ -231,6 +231,39 @@ __device__ __forceinline__ uint32_t bf16_hi_lo(float x) {
     return (uint32_t)h | ((uint32_t)l << 16);
 }
 
+// A wave's 32 x 32 result (accumulator rows = head-dim columns in registers 4g..4g+3 = columns 8g + 4hh ..+3, lane =
+// token 32 wave + l31 of the window) to the head's 30-column slice of the tokens' rows of `dst`, times `mul`, as bf16.
+// The tile goes through 2 KB of LDS that only this wave touches (`stage`, a [32][32] image in the slot_flip layout)
+// so that one store instruction carries the complete 60-byte pieces of 16 rows, four lanes a row: pieces that arrive
+// at a cold cache line in two instructions were seen to cost a read-modify-write of the line each (twice the bytes
+// written, and the lines fetched on top).  The last slot leaves as the 16 bytes that end with the slice.
+// `dst` is the wave-uniform address of the window's first token's slice; a token's row is rel_row * ld further on.
+__device__ __forceinline__ void store_tile_rows_d30(bf16_t *stage, const f32x16 &acc, float mul, bf16_t *dst, int ld, int pitch,
+                                                    int wave, int lane) {
+    const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {  // slots 2p + hh: columns 16p + 8hh .. +7 = register groups 2p (hh = 0: first half) ...
+        // registers 4g..4g+3 hold columns 8g + 4hh..: a slot of 8 columns is split over the two lane halves, so the
+        // halves exchange: afterwards the lower half holds slot 2p whole (g = 2p from both), the upper slot 2p + 1
+        const uint32_t a0 = pack_bf16(acc[8 * p] * mul, acc[8 * p + 1] * mul), a1 = pack_bf16(acc[8 * p + 2] * mul, acc[8 * p + 3] * mul);
+        const uint32_t b0 = pack_bf16(acc[8 * p + 4] * mul, acc[8 * p + 5] * mul), b1 = pack_bf16(acc[8 * p + 6] * mul, acc[8 * p + 7] * mul);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        *reinterpret_cast<uint4 *>(stage + img<32>(l31, 8 * (2 * p + hh))) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+    // (a wave's LDS accesses complete in order, and only this wave touches these rows)
+    const int c = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (lane >> 2) + 16 * i, tok = 32 * wave + row;
+        uint4 v = *reinterpret_cast<const uint4 *>(stage + img<32>(row, 8 * c));
+        const uint32_t before = *reinterpret_cast<const uint32_t *>(stage + img<32>(row, 22));  // columns 22, 23
+        if (c == 3) v = make_uint4(before, v.x, v.y, v.z);
+        const unsigned e = (unsigned)((tok >> 4) * pitch + (tok & 15)) * ld + 8 * c - (c == 3 ? 2 : 0);
+        store16_a4(dst + e, v);
+    }
+}
+
 // forward for 16 x 16 windows in bf16 with an even head dim <= 30, no LePE, no dropout (attn_fwd_w16.hip); returns
 // DSW_OK after launching, or a negative value when the shape is not one it takes (the caller then uses the general
 // kernel)

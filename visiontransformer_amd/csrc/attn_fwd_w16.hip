@@ -9,13 +9,14 @@
 //    transposing reads are bank-conflict-free; 39 KB of LDS per workgroup, several workgroups per CU;
 //  * the row reference r of the softmax (what is subtracted from the logits before the exponential) rides in the
 //    two last padding columns of the head dimension: Q' holds -r split into two bf16 (hi + lo) there against ones
-//    in K, so the matrix core delivers S - r and the exponential follows without a subtraction.  r starts as the
-//    row maximum of the first key tile and is raised only when a later tile exceeds it by more than 2^8 (one
-//    wave-uniform branch per tile, almost never taken after the first tile): no per-tile rescaling of the running
-//    output, and the result is the exact softmax whatever r is, since numerator and denominator share it;
+//    in K, so the matrix core delivers S - r and the exponential follows without a subtraction.  r is the row
+//    maximum of the FIRST key tile: no maximum, no rescaling of the running output for the other seven, and the
+//    result is the exact softmax whatever r is, since numerator and denominator share it - unless a later logit
+//    exceeds r by so much that an exponential overflows, which the denominator shows; the block is then done again
+//    with the maximum over all keys;
 //  * the denominator is row 31 of O^T (a column of ones in V's padding), computed by the matrix core;
-//  * the output leaves from registers: the two lane halves of a query exchange half of their columns
-//    (v_permlane32_swap) so that every lane stores two 16-byte slots of its token row.
+//  * the output leaves through the wave's rows of the (spent) K image, so that one store instruction carries the
+//    complete 60-byte pieces of 16 token rows (store_tile_rows_d30).
 #include "attn_common.hpp"
 
 #pragma clang fp contract(fast)
@@ -29,13 +30,14 @@ struct FwdW16Cfg {
     static constexpr size_t lds_bytes(bool bias) { return (size_t)2 * N_IMG * sizeof(bf16_t) + (bias ? (size_t)TBF * sizeof(float) : 0); }
 };
 
-constexpr float FWD_W16_RAISE = 8.f;  // the reference is raised when a logit exceeds it by more than this (base 2)
-
 // The head dim is 30: a head's slice of a token row is three whole 16-byte slots and one of 12 bytes.  The last
 // slot is read (and written) as the 16 bytes that END with the slice - one dword early, so that no byte outside the
 // slice is touched - and shifted in registers; its fourth dword, columns 30 and 31 of the padded head dim, is ours.
+#ifndef FWD_W16_WAVES
+#define FWD_W16_WAVES 6
+#endif
 template <bool BIAS>
-__global__ __launch_bounds__(512, 8) void win_attn_fwd_w16_kernel(AttnGeom g, const bf16_t *__restrict__ qkv,
+__global__ __launch_bounds__(512, FWD_W16_WAVES) void win_attn_fwd_w16_kernel(AttnGeom g, const bf16_t *__restrict__ qkv,
                                                                   const float *__restrict__ table, float scale,
                                                                   bf16_t *__restrict__ out, float *__restrict__ lse) {
     using Cfg = FwdW16Cfg;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(512, 8) void win_attn_fwd_w16_kernel(AttnGeom g, co
     __syncthreads();
 
     f32x16 oacc;
-    float rref;  // the row reference: always the sum of two bf16, so that Q' carries it exactly
+    float rref = 0.f;  // the row reference: always the sum of two bf16, so that Q' carries it exactly
     // S^T - r for key tile t: the accumulators start from the bias, the matrix core adds K Q'^T and -r
     // the bias of key tile t against this lane's query: register r of lane half hh is key 32t + rho(r) + 4hh, four
     // consecutive registers are four ascending words of the mirrored table
@@ -197,77 +199,50 @@ __global__ __launch_bounds__(512, 8) void win_attn_fwd_w16_kernel(AttnGeom g, co
         return __uint_as_float(r[1]);
     };
 
-    // ---- the optimistic pass: r = row maximum of the first key tile, no maximum after that ---------------------
+    // ---- r = row maximum of the first key tile, no maximum after that ----------------------------------------------
     // Exact whatever r is as long as nothing overflows: exp2(S - r) reaches 2^100 only when a later logit exceeds
-    // every logit of the first tile by 100 (base 2), which the check on the denominator below catches.
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
-    rref = 0.f;
-    {
-        f32x16 sacc;
-        scores(0, sacc);
-        const float sh = set_reference(row_max(sacc));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] -= sh;
-        accumulate(0, sacc);
-    }
-#pragma unroll
-    for (int t = 1; t < NT; ++t) {
-        f32x16 sacc;
-        scores(t, sacc);
-        accumulate(t, sacc);
-    }
-    float sum = denominator();
-    if (__builtin_amdgcn_ballot_w64(!(sum < 0x1p100f)) != 0) {  // uniform; not taken on ordinary logits
-        // ---- the careful pass: the reference follows the running maximum (raised when a tile exceeds it by 2^8) ----
+    // every logit of the first tile by 100 (base 2).  The check on the denominator catches that (one wave-uniform
+    // branch, not taken on ordinary logits) and the block is done again with r = the maximum over ALL keys, found by
+    // a pass of its own over the score tiles - the same code below runs a second time, nothing is kept alive for it.
+    float sum;
+    bool again = false;
+#pragma unroll 1
+    for (;;) {
+        float top;
+        if (!again) {
+            f32x16 sacc;
+            scores(0, sacc);
+            top = row_max(sacc);
+        } else {
+            top = -INFINITY;
+#pragma unroll 1
+            for (int t = 0; t < NT; ++t) {
+                f32x16 sacc;
+                scores(t, sacc);
+                top = fmaxf(top, row_max(sacc));
+            }
+        }
+        // (S - r as it stands now) + r = S: the new reference is the maximum of the logits themselves
+        set_reference(rref + top);
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
-        rref = 0.f;
-        if (hh) qfb[1].w = 0u;
-#pragma unroll 1
+#pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x16 sacc;
             scores(t, sacc);
-            const float tm = row_max(sacc);
-            if (t == 0 || __builtin_amdgcn_ballot_w64(tm > FWD_W16_RAISE) != 0) {
-                const float sh = set_reference(rref + (t == 0 ? tm : fmaxf(tm, 0.f)));
-                const float alpha = __builtin_amdgcn_exp2f(-sh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sacc[r] -= sh;
-                    oacc[r] *= alpha;
-                }
-            }
             accumulate(t, sacc);
         }
         sum = denominator();
+        if (again || __builtin_amdgcn_ballot_w64(!(sum < 0x1p100f)) == 0) break;
+        again = true;
     }
 
     // ---- epilogue: normalise, store -----------------------------------------------------------------------------
     const float inv = 1.0f / sum;
     if (hh == 0) lse[((size_t)win * g.heads + head) * L + qrow] = (rref + __builtin_amdgcn_logf(sum)) * LN2;
-    // registers 4g..4g+3 are head-dim columns 8g + 4hh ..+3; after the exchange the lower half holds columns
-    // 0-7 and 16-23 of its token, the upper half 8-15 and 24-31
-    uint32_t pk[4][2];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-        pk[g4][0] = pack_bf16(oacc[4 * g4] * inv, oacc[4 * g4 + 1] * inv);
-        pk[g4][1] = pack_bf16(oacc[4 * g4 + 2] * inv, oacc[4 * g4 + 3] * inv);
-    }
-    uint4 slot[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p][0], pk[2 * p + 1][0], false, false);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p][1], pk[2 * p + 1][1], false, false);
-        slot[p] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-    }
-    // the upper half's second slot is columns 24-31, of which 30 and 31 are not the token's: it leaves as columns
-    // 22-29, with columns 22 and 23 (this lane's own before the exchange: registers 10, 11) written a second time
-    if (hh) slot[1] = make_uint4(pk[2][1], slot[1].x, slot[1].y, slot[1].z);
-    T *orow = out + origin * C + head * D;
-    const unsigned orel = rel_row(qrow) * C + 8 * hh;
-    store16_a4(orow + orel, slot[0]);
-    store16_a4(orow + (orel + 16 - 2 * hh), slot[1]);
+    // the output tile leaves through this wave's 32 rows of the K image, once no wave reads K or V any more
+    __syncthreads();
+    store_tile_rows_d30(Ki + wave * BLK, oacc, inv, out + origin * C + head * D, C, pitch, wave, lane);
     if (head == g.heads - 1 && C > g.C) {  // this wave's share of the output rows' padding columns
         // (C and g.C are even: whole dwords; a lane takes every other dword of its token's padding)
         const int np2 = (C - g.C) >> 1;
