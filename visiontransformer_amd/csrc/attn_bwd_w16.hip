@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, (DP == 32 ? 4 : 2)) void win_attn_bwd_w16_kern
                 ent[16] = bg_carry_w;
             }
         }
-        // phase 2's B operands: this wave's own query block, rows of Q' and dO' (column = query on the lane)
+    // phase 2's B operands: this wave's own query block, rows of Q' and dO' (column = query on the lane)
         uint4 qfb[NS], gfb[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512, (DP == 32 ? 4 : 2)) void win_attn_bwd_w16_kern
             for (int i = 0; i < ITER; ++i)
                 for (int j = tid % DW; j < npad2; j += DW) *reinterpret_cast<uint32_t *>(pad0 + ((rel0 + i * step) * C3 + 2 * j)) = 0u;
         }
-        lds_barrier();  // K, V are in LDS
+    lds_barrier();  // K, V are in LDS
 
         // =================== phase 2: query on the lane; dQ^T ===================
         f32x16 dQacc[NU];
@@ -437,6 +437,18 @@ struct Bwd30Cfg {
     }
 };
 
+// BWD30_STAMPS (diagnostic builds only, tools/bwd_stamps.py): thread 0 of every workgroup records the shader clock at
+// points of the head-dim-30 kernel into a device array that dsw_debug_read_stamps copies out; no output depends on it
+#ifdef BWD30_STAMPS
+__device__ unsigned long long g_bwd30_stamps[16 * 8192];
+#define BWD30_STAMP(i)                                                                                       \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_bwd30_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define BWD30_STAMP(i) ((void)0)
+#endif
+
 template <int CTRL> __device__ __forceinline__ float dpp_add_quad(float x) {
     return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
 }
@@ -465,6 +477,7 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int C = g.ldo, CG = g.ldg, C3 = g.ldq;
     const float sc2 = scale * LOG2E;
+    BWD30_STAMP(0);
     const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
     // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
     const int win = __builtin_amdgcn_readfirstlane(id / g.heads), head = id - win * g.heads;
@@ -521,17 +534,30 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
         ov[i] = load16_a4(out0 + (rel * C + e0));
         lsev[i] = lse0[row];
     }
+    // the head's column of the bias table, both sweeps requested at once behind the operands: one trip to memory
+    static_assert(TR * TR <= 2 * THREADS, "two table entries per thread");
+    float tabv[2] = {0.f, 0.f};
     if constexpr (BIAS) {
-        for (int it = tid; it < TR * TR; it += THREADS) {
-            const int di = it / TR, dj = it - di * TR;
-            const float v = table[(size_t)it * g.heads + head] * LOG2E;
-            tb[di * TS + dj] = v;
-            tbm[TMAX - (di * TS + dj)] = v;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + THREADS * i < TR * TR) tabv[i] = table[(size_t)(tid + THREADS * i) * g.heads + head];
+    }
+    BWD30_STAMP(12);
+    if constexpr (BIAS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int it = tid + THREADS * i, di = it / TR, dj = it - di * TR;
+            if (it < TR * TR) {
+                const float v = tabv[i] * LOG2E;
+                tb[di * TS + dj] = v;
+                tbm[TMAX - (di * TS + dj)] = v;
+            }
         }
         // this wave's d(table): zero
         float4 *z = reinterpret_cast<float4 *>(bgw + wave * BGF);
         for (int i = lane; i < BGF / 4; i += 64) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    BWD30_STAMP(1);
     if (hh) {  // columns 24-31 arrived as 22-29: shift, ones in the two last columns
         kfb[1] = make_uint4(kfb[1].y, kfb[1].z, kfb[1].w, 0x3F803F80u);
         vfb[1] = make_uint4(vfb[1].y, vfb[1].z, vfb[1].w, 0x3F803F80u);
@@ -580,7 +606,9 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
         dKacc[r] = 0.f;
         dVacc[r] = 0.f;
     }
+    BWD30_STAMP(2);
     lds_barrier();  // Q', dO', the bias tables are in LDS; every wave's d(table) is zero
+    BWD30_STAMP(3);
 
     // =================== phase 1: key on the lane; dK^T, dV^T, d(bias table) ===================
     {
@@ -649,6 +677,7 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
             }
         }
     }
+    BWD30_STAMP(4);
     // phase 2's B operands: this wave's own query block, rows of Q' and dO' (column = query on the lane)
     // (everything from here on that depends on the lane is computed afresh from a copy of the lane index the
     // compiler cannot look through: kept alive across phase 1 instead, these values do not fit the 128 registers and
@@ -674,39 +703,48 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
     bf16_t *dq0 = dqkv + origin * C3;
     store_tile_rows_d30(bufA + wave * BLK, dKacc, LN2, dq0 + koff, C3, pitch, wave, lane2);  // Q' carries scale * log2(e): dK = Q'^T dS * ln 2
     store_tile_rows_d30(bufB + wave * BLK, dVacc, 1.f, dq0 + voff, C3, pitch, wave, lane2);
+    BWD30_STAMP(8);
     // K and V into LDS for phase 2, straight from the B-operand registers (16 bytes = one slot per register)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         *reinterpret_cast<uint4 *>(bufA + wave * BLK + a_off2[s]) = kfb[s];
         *reinterpret_cast<uint4 *>(bufB + wave * BLK + a_off2[s]) = vfb[s];
     }
+    BWD30_STAMP(9);
     if constexpr (BIAS) {
         // the table entered the logits times log2(e) inside exp2, so d/dtable is dS itself.  Entry (di, dj):
         // wave wv holds it in row di + 2*wv + 1 of its table when that row exists.
+        // A wave takes whole rows di of the table (wave, wave + 8, ...): which waves hold the row is then a scalar
+        // loop range.  The lower lane half sums the tables of the lower lane halves (dj index = column), the upper
+        // half those of the upper halves, whose columns are 4 further on in dj; one exchange adds the two.
         float *dst = ws_table + ((size_t)win * g.heads + head) * (TR * TR);
-        for (int it = tid2; it < TR * TR; it += THREADS) {
-            const int di = it / TR - (WS - 1), dj = it - (it / TR) * TR;
+        const int dj = l31b, djh = dj - 4 * hhb;
+        const bool have = djh >= 0;  // (column 31 of the lower half: read, never stored)
+        for (int dix = __builtin_amdgcn_readfirstlane(wave); dix < TR; dix += NW) {
+            const int di = dix - (WS - 1);
+            // rows 0 <= di + 2 wv + 1 <= 16 of wave wv's tables
+            const int lo = di < -1 ? (-di) >> 1 : 0, hi = min(NW - 1, (WS - 1 - di) >> 1);
             float acc = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < NW; ++wv) {
-                const int row = di + 2 * wv + 1;
-                // lower lane half: dj index = column; upper half: its columns are 4 further on in dj
-                if (row >= 0 && row < Cfg::BG_ROWS) {
-                    const float *t0 = bgw + wv * BGF + row * BGS, *t1 = t0 + Cfg::BG_HALF;
-                    const int sw = (row & 1) << 4;
-                    acc += t0[dj ^ sw];  // (dj <= 30)
-                    if (dj >= 4) acc += t1[(dj - 4) ^ sw];
-                }
+            for (int wv = lo; wv <= hi; ++wv) {
+                const int row = di + 2 * wv + 1, sw = (row & 1) << 4;
+                const float v = bgw[wv * BGF + hhb * Cfg::BG_HALF + row * BGS + ((have ? djh : 0) ^ sw)];
+                acc += have ? v : 0.f;
             }
-            dst[it] = acc;
+            const unsigned ai = __float_as_uint(acc);
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(ai, ai, false, false);
+            acc = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+            if (lane2 < TR) dst[dix * TR + dj] = acc;
         }
     }
+    BWD30_STAMP(10);
     if (head == g.heads - 1 && C3 > 3 * g.C) {  // the padding columns of this window's dqkv rows (an even count)
         const int np2 = (C3 - 3 * g.C) >> 1;    // dwords per row; two threads share a row
         T *prow = dqkv + (origin + rel_row(tid2 >> 1)) * C3 + 3 * g.C;
         for (int j = tid2 & 1; j < np2; j += 2) *reinterpret_cast<uint32_t *>(prow + 2 * j) = 0u;
     }
+    BWD30_STAMP(11);
     lds_barrier();  // K, V are in LDS
+    BWD30_STAMP(5);
 
     // =================== phase 2: query on the lane; dQ^T ===================
     f32x16 dQacc;
@@ -750,8 +788,10 @@ __global__ __launch_bounds__(512, 4) void win_attn_bwd_w16_d30_kernel(
             }
         }
     }
+    BWD30_STAMP(6);
     lds_barrier();  // nobody reads K / V any more
     store_tile_rows_d30(bufA + wave * BLK, dQacc, scale, dq0 + qoff, C3, pitch, wave, lane2);
+    BWD30_STAMP(7);
 }
 
 // DSW_ATTN_BWD_W16_OLD=1 in the environment keeps head dim 30 on the kernel for any even head dim (tests compare the two)
@@ -806,3 +846,9 @@ int launch_bwd_w16_two_phase(const AttnGeom &g, const void *qkv, const void *out
 }
 
 }  // namespace dsw
+
+#ifdef BWD30_STAMPS
+extern "C" int dsw_debug_read_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dsw::g_bwd30_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif

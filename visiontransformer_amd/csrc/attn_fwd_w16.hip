@@ -52,24 +52,30 @@ __global__ __launch_bounds__(512, FWD_W16_WAVES) void win_attn_fwd_w16_kernel(At
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int C = g.ldo, C3 = g.ldq;
-    const int id = xcd_remap(blockIdx.x, g.n_win * g.heads);
-    // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
-    const int win = __builtin_amdgcn_readfirstlane(id / g.heads), head = id - win * g.heads;
-    int qoff, koff, voff;
-    qkv_offsets(g, head, qoff, koff, voff);
-    size_t origin;  // token (i, j) of this window sits at row origin + i*pitch + j
-    int pitch;
-    if (g.H == 0) {
-        origin = (size_t)win * L;
-        pitch = WS;
-    } else {
-        const int per = g.nWh * g.nWw;
-        const int b = __builtin_amdgcn_readfirstlane(win / per), r = win - b * per;
-        const int wr = __builtin_amdgcn_readfirstlane(r / g.nWw), wc = r - wr * g.nWw;
-        origin = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
-        pitch = g.W;
-    }
-    if (window_is_off(g, win)) {  // uniform over the workgroup
+    const int pitch = g.H == 0 ? WS : g.W;
+    // where the work item of workgroup number `blk` lives: window, head, column offsets, and the token row of window
+    // position 0 (token (i, j) of the window sits at row org + i*pitch + j)
+    auto locate = [&](int blk, int &win_, int &head_, int &qo, int &ko, int &vo, size_t &org) {
+        const int id = xcd_remap(blk, g.n_win * g.heads);
+        // (wave-uniform quotients of the vector unit's division, handed back to scalar registers)
+        win_ = __builtin_amdgcn_readfirstlane(id / g.heads);
+        head_ = id - win_ * g.heads;
+        qkv_offsets(g, head_, qo, ko, vo);
+        if (g.H == 0) {
+            org = (size_t)win_ * L;
+        } else {
+            const int per = g.nWh * g.nWw;
+            const int b = __builtin_amdgcn_readfirstlane(win_ / per), r = win_ - b * per;
+            const int wr = __builtin_amdgcn_readfirstlane(r / g.nWw), wc = r - wr * g.nWw;
+            org = ((size_t)b * g.H + wr * WS) * g.W + wc * WS;
+        }
+    };
+    int win, head, qoff, koff, voff;
+    size_t origin;
+    locate(blockIdx.x, win, head, qoff, koff, voff, origin);
+    // windows from this number on are switched off (read once)
+    const int n_live = g.n_live != nullptr ? __builtin_amdgcn_readfirstlane(*g.n_live) : 0x7fffffff;
+    if (win >= n_live) {  // uniform over the workgroup
         zero_window_slice<T>(out, g.ldo, origin, pitch, WS, head * D, D, head == g.heads - 1, g.C, tid, THREADS);
         for (int l = tid; l < L; l += THREADS) lse[((size_t)win * g.heads + head) * L + l] = 0.f;
         return;
@@ -78,6 +84,14 @@ __global__ __launch_bounds__(512, FWD_W16_WAVES) void win_attn_fwd_w16_kernel(At
     const T *qkv0 = qkv + origin * C3;  // wave-uniform 64-bit base, 32-bit lane offsets
 
     // ---- loads: this wave's Q fragments (slots hh and 2 + hh of row 32 wave + l31), then K and V --------------
+    // (the head's column of the bias table first, both sweeps at once: back before the operands)
+    static_assert(TR * TR <= 2 * THREADS, "two table entries per thread");
+    float tabv[2] = {0.f, 0.f};
+    if constexpr (BIAS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + THREADS * i < TR * TR) tabv[i] = table[(size_t)(tid + THREADS * i) * g.heads + head];
+    }
     const int qrow = 32 * wave + l31;
     const unsigned qrel = rel_row(qrow) * C3 + qoff + 8 * hh;
     uint4 qraw[2];
@@ -94,9 +108,10 @@ __global__ __launch_bounds__(512, FWD_W16_WAVES) void win_attn_fwd_w16_kernel(At
             vv[i] = load16_a4(qkv0 + (rel + voff));
         }
         if constexpr (BIAS) {
-            for (int it = tid; it < TR * TR; it += THREADS) {
-                const int di = it / TR, dj = it - di * TR;
-                tb[TMAX - (di * TS + dj)] = table[(size_t)it * g.heads + head] * LOG2E;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int it = tid + THREADS * i, di = it / TR, dj = it - di * TR;
+                if (it < TR * TR) tb[TMAX - (di * TS + dj)] = tabv[i] * LOG2E;
             }
         }
 #pragma unroll
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(512, FWD_W16_WAVES) void win_attn_fwd_w16_kernel(At
     }
 
     // ---- epilogue: normalise, store -----------------------------------------------------------------------------
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);  // (1 ulp: the result is rounded to bf16)
     if (hh == 0) lse[((size_t)win * g.heads + head) * L + qrow] = (rref + __builtin_amdgcn_logf(sum)) * LN2;
     // the output tile leaves through this wave's 32 rows of the K image, once no wave reads K or V any more
     __syncthreads();
