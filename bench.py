@@ -500,10 +500,12 @@ def main():
     x = torch.randn(B_PER_GPU, HW, HW, C, device=device, generator=gen).requires_grad_()
     pair.sdwa.gumbel_noise = -torch.empty(B_PER_GPU, (HW // WIN) ** 2, device=device).exponential_(generator=gen).log()
 
-    def step():
+    from visiontransformer_amd.parallel import GraphedTrainStep, graph_safe_sum
+
+    def eager_step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = model(x)
-        y.float().sum().backward()
+        graph_safe_sum(y.float()).backward()
         model.zero_grad(set_to_none=True)
         x.grad = None
 
@@ -513,8 +515,36 @@ def main():
     # waits on the GPU, would otherwise land inside a 20-step timed region and double its average.
     import gc
     for _ in range(15):
-        step()
+        eager_step()
     torch.cuda.synchronize()
+    # The step as a training loop on this machine runs it: forward, loss and backward captured once as a HIP graph
+    # and replayed (parallel.GraphedTrainStep; the path has no host read).  Issued launch by launch the step costs
+    # the host as long as it costs the GPU (tools/host_step_probe.py).  The same kernels on the same data either
+    # way; BENCH_EAGER=1 times the launch-by-launch form, which is also the fallback when the capture fails.
+    step_mode = "hip graph replay (forward + loss + backward captured once)"
+    step = eager_step
+    if os.environ.get("BENCH_EAGER") == "1":
+        step_mode = "eager (BENCH_EAGER=1)"
+    elif grouped and os.environ.get("BENCH_DDP") == "1":
+        step_mode = "eager (DistributedDataParallel's reducer works from autograd hooks)"
+    else:
+        try:
+            # N > 1: the graph holds the local step; the one all-reduce of the flat gradient buffer follows the replay
+            graphed = GraphedTrainStep(pair, lambda y: graph_safe_sum(y.float()))
+            if grouped:
+                def step():
+                    graphed(x)
+                    model.reduce_gradients()
+                step_mode += ", then one RCCL all-reduce of the flat gradient buffer"
+            else:
+                step = lambda: graphed(x)
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:   # reported in the line; the eager step is the same work
+            step_mode = "eager (graph capture failed: %s: %s)" % (type(e).__name__, str(e)[:200])
+            step = eager_step
+            model.zero_grad(set_to_none=True)
+            x.grad = None
     gc.collect()
     gc.freeze()
     for _ in range(args.warmup):
@@ -564,6 +594,7 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
+            "step_mode": step_mode,
             "config": {"workload": "B: DSWT WindowedMSA+DS-MSA fwd+bwd, batch 32 x 64x64 LR patches, C=180, 6 heads, "
                                    "16x16 windows, bf16 autocast, k=4 windows/image (num_win_selected 0.25), "
                                    "%d of %d candidate windows passed the gate" % (n_pass, B_PER_GPU * 4),

@@ -270,7 +270,12 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 for (int g = 0; g < 4; ++g) {
                     const float4 v = make_float4(a[t][4 * g] + bv[t][g].x, a[t][4 * g + 1] + bv[t][g].y, a[t][4 * g + 2] + bv[t][g].z,
                                                  a[t][4 * g + 3] + bv[t][g].w);
-                    io<TC>::st4(reinterpret_cast<TC *>(stg + l31 * SROW) + tt * 32 + 8 * g + 4 * hh, v);
+                    // bf16: a lane stores 8 bytes, and the rows 8 apart that one store instruction's 16-lane groups hold
+                    // are 288 dwords apart - the same banks.  Rows 8-15 and 24-31 therefore keep the two halves of
+                    // every 16-byte piece swapped (the reader below swaps them back in registers, for free: which
+                    // rows it holds is a compile-time constant per pass).
+                    const int swz = sizeof(TC) == 2 ? ((l31 >> 3) & 1) * 4 : 0;
+                    io<TC>::st4(reinterpret_cast<TC *>(stg + l31 * SROW) + ((tt * 32 + 8 * g + 4 * hh) ^ swz), v);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 const int row = i * 8 + (lane >> 3), m = m0 + wave * 32 + row;
                 const int col = nb + ps * SW + (lane & 7) * PC;
                 uint4 v = *reinterpret_cast<const uint4 *>(stg + row * SROW + (lane & 7) * 16);
+                if (sizeof(TC) == 2 && (i & 1)) v = make_uint4(v.z, v.w, v.x, v.y);
                 TC *dst = C + (size_t)m * ldc + col;
                 if (m < M) {
                     if constexpr (sizeof(TC) == 4) {

@@ -140,6 +140,11 @@ class FlatDataParallel(torch.nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self._reduce)
         return None
 
+    def reduce_gradients(self):
+        """the all-reduce of a step whose backward pass did not run under this wrapper's hook: after a replay of
+        GraphedTrainStep(self.module, ...), whose captured backward leaves the local gradients in p.grad"""
+        self._reduce()
+
     @torch.no_grad()
     def _reduce(self):
         self._armed_task = None
@@ -277,6 +282,113 @@ class GraphedForward:
         static_x.copy_(x)
         graph.replay()
         return static_y
+
+
+def graph_safe_sum(t, block=1024):
+    """Sum of all elements of t by reductions that each fit one workgroup (rows of `block` elements, then the row
+    sums the same way), differentiable.  For losses inside GraphedTrainStep: torch's reduction of a large tensor to
+    one value runs over several workgroups behind a memset of its arrival counters, and in a replayed graph on
+    ROCm 7.2 that memset node was seen to lose its place among the kernel nodes when the host had synchronised
+    before the replay - the value came out wrong (a partial sum) while every gradient stayed right."""
+    t = t.reshape(-1)
+    while t.numel() > 4 * block:
+        n = t.numel()
+        m = n // block * block
+        head = t[:m].view(-1, block).sum(1)
+        t = head if m == n else torch.cat([head, t[m:]])
+    return t.sum()
+
+
+def graph_safe_mean(t, block=1024):
+    """mean of all elements of t, see graph_safe_sum"""
+    return graph_safe_sum(t, block) / t.numel()
+
+
+class GraphedTrainStep:
+    """Forward, loss and backward of `model` captured once per input shape as a HIP graph and replayed.
+
+    The attention pair's training step is about sixty launches of 5-200 us each, and the Python and autograd work
+    that issues them (about 1.4 ms) is as long as the GPU's share: replayed from a graph the step costs the host one
+    call.  What makes the capture possible is that the training path has no host read (DS-MSA keeps its pass count
+    on the device, every window slot is computed or zeroed by the kernels) and that every kernel is deterministic.
+
+    step = GraphedTrainStep(model, loss_fn); loss = step(x, *loss_args) leaves the gradients in p.grad - the
+    graph's own buffers, OVERWRITTEN by the next call (not accumulated: do not zero them, and take optimizer steps
+    between calls as usual; they read p.grad and update the parameters in place, which the replays see).  x and
+    loss_args are copied into the graph's input buffers unless they ARE those buffers (the tensors passed at
+    capture are adopted), so a loader that fills the same tensors every step pays no copy; x.grad is produced when
+    x requires it.  A `model` wrapped in FlatDataParallel has its one all-reduce inside the graph.  Host-side
+    randomness drawn per call (attention dropout seeds) is replayed as captured; the Gumbel noise of DS-MSA is a
+    tensor and can be refilled in place between calls.  Reduce the loss to its scalar with graph_safe_sum /
+    graph_safe_mean (see there) rather than with a plain .sum() / .mean() of a large tensor.  One graph per (shapes, dtypes, autocast) key, at most
+    max_graphs; beyond that, and on CPU tensors, the step runs eagerly."""
+
+    def __init__(self, model, loss_fn, autocast_dtype=torch.bfloat16, warmup=3, max_graphs=4):
+        self.model = model
+        self.loss_fn = loss_fn
+        self.autocast_dtype = autocast_dtype
+        self.warmup = warmup
+        self.max_graphs = max_graphs
+        self._graphs = {}
+
+    def _eager(self, x, *loss_args):
+        if self.autocast_dtype is not None and x.is_cuda:
+            with torch.autocast("cuda", dtype=self.autocast_dtype):
+                y = self.model(x)
+        else:
+            y = self.model(x)
+        loss = self.loss_fn(y, *loss_args)
+        loss.backward()
+        return loss.detach()
+
+    def _params(self):
+        return [p for p in self.model.parameters() if p.requires_grad]
+
+    def __call__(self, x, *loss_args):
+        if not x.is_cuda:
+            return self._eager(x, *loss_args)
+        key = (tuple(x.shape), x.dtype, x.device, x.requires_grad, self.autocast_dtype,
+               tuple((tuple(a.shape), a.dtype) for a in loss_args))
+        entry = self._graphs.get(key)
+        if entry is None:
+            if len(self._graphs) >= self.max_graphs:
+                return self._eager(x, *loss_args)
+            entry = self._graphs[key] = self._capture(x, loss_args)
+        graph, static_x, static_args, static_loss, grads, x_grad = entry
+        if x.data_ptr() != static_x.data_ptr():
+            static_x.copy_(x)
+        for a, sa in zip(loss_args, static_args):
+            if a.data_ptr() != sa.data_ptr():
+                sa.copy_(a)
+        graph.replay()
+        for p, g in grads:
+            if p.grad is not g:
+                p.grad = g
+        if x_grad is not None:
+            x.grad = x_grad
+        return static_loss
+
+    def _capture(self, x, loss_args):
+        params = self._params()
+        # eager warm-up on a side stream (code objects, allocator growth, library set-up), as graph capture asks
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                for p in params:
+                    p.grad = None
+                x.grad = None
+                self._eager(x, *loss_args)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        for p in params:
+            p.grad = None      # the captured backward then CREATES the gradients (in the graph's pool): no accumulate
+        x.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = self._eager(x, *loss_args)
+        grads = [(p, p.grad) for p in params if p.grad is not None]
+        return graph, x, tuple(loss_args), static_loss, grads, x.grad
 
 
 @torch.no_grad()
