@@ -54,10 +54,14 @@ def build_pair(device, seed=0):
             self.sdwa = DeformableSparseWindowAttention(WIN, C, HEADS)
 
         def forward(self, x):
-            # residual form of the reference's ViTBlock (DSwinT_arch.py:355-356): the fp32 stream
-            # feeds both attentions
-            x = x + self.wmsa(x)
-            return x + self.sdwa(x)
+            # residual form of the reference's ViTBlock (DSwinT_arch.py:355-356): the fp32 stream feeds both
+            # attentions; x + branch(x) with the addition inside the branch's closing kernel (BENCH_UNFUSED_RESIDUAL=1:
+            # as two torch additions)
+            if os.environ.get("BENCH_UNFUSED_RESIDUAL") == "1":
+                x = x + self.wmsa(x)
+                return x + self.sdwa(x)
+            x = self.wmsa(x, residual=(x, None))
+            return self.sdwa(x, residual=(x, None))
 
     m = Pair()
     with torch.no_grad():

@@ -142,6 +142,18 @@ int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtyp
                          int ld_d_after, float *d_gates_delta, float *d_scores_delta, float *partial,
                          const int *n_live, void *stream);
 
+/* The same backward with dx = dx_add + (the gradient): dx_add [B,H,W,C], of dx's dtype and not dx itself, is a
+ * gradient that reaches the same tensor by another route - the residual around the module,
+ * DSwinT_arch.py:356 - read here instead of being added by a pass of its own; it is left untouched. */
+int dsw_scatter_mean_bwd_add(const void *dy, int dy_dtype, const void *x, int x_dtype,
+                             const void *after, int after_dtype, const float *gates_delta,
+                             const float *scores_delta, const int *cellmap, const int *win_b,
+                             const int *win_h1, const int *win_w1, int n_win,
+                             int B, int H, int W, int C, int w, int ld_after,
+                             void *dx, int dx_dtype, const void *dx_add, void *d_after, int d_after_dtype,
+                             int ld_d_after, float *d_gates_delta, float *d_scores_delta, float *partial,
+                             const int *n_live, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * (3)+(5) Fused window attention on MFMA: softmax(q k^T * scale + bias) v per (window, head),
  *     with window partition / headify / chunk / deheadify / reverse done as address arithmetic.

@@ -135,6 +135,99 @@ def test_dsmsa_bf16_autocast_against_the_oracle(cuda0, training):
         assert rel_err(p.grad, ref) < tol, (n, rel_err(p.grad, ref))
 
 
+def test_wmsa_with_the_residual_inside_against_the_oracle(cuda0):
+    """x + WindowedMSA(x) with the residual taken inside the closing projection (forward) and the residual's gradient
+    read by the kernel that writes the q|k|v projection's input gradient (backward): bf16 autocast on the GPU against
+    x + oracle on the same bf16-representable inputs - y (fp32), dx and every parameter gradient; and against the
+    unfused composition, which the fused form must follow at least as closely as the oracle."""
+    from visiontransformer_amd.dswin import WindowedMSA
+    torch.manual_seed(31)
+    mod = WindowedMSA(16, 180, 6)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn_like(p) * (0.5 if p.dim() == 2 and p.shape[1] == 6 else (p.shape[-1] ** -0.5 if p.dim() == 2 else 0.1)))
+    _bf16_representable_(mod)
+    x = torch.randn(2, 64, 64, 180).to(torch.bfloat16).float()
+    r = torch.randn(2, 64, 64, 180)
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in mod.state_dict().items()}
+    x_ref = x.clone().requires_grad_()
+    y_ref = x_ref + D.wmsa_forward(P, x_ref, 16, 6)
+    dx_ref, g_ref = _oracle_grads(P, y_ref, x_ref, r)
+    mod = mod.to(cuda0)
+    rg = r.to(cuda0)
+
+    def run(fused):
+        mod.zero_grad(set_to_none=True)
+        xg = x.to(cuda0).requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(xg, residual=(xg, None)) if fused else xg + mod(xg)
+        assert y.dtype == torch.float32
+        (y * rg).sum().backward()
+        return y.detach(), xg.grad, {n: p.grad.clone() for n, p in mod.named_parameters()}
+
+    y, dx, g = run(True)
+    assert rel_err(y, y_ref) < BF16_TOL
+    assert rel_err(dx, dx_ref) < BF16_TOL
+    for n in g:
+        assert rel_err(g[n], g_ref[n]) < BF16_TOL, n
+    y0, dx0, g0 = run(False)
+    assert rel_err(y, y0) < 5e-3 and rel_err(dx, dx0) < 5e-3
+    for n in g:
+        assert rel_err(g[n], g0[n]) < 1e-2, n
+    # a stream that is not the module's input: the residual's gradient goes back through autograd
+    xa = x.to(cuda0).requires_grad_()
+    sa = (0.5 * x).to(cuda0).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = mod(xa, residual=(sa, 1.0))
+    (ya * rg).sum().backward()
+    assert torch.equal(sa.grad, rg)
+    assert rel_err(xa.grad, dx0 - rg) < 1e-2
+
+
+def test_dsmsa_with_the_residual_inside_against_its_composition(cuda0):
+    """x + DS-MSA(x) in training with the residual taken inside the closing convolution and its gradient read by the
+    scatter's backward kernel, against the unfused composition x + module(x) on the same inputs and noise: same window
+    decisions (bit-equal), y, dx and every parameter gradient within bf16 rounding of each other (the fused form skips
+    one rounding of the branch to bf16)."""
+    from visiontransformer_amd.dswin import DeformableSparseWindowAttention
+    torch.manual_seed(32)
+    B, H, W, C, heads, w = 4, 64, 64, 180, 6, 16
+    mod = DeformableSparseWindowAttention(w, C, heads)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            p.copy_(torch.randn_like(p) * (p[0].numel() ** -0.5 if p.dim() >= 2 else 0.1))
+        mod.pe.relative_position_bias_table.normal_(0, 0.5)
+        mod.sparse_discriminator[4].weight.mul_(6.0)
+        mod.sparse_discriminator[4].bias[1] += 0.6
+    mod.num_win_selected = 0.5
+    mod = mod.to(cuda0).train()
+    mod.gumbel_noise = -torch.empty(B, (H // w) * (W // w), device=cuda0).exponential_().log()
+    x = torch.randn(B, H, W, C, device=cuda0)
+    rg = torch.randn(B, H, W, C, device=cuda0)
+
+    def run(fused):
+        mod.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(xg, residual=(xg, None)) if fused else xg + mod(xg)
+        assert y.dtype == torch.float32
+        (y * rg).sum().backward()
+        sel = mod.last_selection
+        return y.detach(), xg.grad, {n: p.grad.clone() for n, p in mod.named_parameters()}, (sel.cand_idx.clone(), sel.cand_pass.clone(), sel.win_h1.clone())
+
+    y, dx, g, s = run(True)
+    y0, dx0, g0, s0 = run(False)
+    assert all(torch.equal(a, b) for a, b in zip(s, s0))
+    assert int(mod.last_selection.n_dev.item()) > 0
+    assert rel_err(y, y0) < 5e-3
+    assert rel_err(dx, dx0) < 5e-3
+    for n in g:
+        if float(g0[n].abs().max()) == 0.0:
+            assert float(g[n].abs().max()) == 0.0, n
+            continue
+        assert rel_err(g[n], g0[n]) < (6e-2 if n.startswith("sparse_discriminator") else 1.5e-2), (n, rel_err(g[n], g0[n]))
+
+
 def test_default_width_dswt_against_the_reference(cuda0):
     """The 14.6 M-parameter default DSWT network (configs/config.yaml) on one 64x64 LR patch, fp32, eval: the
     output the REFERENCE produced (tests/golden/make_golden.py dswt_model_default) for parameters drawn per

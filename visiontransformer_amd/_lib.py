@@ -34,6 +34,8 @@ SIGNATURES = {
     "dsw_scatter_mean_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 7 + [_P, _I, _P]),
     "dsw_scatter_mean_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 7 +
                              [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "dsw_scatter_mean_bwd_add": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 7 +
+                                 [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "dsw_win_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _F, ctypes.c_ulonglong, _P, _P]),
     "dsw_win_attn_bwd_workspace": (_Z, [_I] * 8),
     "dsw_win_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P,

@@ -286,7 +286,9 @@ template <typename TG, typename TO, bool ACC>
 __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
     const TG *__restrict__ dy, const float *__restrict__ gates_delta, const float *__restrict__ scores_delta,
     const int *__restrict__ cellmap, const int *__restrict__ win_h1, const int *__restrict__ win_w1, int H,
-    int W, int C, int w, int tiles_per_row, TO *__restrict__ dx) {
+    int W, int C, int w, int tiles_per_row, TO *dx, const TO *acc_src) {
+    // (ACC: the result is acc_src + the gradient; acc_src is dx itself for accumulation in place, or another map of
+    // the same shape - a gradient that reaches the same tensor by another route - which is then left untouched)
     __shared__ float fac[2][TILE_PIX + 1];  // sum_n(s_n*g_n)/count at the sample position, 0 if uncovered
     const int Hw = H / w, Ww = W / w;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
     const TG *grow = gimg + (size_t)y * W * C;                     // image row y
     const TG *gup = gimg + (size_t)(y > 0 ? y - 1 : 0) * W * C;    // row y - 1 (its factors are 0 when y == 0)
     TO *drow = dx + (((size_t)b * H + y) * W) * C;
+    const TO *arow = ACC ? acc_src + (((size_t)b * H + y) * W) * C : nullptr;
     // A thread takes SB_U items (pixel, 4 channels) per trip.  Their own dy values (and the destination when
     // accumulating) are asked for together one trip ahead - the first trip's before the covering windows are
     // looked up, so that the lookup's two memory latencies pass under them - and an item with a covered sample
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(GS_THREADS) void scatter_bwd_dx_kernel(
             t.p[u] = p;
             t.c[u] = c;
             t.ctr[u] = io<TG>::ld4(grow + (size_t)(x0 + p) * C + c);
-            if constexpr (ACC) t.old[u] = io<TO>::ld4(drow + (size_t)(x0 + p) * C + c);
+            if constexpr (ACC) t.old[u] = io<TO>::ld4(arow + (size_t)(x0 + p) * C + c);
         }
     };
     Trip cur;
@@ -531,13 +534,13 @@ extern "C" int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *afte
     return check_launch("scatter_fwd_kernel");
 }
 
-extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype,
-                                    const void *after, int after_dtype, const float *gates_delta,
-                                    const float *scores_delta, const int *cellmap, const int *win_b,
-                                    const int *win_h1, const int *win_w1, int n_win, int B, int H, int W,
-                                    int C, int w, int ld_after, void *dx, int dx_dtype, int accumulate_dx,
-                                    void *d_after, int d_after_dtype, int ld_d_after, float *d_gates_delta,
-                                    float *d_scores_delta, float *partial, const int *n_live, void *stream) {
+static int scatter_mean_bwd_impl(const void *dy, int dy_dtype, const void *x, int x_dtype,
+                                 const void *after, int after_dtype, const float *gates_delta,
+                                 const float *scores_delta, const int *cellmap, const int *win_b,
+                                 const int *win_h1, const int *win_w1, int n_win, int B, int H, int W,
+                                 int C, int w, int ld_after, void *dx, int dx_dtype, int accumulate_dx, const void *dx_add,
+                                 void *d_after, int d_after_dtype, int ld_d_after, float *d_gates_delta,
+                                 float *d_scores_delta, float *partial, const int *n_live, void *stream) {
     int rc = check_geometry("dsw_scatter_mean_bwd", B, H, W, C, w);
     if (rc) return rc;
     if (!ld_after) ld_after = C;
@@ -555,14 +558,14 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
     const int tiles = (W + TILE_PIX - 1) / TILE_PIX;
     hipStream_t st = as_stream(stream);
     DSW_DISPATCH_DTYPE(dy_dtype, TG, DSW_DISPATCH_DTYPE(dx_dtype, TO, {
-        if (accumulate_dx)
+        if (accumulate_dx || dx_add != nullptr)
             hipLaunchKernelGGL((scatter_bwd_dx_kernel<TG, TO, true>), dim3(B * H * tiles), dim3(GS_THREADS), 0, st,
                                (const TG *)dy, gates_delta, scores_delta, cellmap, win_h1, win_w1, H, W, C, w, tiles,
-                               (TO *)dx);
+                               (TO *)dx, dx_add != nullptr ? (const TO *)dx_add : (const TO *)dx);
         else
             hipLaunchKernelGGL((scatter_bwd_dx_kernel<TG, TO, false>), dim3(B * H * tiles), dim3(GS_THREADS), 0, st,
                                (const TG *)dy, gates_delta, scores_delta, cellmap, win_h1, win_w1, H, W, C, w, tiles,
-                               (TO *)dx);
+                               (TO *)dx, (const TO *)nullptr);
     }));
     rc = check_launch("scatter_bwd_dx_kernel");
     if (rc || n_win == 0) return rc;
@@ -586,4 +589,29 @@ extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x,
     hipLaunchKernelGGL(scatter_bwd_reduce_kernel, dim3((n_win + 63) / 64), dim3(64), 0, st, partial, n_win, w,
                        d_gates_delta, d_scores_delta);
     return check_launch("scatter_bwd_reduce_kernel");
+}
+
+extern "C" int dsw_scatter_mean_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype,
+                                    const void *after, int after_dtype, const float *gates_delta,
+                                    const float *scores_delta, const int *cellmap, const int *win_b,
+                                    const int *win_h1, const int *win_w1, int n_win, int B, int H, int W,
+                                    int C, int w, int ld_after, void *dx, int dx_dtype, int accumulate_dx,
+                                    void *d_after, int d_after_dtype, int ld_d_after, float *d_gates_delta,
+                                    float *d_scores_delta, float *partial, const int *n_live, void *stream) {
+    return scatter_mean_bwd_impl(dy, dy_dtype, x, x_dtype, after, after_dtype, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1,
+                                 n_win, B, H, W, C, w, ld_after, dx, dx_dtype, accumulate_dx, nullptr, d_after, d_after_dtype, ld_d_after,
+                                 d_gates_delta, d_scores_delta, partial, n_live, stream);
+}
+
+extern "C" int dsw_scatter_mean_bwd_add(const void *dy, int dy_dtype, const void *x, int x_dtype,
+                                        const void *after, int after_dtype, const float *gates_delta,
+                                        const float *scores_delta, const int *cellmap, const int *win_b,
+                                        const int *win_h1, const int *win_w1, int n_win, int B, int H, int W,
+                                        int C, int w, int ld_after, void *dx, int dx_dtype, const void *dx_add,
+                                        void *d_after, int d_after_dtype, int ld_d_after, float *d_gates_delta,
+                                        float *d_scores_delta, float *partial, const int *n_live, void *stream) {
+    DSW_REQUIRE(dx_add != nullptr && dx_add != dx, "dsw_scatter_mean_bwd_add: dx_add must be a map other than dx");
+    return scatter_mean_bwd_impl(dy, dy_dtype, x, x_dtype, after, after_dtype, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1,
+                                 n_win, B, H, W, C, w, ld_after, dx, dx_dtype, 0, dx_add, d_after, d_after_dtype, ld_d_after,
+                                 d_gates_delta, d_scores_delta, partial, n_live, stream);
 }

@@ -107,19 +107,33 @@ class WindowedMSA(WindowedAttention):
         self.padded_output = True
 
     def forward(self, x, residual=None):
-        """residual = (stream, r), inference only: returns stream + r * attention(x) with the residual taken
-        inside out_proj's kernel (the caller's ReZero residual, DSwinT_arch.py:355), instead of attention(x)."""
+        """residual = (stream, r): returns stream + r * attention(x) - the caller's residual (DSwinT_arch.py:355) -
+        instead of attention(x), with the residual taken inside out_proj's kernel where that is possible: without
+        autograd for any r (ReZero), with autograd for a plain residual (r None or 1.0).  When the stream is x itself
+        (y = x + attention(x)), its gradient dy is not added to the projection's input gradient by a pass of its own:
+        the kernel that writes that gradient reads it as one more operand (functional.PendingGrad)."""
         B, H, W, C = x.shape
         # attention dropout as F.dropout(..., training=self.training) applies it (DSwinT_arch.py:172), inside the kernels
         drop_p = self.attn_drop if self.training else 0.0
+        plain = residual is not None and (residual[1] is None or (isinstance(residual[1], (int, float)) and residual[1] == 1))
+        pend = K.PendingGrad() if (plain and torch.is_grad_enabled() and residual[0] is x and x.requires_grad
+                                   and x.dtype == torch.float32 and x.is_contiguous()) else None
         z = None
         if drop_p == 0.0:   # without autograd: projection and attention in one kernel, q|k|v never written
             z = K.projected_window_attention(x, self.qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED,
                                              grid=(B, H, W), pad_out=True)
         if z is None:
-            qkv = K.linear(x, self.qkv, pad_out=True)
+            qkv = K.linear(x, self.qkv, pad_out=True, grad_extra=pend)
             z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W),
                                    pad_out=True, dropout_p=drop_p, dropout_seed=self.dropout_seed)
+        if plain:
+            y = K.linear_plus_residual(z, self.out_proj, residual[0], pend) if torch.is_grad_enabled() else None
+            if y is None and not torch.is_grad_enabled():
+                y = K.linear_residual(z, self.out_proj, residual[0], torch.ones(1, device=x.device))
+            if y is not None:
+                return y
+            # (pend, if any, stays empty: the addition below hands the stream its gradient through autograd)
+            return residual[0] + K.linear(z, self.out_proj, pad_out=True)
         if residual is not None:
             y = K.linear_residual(z, self.out_proj, *residual)
             return y if y is not None else K.rezero_residual(residual[0], residual[1], K.linear(z, self.out_proj, pad_out=True))
@@ -215,19 +229,29 @@ class DeformableSparseWindowAttention(WindowedAttention):
         return -torch.empty_like(scores_flat, memory_format=torch.legacy_contiguous_format).exponential_().log()
 
     def forward(self, x, residual=None):
-        """residual = (stream, r), inference only: returns stream + r * attention(x) - the caller's ReZero residual
-        (DSwinT_arch.py:356) - taken inside the closing convolution's kernel where that is the last step."""
+        """residual = (stream, r): returns stream + r * attention(x) - the caller's residual (DSwinT_arch.py:356) -
+        taken inside the closing convolution's kernel where that is the last step: without autograd for any r (ReZero),
+        with autograd for a plain residual (r None or 1.0; when the stream is x itself its gradient joins the
+        module's input gradient inside the scatter's backward kernel, functional.PendingGrad)."""
         if residual is None:
             return self._forward(x, None)
+        plain = residual[1] is None or (isinstance(residual[1], (int, float)) and residual[1] == 1)
+        if plain and not torch.is_grad_enabled():
+            residual = (residual[0], torch.ones(1, device=x.device))
         y = self._forward(x, residual)
         if isinstance(y, tuple):     # (result, True): the residual is in already
             return y[0]
+        if plain:
+            return residual[0] + y
         return K.rezero_residual(residual[0], residual[1], y)
 
     def _forward(self, x, residual):
         B, H, W, C = x.shape
         w = self.w
+        x_in = x
         x = K.supported_input(x).contiguous()
+        if x is not x_in:
+            x_in = None      # the kernels read a copy: the caller's tensor is not the one the sink collects for
         act = K.autocast_dtype(x.dtype)
         # the three readers of x meet in one gradient buffer (only when all three are certain to run
         # in the backward pass: the early returns below leave the sparse discriminator alone)
@@ -262,7 +286,15 @@ class DeformableSparseWindowAttention(WindowedAttention):
             after = K.linear(z, self.out_proj, pad_out=True, live=live)
             y = K.scatter_mean_residual(x, after, sel, w, sink=sink)
             # no window passed (DSwinT_arch.py:291-292: return x): the last kernel copies instead of convolving
-            if residual is not None:
+            if residual is not None and torch.is_grad_enabled():
+                if residual[1] is None or isinstance(residual[1], (int, float)):   # a plain residual (forward() checked: 1)
+                    # the stream's gradient meets the three readers of x in the sink when the stream is x
+                    pend = sink.pending if (sink is not None and residual[0] is x_in) else None
+                    out = K.dwconv3x3_plus_residual_nhwc(y, self.out_conv.weight, self.out_conv.bias, residual[0], pend,
+                                                         identity_if_zero=sel.n_dev)
+                    if out is not None:
+                        return out, True
+            elif residual is not None:
                 out = K.dwconv3x3_residual_nhwc(y, self.out_conv.weight, self.out_conv.bias, residual[0], residual[1],
                                                 identity_if_zero=sel.n_dev)
                 if out is not None:

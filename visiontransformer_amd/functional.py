@@ -249,6 +249,26 @@ def select_windows_static(sd, noise, tau, k, w, H, W):
                      n_dev=n_pass)
 
 
+class PendingGrad:
+    """A gradient on its way to a tensor that a later backward kernel of the same pass also produces a gradient for:
+    the residual around a module (y = x + f(x), DSwinT_arch.py:355-356) hands dy here instead of returning it to
+    autograd, and the kernel that writes f's input gradient reads it as one more operand - out = dy + its own
+    result - instead of autograd adding the two maps in a pass of its own.  Never modified: it may be a tensor
+    that other consumers of dy still read.  The state belongs to one backward pass (see GradSink._same_pass)."""
+
+    def __init__(self):
+        self.g = None
+        self.task = None
+
+    def put(self, g):
+        self.task = torch._C._current_graph_task_id()
+        self.g = g
+
+    def take(self):
+        g, self.g = self.g, None
+        return g if self.task == torch._C._current_graph_task_id() else None
+
+
 class GradSink:
     """Meeting point for the gradients that several custom ops send to the SAME input tensor.
 
@@ -266,6 +286,7 @@ class GradSink:
         self.count = 0
         self.buf = None
         self.task = None
+        self.pending = PendingGrad()   # the residual's gradient, when the caller's residual is taken inside the module
 
     def _same_pass(self):
         """state belongs to one backward pass: a pass that ended early (an exception, a partial backward over a
@@ -286,6 +307,9 @@ class GradSink:
         self.count += 1
         if self.count == self.expected:
             self.count, self.buf = 0, None
+            extra = self.pending.take()
+            if extra is not None:   # no kernel of this pass read it as an operand: one pass over our own buffer
+                buf.add_(extra.reshape(buf.shape))
             return buf
         self.buf = buf
         return None
@@ -371,11 +395,22 @@ class _ScatterMeanFn(torch.autograd.Function):
         d_after = _mark_padded(torch.empty(after.shape[0], lda, dtype=after.dtype, device=dev))
         dg = torch.empty(2, n, dtype=torch.float32, device=dev)
         partial = torch.empty(2 * n * w, dtype=torch.float32, device=dev)
-        call("dsw_scatter_mean_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype),
-             _dptr(after), dtype_code(after.dtype), ptr(gates_delta), ptr(scores_delta), ptr(cellmap),
-             ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, lda, ptr(dx), dtype_code(dx.dtype), acc,
-             ptr(d_after), dtype_code(d_after.dtype), lda, ptr(dg[0]), ptr(dg[1]), ptr(partial),
-             None if n_live is None else ptr(n_live), stream(dev))
+        extra = sink.pending.take() if sink is not None and acc == 0 else None
+        if extra is not None and not (extra.dtype == dx.dtype and extra.shape == dx.shape and extra.is_contiguous()):
+            sink.pending.put(extra)   # not a map this kernel can read: the sink's last delivery adds it
+            extra = None
+        if extra is not None:
+            call("dsw_scatter_mean_bwd_add", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype),
+                 _dptr(after), dtype_code(after.dtype), ptr(gates_delta), ptr(scores_delta), ptr(cellmap),
+                 ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, lda, ptr(dx), dtype_code(dx.dtype), ptr(extra),
+                 ptr(d_after), dtype_code(d_after.dtype), lda, ptr(dg[0]), ptr(dg[1]), ptr(partial),
+                 None if n_live is None else ptr(n_live), stream(dev))
+        else:
+            call("dsw_scatter_mean_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype),
+                 _dptr(after), dtype_code(after.dtype), ptr(gates_delta), ptr(scores_delta), ptr(cellmap),
+                 ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, lda, ptr(dx), dtype_code(dx.dtype), acc,
+                 ptr(d_after), dtype_code(d_after.dtype), lda, ptr(dg[0]), ptr(dg[1]), ptr(partial),
+                 None if n_live is None else ptr(n_live), stream(dev))
         return _dx_deliver(sink, dx), d_after[:, :C].view(after_shape), dg[0], dg[1], None, None, None, None, None, None, None
 
 
@@ -683,6 +718,60 @@ def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None, identity_if_zero=None):
     return _run(_DWConvFn, x, weight, bias, out_dtype or x.dtype, identity_if_zero)
 
 
+class _DWConvResidualFn(torch.autograd.Function):
+    """resid + dwconv3x3(x) as fp32 (dsw_dwconv3x3_residual_fwd with a scale of one): DS-MSA's closing convolution
+    with the plain residual of the block around it.  The backward reads the fp32 gradient as it arrives; the
+    residual's share of it - dy itself - goes to `pending` when the caller gives one (PendingGrad) and back to
+    autograd otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, resid, pending, identity_if_zero=None):
+        _lib.require_cuda(x, resid)
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        w32 = weight.detach().to(torch.float32).reshape(C, 9).contiguous()
+        b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        one = torch.ones(1, dtype=torch.float32, device=x.device)
+        y = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        call("dsw_dwconv3x3_residual_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(resid), ptr(one), ptr(y),
+             None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
+        ctx.save_for_backward(x, w32, identity_if_zero)
+        ctx.meta = (weight.shape, weight.dtype, None if bias is None else bias.dtype)
+        ctx.pending = pending
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w32, ident = ctx.saved_tensors
+        wshape, wdt, bdt = ctx.meta
+        B, H, W, C = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, 9, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        nblk = _lib.load().dsw_dwconv3x3_bwd_blocks(B, H, W)
+        partial = torch.empty((nblk + 1) * C * 10, dtype=torch.float32, device=dev)
+        call("dsw_dwconv3x3_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype), ptr(w32), B, H, W, C,
+             ptr(dx), dtype_code(dx.dtype), ptr(dw), ptr(db), ptr(partial), None if ident is None else ptr(ident), stream(dev))
+        d_resid = None
+        if ctx.needs_input_grad[3]:
+            if ctx.pending is not None:
+                ctx.pending.put(dy)
+            else:
+                d_resid = dy
+        return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), d_resid, None, None
+
+
+def dwconv3x3_plus_residual_nhwc(x, weight, bias, resid, pending=None, identity_if_zero=None):
+    """resid + dwconv3x3(x), fp32, with autograd (see _DWConvResidualFn); None when the call is not one the kernel
+    takes - the caller then composes dwconv3x3_nhwc() and an addition."""
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and resid.is_cuda and resid.dtype == torch.float32
+            and resid.is_contiguous() and resid.shape == x.shape and x.shape[-1] % 4 == 0 and resid.data_ptr() % 16 == 0):
+        return None
+    return _run(_DWConvResidualFn, x, weight, bias, resid, pending, identity_if_zero)
+
+
 def dwconv3x3_residual_nhwc(x, weight, bias, resid, r, identity_if_zero=None):
     """resid + r * dwconv3x3(x) as fp32 in one kernel (dsw_dwconv3x3_residual_fwd): DS-MSA's closing convolution with
     the ReZero residual of the block around it (DSwinT_arch.py:317 with :356).  Without autograd only; returns None
@@ -945,6 +1034,20 @@ def _mfma_linear(a2, K, w_op, bias, N, out, ncols, a_copy, accumulate=False, liv
          stream(out.device))
 
 
+_ONE = {}
+
+
+def _one(device):
+    """a float32 [1] tensor holding 1.0 on `device` (the scale operand of the residual kernels); kept per device, but
+    never one that was allocated inside a stream capture (it would live in that graph's memory pool)"""
+    t = _ONE.get(device)
+    if t is None:
+        t = torch.ones(1, dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _ONE[device] = t
+    return t
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b for the projections of the attention modules.
 
@@ -964,7 +1067,10 @@ class _LinearFn(torch.autograd.Function):
       chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act_dtype, pad_out, live=None):
+    def forward(ctx, x, weight, bias, act_dtype, pad_out, live=None, resid=None, pending_out=None, pending_in=None):
+        # resid (fp32, the result's shape): the result is resid + (x W^T + b) as fp32, one kernel (the caller has
+        # checked that the kernel takes the call); its gradient share, dy itself, goes to pending_out when given.
+        # pending_in: a PendingGrad whose gradient the input-gradient kernel adds to dx as it writes it.
         N, Kd = weight.shape
         x2 = x.reshape(-1, Kd)
         T = x2.shape[0]
@@ -991,8 +1097,15 @@ class _LinearFn(torch.autograd.Function):
                 else:
                     a2 = xk = _cast_padded(x2, act_dtype)
                     K = Kp
-                y_p = torch.empty(T, Nout, dtype=act_dtype, device=x2.device)
-                _mfma_linear(a2, K, w_p, b32, N, y_p, Nout, a_copy, live=live)
+                if resid is not None:
+                    assert a_copy is None and live is None
+                    y_p = torch.empty(T, N, dtype=torch.float32, device=x2.device)
+                    call("dsw_linear_residual", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K,
+                         ptr(w_p), w_p.shape[0], w_p.shape[1], None if b32 is None else ptr(b32), N, ptr(resid), N, ptr(_one(x2.device)),
+                         ptr(y_p), N, N, stream(x2.device))
+                else:
+                    y_p = torch.empty(T, Nout, dtype=act_dtype, device=x2.device)
+                    _mfma_linear(a2, K, w_p, b32, N, y_p, Nout, a_copy, live=live)
                 if xk is None:
                     xk = x2  # no weight gradient wanted: only the shape is read
                 w_saved = w_pt
@@ -1007,10 +1120,12 @@ class _LinearFn(torch.autograd.Function):
                 else:
                     y_p = xk @ w_p[:Nout, :Kx].t()
                 w_saved = w_p
-            _mark_padded(y_p)  # padding columns = zero weight rows x finite inputs + zero bias
+            if resid is None:
+                _mark_padded(y_p)  # padding columns = zero weight rows x finite inputs + zero bias
         ctx.save_for_backward(xk, w_saved)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, N, Kd, mfma)
         ctx.live = live if mfma else None
+        ctx.pending = (pending_out, pending_in)
         return y_p[:, :N].view(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -1050,7 +1165,18 @@ class _LinearFn(torch.autograd.Function):
                     dx = dx_p[:, :Kd].view(xshape) if Kp != Kd else dx_p.view(xshape)
                 else:
                     dx = torch.empty(T, Kd, dtype=xdt, device=dy2.device)
-                    _mfma_linear(a2, K, w_s, None, 0, dx, Kd, a_copy, live=ctx.live)
+                    extra = ctx.pending[1].take() if ctx.pending[1] is not None else None
+                    if (extra is not None and a_copy is None and ctx.live is None and xdt == torch.float32 and extra.dtype == xdt
+                            and extra.is_contiguous() and extra.numel() == dx.numel() and extra.data_ptr() % 16 == 0):
+                        # dx = extra + dy W: the gradient that reaches x by the residual around the module, read
+                        # in the epilogue instead of being added by a pass of its own
+                        call("dsw_linear_residual", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K,
+                             ptr(w_s), w_s.shape[0], w_s.shape[1], None, 0, ptr(extra), Kd, ptr(_one(dy2.device)), ptr(dx), Kd, Kd,
+                             stream(dy2.device))
+                    else:
+                        _mfma_linear(a2, K, w_s, None, 0, dx, Kd, a_copy, live=ctx.live)
+                        if extra is not None:
+                            dx.add_(extra.reshape(dx.shape))
                     dx = dx.view(xshape)
             if dyk is None and (need_dw or (need_dx and dx is None)):
                 dyk = _cast_padded(dy2, act) if dy2.dtype != act else dy2.contiguous()
@@ -1085,18 +1211,48 @@ class _LinearFn(torch.autograd.Function):
                     dw = (dyk.t() @ xk).float()[:N, :Kd].to(wdt)
             if want_db and db is None:
                 db = colsum(dyk)[:N].to(bdt)
-        return dx, dw, db, None, None, None
+            # a residual's gradient that no kernel above read (a path without the epilogue, or no dx wanted here)
+            extra = ctx.pending[1].take() if ctx.pending[1] is not None else None
+            if extra is not None and dx is not None:
+                dx = dx + extra.reshape(dx.shape).to(dx.dtype)
+        d_resid = None
+        if ctx.needs_input_grad[6]:
+            if ctx.pending[0] is not None:
+                ctx.pending[0].put(dy)
+            else:
+                d_resid = dy
+        return dx, dw, db, None, None, None, d_resid, None, None
 
 
-def linear(x, lin, pad_out=False, live=None):
+def linear_plus_residual(a, lin, resid, pending=None):
+    """resid + lin(a) as fp32 in one kernel, with autograd (dsw_linear_residual with a scale of one: the projection that
+    closes a branch with the plain residual around it, DSwinT_arch.py:337 with :355).  bf16 autocast, `a` in padded
+    bf16 rows (what the attention kernels write), resid a contiguous fp32 tensor of the result's shape.  The backward
+    reads the fp32 gradient as it arrives; the residual's share of it goes to `pending` (PendingGrad) when given, back
+    to autograd otherwise.  None when the call is not one the kernel takes."""
+    weight = lin.weight
+    N, Kd = weight.shape
+    if not (autocast_dtype(None) == torch.bfloat16 and a.is_cuda and resid.is_cuda and resid.dtype == torch.float32
+            and resid.is_contiguous() and resid.shape[-1] == N and N % 4 == 0 and a.shape[:-1] == resid.shape[:-1]
+            and a.numel() > 0 and weight.is_contiguous() and weight.dtype in (torch.float32, torch.bfloat16)
+            and weight.data_ptr() % 16 == 0 and resid.data_ptr() % 16 == 0):
+        return None
+    if _padded_rows(a.reshape(-1, Kd), torch.bfloat16) is None:
+        return None
+    return _run(_LinearFn, a, weight, lin.bias, torch.bfloat16, False, None, resid, pending, None)
+
+
+def linear(x, lin, pad_out=False, live=None, grad_extra=None):
     """`lin(x)` for an nn.Linear `lin`, honouring CUDA autocast like F.linear does.  pad_out: leave
     the result in rows padded to a multiple of 64 elements (returned as a view of the first
     out_features columns); for callers whose consumers accept such views.
     live = (counter, unit_rows): an int32 counter on the device; the rows at and beyond counter * unit_rows are
     switched off (DS-MSA: the window slots behind the ones that passed the gate) - under bf16 autocast the kernels do
-    no work for them, forward or backward, and leave zeros in their place; other paths compute them like any row."""
+    no work for them, forward or backward, and leave zeros in their place; other paths compute them like any row.
+    grad_extra: a PendingGrad; what it holds when the backward pass gets here is added to x's gradient by the kernel
+    that writes it."""
     act = autocast_dtype(x.dtype)
-    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out), live)
+    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out), live, None, None, grad_extra)
 
 
 def linear_residual(a, lin, resid, r):
