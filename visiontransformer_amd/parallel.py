@@ -284,19 +284,31 @@ class GraphedForward:
         return static_y
 
 
+class _BlockwiseSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, block):
+        ctx.shape = t.shape
+        t = t.detach().reshape(-1)
+        while t.numel() > 4 * block:
+            n = t.numel()
+            m = n // block * block
+            head = t.view(-1, block).sum(1) if m == n else t[:m].view(-1, block).sum(1)
+            t = head if m == n else torch.cat([head, t[m:]])
+        return t.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.expand(ctx.shape), None     # as torch.sum's backward: a broadcast view, no pass over memory
+
+
 def graph_safe_sum(t, block=1024):
     """Sum of all elements of t by reductions that each fit one workgroup (rows of `block` elements, then the row
-    sums the same way), differentiable.  For losses inside GraphedTrainStep: torch's reduction of a large tensor to
-    one value runs over several workgroups behind a memset of its arrival counters, and in a replayed graph on
-    ROCm 7.2 that memset node was seen to lose its place among the kernel nodes when the host had synchronised
-    before the replay - the value came out wrong (a partial sum) while every gradient stayed right."""
-    t = t.reshape(-1)
-    while t.numel() > 4 * block:
-        n = t.numel()
-        m = n // block * block
-        head = t[:m].view(-1, block).sum(1)
-        t = head if m == n else torch.cat([head, t[m:]])
-    return t.sum()
+    sums the same way), differentiable (the gradient is the broadcast of the incoming one, as for torch.sum).  For
+    losses inside GraphedTrainStep: torch's reduction of a large tensor to one value runs over several workgroups
+    behind a memset of its arrival counters, and in a replayed graph on ROCm 7.2 that memset node was seen to lose its
+    place among the kernel nodes when the host had synchronised before the replay - the value came out wrong (a
+    partial sum) while every gradient stayed right."""
+    return _BlockwiseSumFn.apply(t, block)
 
 
 def graph_safe_mean(t, block=1024):
