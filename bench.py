@@ -72,17 +72,23 @@ def build_pair(device, seed=0):
     return m.to(device).train()
 
 
-def time_calls(fn, iters, warm=3):
+def time_calls(fn, iters, warm=3, rounds=1):
+    """seconds per call: events on the launch stream around `iters` calls; with rounds > 1 the median of that many
+    such measurements (the first one after a change of kernel runs several per cent slower than the ones behind it)"""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per call
+    res = []
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) * 1e-3 / iters)
+    res.sort()
+    return res[len(res) // 2]
 
 
 def kernel_rooflines(device, iters=20, warm=3, k=4, attention=True):
@@ -122,8 +128,9 @@ def _attention_rooflines(device, iters, warm, out):
     do = gbuf[:, :C].view(B_PER_GPU, HW, HW, C)
     with torch.no_grad():
         t_f = time_calls(lambda: K.window_attention(qkv, table, WIN, HEADS, QKV_INTERLEAVED, grid=(B_PER_GPU, HW, HW), pad_out=True),
-                         iters, warm)
-    t_b = time_calls(lambda: torch.autograd.grad(o, (qkv, tab), do, retain_graph=True), iters, warm)
+                         iters, max(warm, 10), rounds=5 if iters > 2 else 1)
+    t_b = time_calls(lambda: torch.autograd.grad(o, (qkv, tab), do, retain_graph=True), iters, max(warm, 10) if iters > 2 else warm,
+                     rounds=5 if iters > 2 else 1)
     flops_f, flops_b = 4.0 * T * L * C, 8.0 * T * L * C
     # algorithmic HBM bytes (bf16): forward reads qkv, writes out (+ lse); backward reads qkv, out, dout
     # (+ lse), writes dqkv.  At head dim 30 both passes need more time on the HBM roofline than on the

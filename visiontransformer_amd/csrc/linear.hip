@@ -111,6 +111,18 @@ __device__ __forceinline__ void chunk_mfma(const bf16_t *brow, const bf16x8 (&af
 
 // NACC: 0 = one k slab (a chunk is stored as soon as it is complete); > 0 = several slabs, the accumulators of NACC
 // chunks persist across them
+// LINEAR_STAMPS (diagnostic builds only, tools/linear_stamps.py): thread 0 of every workgroup records the shader clock
+// at points of the projection kernel into a device array that dsw_debug_read_linear_stamps copies out
+#ifdef LINEAR_STAMPS
+__device__ unsigned long long g_linear_stamps[8 * 8192];
+#define LN_STAMP(i)                                                                                            \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) g_linear_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define LN_STAMP(i) ((void)0)
+#endif
+
 template <typename TA, typename TC, int KS, int NACC>
 __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
@@ -126,6 +138,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     float *biasl = reinterpret_cast<float *>(Bs + LN_CN * LS);  // bias of this block's columns, zero where there is none
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    LN_STAMP(0);
     // fp32 results only: C = resid + rs * (A W^T + bias); resid == C is plain accumulation
     const float rs = rscale != nullptr ? *rscale : 1.f;
     const int m0 = blockIdx.x * LN_BM;
@@ -336,6 +349,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
 #pragma unroll
                 for (int j = 0; j < KS / 64; ++j) ap[p * (KS / 64) + j].load(rs_a, a_off[p] + j * 64 * (unsigned)sizeof(TA), soff, half16);
             if (slab == 0) load_b(0, 0);
+            if (slab == 0) LN_STAMP(1);
             lds_barrier();  // the previous slab's reads of As / Bs are over
 #pragma unroll
             for (int p = 0; p < 4; ++p)
@@ -350,7 +364,9 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 }
             write_b();
         }
+        if (slab == 0) LN_STAMP(2);
         lds_barrier();
+        if (slab == 0) LN_STAMP(3);
         // this wave's 32 rows of the slab as MFMA operands
         bf16x8 afr[NKS];
         {
@@ -359,6 +375,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
             for (int ks = 0; ks < NKS; ++ks) afr[ks] = as_bf16x8(*reinterpret_cast<const uint4 *>(arow + ks * 16));
         }
         for (int chunk = 0; chunk < nch; ++chunk) {
+            if (slab == 0 && chunk == 1) LN_STAMP(4);
             if (chunk > 0) {
                 lds_barrier();
                 write_b();
@@ -382,11 +399,13 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
             }
         }
     }
+    LN_STAMP(5);
     if constexpr (PERSIST) {
 #pragma unroll
         for (int cc = 0; cc < NACC; ++cc)
             if (cc < nch) store_tiles(acc[cc], cc);
     }
+    LN_STAMP(6);
 }
 
 // w [N, K] (fp32 or bf16) -> zero-padded bf16 copies: wp [Np, Kp] and its transpose wpt [Kp, Np]
@@ -866,3 +885,9 @@ extern "C" int dsw_conv3x3_wgrad(const void *dy, long long ldy, const void *x, l
     if (B <= 0 || H <= 0 || W <= 0) return fail(DSW_EINVAL, "dsw_conv3x3_wgrad: bad sizes B=%d H=%d W=%d", B, H, W);
     return wgrad_launch("dsw_conv3x3_wgrad", dy, ldy, x, ldx, (long long)B * H * W, Co, Ci, H, W, dw, db, workspace, stream);
 }
+
+#ifdef LINEAR_STAMPS
+extern "C" int dsw_debug_read_linear_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dsw::g_linear_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
