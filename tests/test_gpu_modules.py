@@ -592,8 +592,10 @@ def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window
         return real_call(name, *args)
 
     outs = {}
+    grid_d30 = K.FUSE_PROJECTION_GRID_D30
     for fuse in (True, False):
         K.FUSE_PROJECTION = K.FUSE_GATED_SILU = fuse
+        K.FUSE_PROJECTION_GRID_D30 = True   # off by default: at 16x16 windows of head dim 30 the separate kernels are faster
         calls.clear()
         K.call = spy
         try:
@@ -602,6 +604,7 @@ def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window
         finally:
             K.call = real_call
             K.FUSE_PROJECTION = K.FUSE_GATED_SILU = True
+            K.FUSE_PROJECTION_GRID_D30 = grid_d30
         n_fused = calls.count("dsw_win_attn_proj_fwd")
         assert (n_fused > 0 and "dsw_win_attn_fwd" not in calls) if fuse else (n_fused == 0 and "dsw_win_attn_fwd" in calls)
         n_gate = calls.count("dsw_linear_gated_silu")               # fc1 of the MLP with the gate in its epilogue

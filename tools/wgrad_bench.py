@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""dsw_linear_wgrad at the bench shapes (131 072 tokens): q|k|v (N 540, K 180), out projection (N 180, K 180), MLP
+(N 360, K 180 and N 180, K 360), medians of five rounds.  DSW_WGRAD_WGS sets the workgroup count aimed at."""
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visiontransformer_amd import _lib  # noqa: E402
+from visiontransformer_amd._lib import call, ptr, stream  # noqa: E402
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+c64 = lambda n: (n + 63) // 64 * 64
+M = 131072
+for N, K in ((540, 180), (180, 180), (360, 180), (180, 360)):
+    dy = torch.zeros(M, c64(N), device=dev, dtype=torch.bfloat16)
+    dy[:, :N] = torch.randn(M, N, device=dev).bfloat16()
+    x = torch.zeros(M, c64(K), device=dev, dtype=torch.bfloat16)
+    x[:, :K] = torch.randn(M, K, device=dev).bfloat16()
+    dw = torch.empty(N, K, device=dev)
+    db = torch.empty(N, device=dev) if K % 64 else None
+    ws = torch.empty(int(lib.dsw_linear_wgrad_workspace(M, N, K)), device=dev)
+
+    def run():
+        call("dsw_linear_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), M, N, K, ptr(dw), None if db is None else ptr(db), ptr(ws), None, 0, stream(dev))
+    for _ in range(5):
+        run()
+    res = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) * 1e3 / 20)
+    ref = dy[:, :N].float().t() @ x[:, :K].float()
+    err = float((dw - ref).norm() / ref.norm())
+    by = M * (c64(N) + c64(K)) * 2
+    t = statistics.median(res)
+    print("N=%3d K=%3d  %6.1f us  %5.2f TB/s of operands  workspace %5.1f MB  err %.1e" % (N, K, t, by / t / 1e6, ws.numel() * 4 / 1e6, err), flush=True)

@@ -813,7 +813,11 @@ extern "C" int dsw_conv3x3_nhwc_residual(const void *x, int x_dtype, long long l
 static void wgrad_split(long long M, int Np, int Kp, int ntap, int *rows_per_block, int *S) {
     const int TN = wgrad_wide(Kp) ? WgWide::TN : WgNarrow::TN, TK = wgrad_wide(Kp) ? WgWide::TK : WgNarrow::TK;
     const int nb = ((Np + TN - 1) / TN) * ((Kp + TK - 1) / TK) * ntap;
-    long long want = 256 / nb;  // about one workgroup per CU: every extra one adds a partial block to write and re-read
+    static const int target = [] {   // DSW_WGRAD_WGS in the environment: the workgroup count aimed at (experiments)
+        const char *e = getenv("DSW_WGRAD_WGS");
+        return e != nullptr && atoi(e) > 0 ? atoi(e) : 256;
+    }();
+    long long want = target / nb;  // about one workgroup per CU: every extra one adds a partial block to write and re-read
     if (want < 8 && ntap > 1) want = 8;  // 9 taps: keep some row ranges so that a block's stream stays short
     if (want < 1) want = 1;
     long long rpb = (M + want - 1) / want;

@@ -119,7 +119,8 @@ class WindowedMSA(WindowedAttention):
         pend = K.PendingGrad() if (plain and torch.is_grad_enabled() and residual[0] is x and x.requires_grad
                                    and x.dtype == torch.float32 and x.is_contiguous()) else None
         z = None
-        if drop_p == 0.0:   # without autograd: projection and attention in one kernel, q|k|v never written
+        # without autograd: projection and attention in one kernel, q|k|v never written - where that is the faster form
+        if drop_p == 0.0 and (K.FUSE_PROJECTION_GRID_D30 or not (self.win == 16 and C // self.num_heads == 30)):
             z = K.projected_window_attention(x, self.qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED,
                                              grid=(B, H, W), pad_out=True)
         if z is None:

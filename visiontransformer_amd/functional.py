@@ -6,6 +6,7 @@ exactly what the backward kernels read.  Nothing here computes on the CPU.
 """
 import contextlib
 import ctypes
+import os
 import weakref
 from dataclasses import dataclass
 
@@ -545,6 +546,14 @@ def window_attention(qkv, table, w, heads, layout, grid=None, scale=None, lepe_w
 
 
 FUSE_PROJECTION = True   # False: projected_window_attention always declines (the two separate kernels run)
+
+
+# Image-grid calls at 16x16 windows and head dim 30 (DSWT's WindowedMSA) have a forward kernel of their own
+# (win_attn_fwd_w16_kernel) that, with the projection kernel in front of it, is faster than the fusion built on the
+# general attention core (106 against 120 us at 131 072 tokens), so WindowedMSA does not ask for the fusion there;
+# the packed-window calls of DS-MSA, where a quarter of the tokens are attended, stay fused (36 against 42 us).
+# DSW_FUSE_PROJ_GRID=1 in the environment (or setting this flag) asks for it everywhere.
+FUSE_PROJECTION_GRID_D30 = os.environ.get("DSW_FUSE_PROJ_GRID") == "1"
 
 
 def projected_window_attention(x, lin, table, w, heads, layout, grid=None, scale=None, pad_out=False, n_live=None):
