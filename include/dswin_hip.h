@@ -535,12 +535,15 @@ int dsw_conv3x3_wgrad(const void *dy, long long ldy, const void *x, long long ld
  * msft_arch.py:152-153, applied at :163-165): out = (x - mean) * rstd * weight + bias, written as fp32 or
  * bf16 with row stride ldo >= C (columns C..ldo-1 zeroed), like dsw_rmsnorm_fwd.  C % 4 == 0, C <= 256;
  * mean, rstd: fp32 [M], both or neither.  Backward: dx fp32 [M][C]; partial holds dsw_rmsnorm_blocks(M)
- * rows of [d(weight) | d(bias)] (2 C floats each) to be summed over rows. */
+ * rows of [d(weight) | d(bias)] (2 C floats each) to be summed over rows.  dx_add (fp32 [M][C], or NULL) and
+ * dx_add2 (fp32, row stride ld_add2, covering the first cols2 columns; or NULL) are gradients that reached x
+ * by other ways - the residual around the block (msft_arch.py:163-165), the concatenation in front of the
+ * fusing block (msft_arch.py:210) - and are added as dx is written, in place of passes of their own. */
 int dsw_layernorm_fwd(const float *x, const float *weight, const float *bias, float eps, long long M, int C,
                       void *out, int out_dtype, long long ldo, float *mean, float *rstd, void *stream);
 int dsw_layernorm_bwd(const void *dy, int dy_dtype, long long ld_dy, const float *x, const float *weight,
-                      const float *mean, const float *rstd, long long M, int C, float *dx, float *partial,
-                      void *stream);
+                      const float *mean, const float *rstd, long long M, int C, float *dx, const float *dx_add,
+                      const float *dx_add2, long long ld_add2, int cols2, float *partial, void *stream);
 
 #ifdef __cplusplus
 }

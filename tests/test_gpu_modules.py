@@ -333,6 +333,45 @@ def test_msft_vitblock_bf16_autocast_at_config_c_widths_against_the_oracle(cuda0
         assert rel_err(p.grad, P[n].grad) < tol, n
 
 
+@pytest.mark.parametrize("autocast", [False, True])
+def test_msft_block_with_the_gradient_sums_inside_the_kernels(cuda0, autocast):
+    """MSFBlock_3 on the channels-last stream (msft_arch.py:169-210) at the headline configuration's widths: the sums
+    of the gradients of every residual's input and of the block's input (residual + concatenation + first
+    projection, msft_arch.py:163-165, :199, :210) taken inside the norm / projection backward kernels against the
+    same block with autograd adding the maps: the same output bits, gradients equal up to the order of fp32 sums."""
+    from visiontransformer_amd import functional as K, models
+    torch.manual_seed(11)
+    blk = models.MSFBlock_3(levels=2, window_size=8, dim=192, level_dim=96, n_heads=6, n_heads_fuse=4, ffn_scale=2, drop_path=0.0)
+    with torch.no_grad():
+        blk.rezero.fill_(0.7)
+    blk = blk.to(cuda0).eval()
+    for sub in blk.modules():
+        if hasattr(sub, "attn_drop"):
+            sub.attn_drop = 0.0
+    x = torch.randn(2, 32, 32, 192, device=cuda0)
+    r = torch.randn(2, 32, 32, 192, device=cuda0)
+    res = []
+    for meet in (True, False):
+        K.GRAD_MEETING = meet
+        try:
+            blk.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_()
+            xin = xg * 1.0     # not a leaf: the block's input gradient arrives through autograd like inside the network
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                y = blk.forward_nhwc(xin)
+            (y.float() * r).sum().backward()
+        finally:
+            K.GRAD_MEETING = True
+        res.append((y.detach().float(), xg.grad.clone(), {n: p.grad.float().clone() for n, p in blk.named_parameters()}))
+    (y1, gx1, gp1), (y0, gx0, gp0) = res
+    assert torch.equal(y1, y0)
+    tol = 2e-3 if autocast else 2e-5    # bf16: a sum that meets in another order rounds differently on its way into the next bf16 operand
+    assert rel_err(gx1, gx0) < tol
+    assert set(gp1) == set(gp0)
+    for n in gp0:
+        assert rel_err(gp1[n], gp0[n]) < tol, n
+
+
 def test_msft_wmsa_bf16(cuda0):
     """bf16 run of the msft attention against its own fp32 run (2e-2)."""
     from visiontransformer_amd.msft import WindowedMSA

@@ -82,7 +82,7 @@ SIGNATURES = {
     "dsw_conv3x3_wgrad_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "dsw_conv3x3_wgrad": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dsw_layernorm_fwd": (_I, [_P, _P, _P, _F, ctypes.c_longlong, _I, _P, _I, ctypes.c_longlong, _P, _P, _P]),
-    "dsw_layernorm_bwd": (_I, [_P, _I, ctypes.c_longlong, _P, _P, _P, _P, ctypes.c_longlong, _I, _P, _P, _P]),
+    "dsw_layernorm_bwd": (_I, [_P, _I, ctypes.c_longlong, _P, _P, _P, _P, ctypes.c_longlong, _I, _P, _P, _P, ctypes.c_longlong, _I, _P, _P]),
     "dsw_ema_update": (_I, [_I, _P, _P, _P, _I, _F, _F, _P]),
     "dsw_win_attn_proj_fwd": (_I, [_P, ctypes.c_longlong, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
     "dsw_adam_update": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P]),

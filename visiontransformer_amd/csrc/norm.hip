@@ -599,7 +599,8 @@ template <typename TG>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG *__restrict__ dy, long long ldg, const float *__restrict__ x,
                                                             const float *__restrict__ w, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, long long M, int C, float *__restrict__ dx,
-                                                            float *__restrict__ partial) {
+                                                            const float *__restrict__ dx_add, const float *__restrict__ dx_add2,
+                                                            long long ld_add2, int cols2, float *__restrict__ partial) {
     __shared__ float4 red[RN_RPB][RN_LPR * RN_MAXV];
     const int sub = threadIdx.x & (RN_LPR - 1), rloc = threadIdx.x / RN_LPR;
     const int nv = C / 4;
@@ -632,10 +633,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG *__restrict
         if (ok) {
 #pragma unroll
             for (int i = 0; i < RN_MAXV; ++i)
-                if (sub + RN_LPR * i < nv)
-                    *reinterpret_cast<float4 *>(dx + row * C + 4 * (sub + RN_LPR * i)) =
-                        make_float4((g[i].x - s1 - xh[i].x * s2) * rs, (g[i].y - s1 - xh[i].y * s2) * rs, (g[i].z - s1 - xh[i].z * s2) * rs,
-                                    (g[i].w - s1 - xh[i].w * s2) * rs);
+                if (sub + RN_LPR * i < nv) {
+                    const int c = 4 * (sub + RN_LPR * i);
+                    float4 v = make_float4((g[i].x - s1 - xh[i].x * s2) * rs, (g[i].y - s1 - xh[i].y * s2) * rs, (g[i].z - s1 - xh[i].z * s2) * rs,
+                                           (g[i].w - s1 - xh[i].w * s2) * rs);
+                    // gradients that reached x by other ways: a map of x's shape, and one that covers the first cols2 columns
+                    if (dx_add != nullptr) v = v + *reinterpret_cast<const float4 *>(dx_add + row * C + c);
+                    if (dx_add2 != nullptr && c < cols2) v = v + *reinterpret_cast<const float4 *>(dx_add2 + row * ld_add2 + c);
+                    *reinterpret_cast<float4 *>(dx + row * C + c) = v;
+                }
         }
     }
 #pragma unroll
@@ -674,15 +680,19 @@ extern "C" int dsw_layernorm_fwd(const float *x, const float *weight, const floa
 }
 
 extern "C" int dsw_layernorm_bwd(const void *dy, int dy_dtype, long long ld_dy, const float *x, const float *weight, const float *mean,
-                                 const float *rstd, long long M, int C, float *dx, float *partial, void *stream) {
+                                 const float *rstd, long long M, int C, float *dx, const float *dx_add, const float *dx_add2,
+                                 long long ld_add2, int cols2, float *partial, void *stream) {
     if (M <= 0 || C <= 0 || ld_dy < C) return fail(DSW_EINVAL, "dsw_layernorm_bwd: bad sizes M=%lld C=%d ld_dy=%lld", M, C, ld_dy);
     if (C % 4 || ld_dy % 4 || C > 4 * RN_LPR * RN_MAXV)
         return fail(DSW_EUNSUPPORTED, "dsw_layernorm_bwd: C and the gradient's row stride must be multiples of 4, C at most %d (C=%d ld_dy=%lld)",
                     4 * RN_LPR * RN_MAXV, C, ld_dy);
+    if (dx_add2 != nullptr && (cols2 <= 0 || cols2 > C || cols2 % 4 || ld_add2 < cols2 || ld_add2 % 4 || (reinterpret_cast<uintptr_t>(dx_add2) & 15)))
+        return fail(DSW_EINVAL, "dsw_layernorm_bwd: the partial-width addend needs 0 < cols2 <= C, cols2 and its row stride multiples of 4, "
+                                "16-byte alignment (cols2=%d ld_add2=%lld C=%d)", cols2, ld_add2, C);
     DSW_REQUIRE(dy && x && weight && mean && rstd && dx && partial, "dsw_layernorm_bwd: null pointer");
     DSW_DISPATCH_DTYPE(dy_dtype, TG, {
         hipLaunchKernelGGL(layernorm_bwd_kernel<TG>, dim3(rn_blocks(M)), dim3(256), 0, as_stream(stream), (const TG *)dy, ld_dy, x, weight,
-                           mean, rstd, M, C, dx, partial);
+                           mean, rstd, M, C, dx, dx_add, dx_add2, ld_add2, cols2, partial);
     });
     return check_launch("layernorm_bwd_kernel");
 }

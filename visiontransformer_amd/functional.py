@@ -270,6 +270,37 @@ class PendingGrad:
         return g if self.task == torch._C._current_graph_task_id() else None
 
 
+class _ParkGradFn(torch.autograd.Function):
+    """identity whose backward parks the gradient in a PendingGrad instead of returning it (stock-op paths)"""
+
+    @staticmethod
+    def forward(ctx, x, pending):
+        ctx.pending = pending
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.pending.put(g)
+        return None, None
+
+
+class _AddPendingFn(torch.autograd.Function):
+    """identity whose backward adds what a PendingGrad holds to the gradient's leading columns (stock-op paths)"""
+
+    @staticmethod
+    def forward(ctx, x, pending):
+        ctx.pending = pending
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        e = ctx.pending.take()
+        if e is not None:
+            g = g.clone()
+            g[..., :e.shape[-1]] += e.reshape(g.shape[:-1] + (e.shape[-1],))
+        return g, None
+
+
 class GradSink:
     """Meeting point for the gradients that several custom ops send to the SAME input tensor.
 
@@ -1175,13 +1206,14 @@ class _LinearFn(torch.autograd.Function):
                 else:
                     dx = torch.empty(T, Kd, dtype=xdt, device=dy2.device)
                     extra = ctx.pending[1].take() if ctx.pending[1] is not None else None
-                    if (extra is not None and a_copy is None and ctx.live is None and xdt == torch.float32 and extra.dtype == xdt
-                            and extra.is_contiguous() and extra.numel() == dx.numel() and extra.data_ptr() % 16 == 0):
-                        # dx = extra + dy W: the gradient that reaches x by the residual around the module, read
-                        # in the epilogue instead of being added by a pass of its own
+                    e2 = _row_view_f32(extra) if extra is not None and xdt == torch.float32 else None
+                    if e2 is not None and a_copy is None and ctx.live is None and e2.shape == (T, Kd):
+                        # dx = extra + dy W: the gradient that reaches x by another way (the residual around the module,
+                        # a concatenation that x is part of), read in the epilogue where it lies - a dense map or the
+                        # leading columns of a wider one - instead of being added by a pass of its own
                         call("dsw_linear_residual", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K,
-                             ptr(w_s), w_s.shape[0], w_s.shape[1], None, 0, ptr(extra), Kd, ptr(_one(dy2.device)), ptr(dx), Kd, Kd,
-                             stream(dy2.device))
+                             ptr(w_s), w_s.shape[0], w_s.shape[1], None, 0, _dptr(e2), e2.stride(0) if T > 1 else Kd, ptr(_one(dy2.device)),
+                             ptr(dx), Kd, Kd, stream(dy2.device))
                     else:
                         _mfma_linear(a2, K, w_s, None, 0, dx, Kd, a_copy, live=ctx.live)
                         if extra is not None:
@@ -1411,7 +1443,7 @@ def rms_norm(x, norm, for_projection=False, sink=None, dense_act=False):
     trip) and returned as a view of the first C columns.  dense_act: under bf16 autocast the result is a dense
     bf16 tensor (for a consumer whose kernels round their input to bf16 anyway and want NHWC rows of C)."""
     if not _norm_kernel_ok(x, norm):
-        assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
+        assert sink is None and pending is None, "a gradient sink needs the kernel path (see prenorm_sink)"
         return norm(x)
     eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
     act = autocast_dtype(x.dtype)
@@ -1499,7 +1531,8 @@ def gelu(x, pad_out=False):
 # ---------------------------------------------------------------------------------------------
 class _RezeroFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, branch, sink=None, mask=None, keep=1.0, seeded=None):
+    def forward(ctx, x, r, branch, sink=None, mask=None, keep=1.0, seeded=None, pending=None):
+        # pending (PendingGrad): x's share of the gradient, dy itself, is parked there instead of being returned
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         b2, ldb = _row_view4(branch, C)
@@ -1519,6 +1552,7 @@ class _RezeroFn(torch.autograd.Function):
             ctx.save_for_backward(b2, r32, mask)
         ctx.meta = (x.shape, branch.shape, ldb, r.shape, r.dtype, sink, float(keep))
         ctx.seeded = seeded
+        ctx.pending = pending
         return y.view(x.shape)
 
     @staticmethod
@@ -1545,41 +1579,49 @@ class _RezeroFn(torch.autograd.Function):
                 call("dsw_rezero_dropout_bwd", ptr(dy2), _dptr(b2), dtype_code(b2.dtype), ldb, ptr(r32), ptr(mask), keep, M, C,
                      ptr(dbuf), ld_db, ptr(partial), stream(b2.device))
             db = (dbuf[:, :C] if ld_db != C else dbuf).view(bshape)
-            dr = partial.sum().reshape(rshape).to(rdt)
+            dr = partial.sum().reshape(rshape).to(rdt) if ctx.needs_input_grad[1] else None
+        if ctx.pending is not None and ctx.needs_input_grad[0]:
+            assert sink is None
+            ctx.pending.put(dy2.view(xshape))
+            return None, dr, db, None, None, None, None, None
         if sink is None or not ctx.needs_input_grad[0]:
-            return dy, dr, db, None, None, None, None
+            return dy, dr, db, None, None, None, None, None
         # the residual's share of x's gradient is dy itself: the norm's backward reads it and writes the sum
         sink._same_pass()
         if sink.buf is not None:  # the norm's gradient came first: its buffer is ours to add into
             sink.buf.view(M, C).add_(dy2)
-            return sink.deliver(sink.buf), dr, db, None, None, None, None
-        return sink.deliver(dy2.view(xshape)), dr, db, None, None, None, None
+            return sink.deliver(sink.buf), dr, db, None, None, None, None, None
+        return sink.deliver(dy2.view(xshape)), dr, db, None, None, None, None, None
 
 
-def rezero_residual(x, r, branch, sink=None, dropout=None, dropout_seed=None, dropout_mask=None):
+def rezero_residual(x, r, branch, sink=None, dropout=None, dropout_seed=None, dropout_mask=None, pending=None):
     """x + r * dropout(branch) for the fp32 stream x [..., C], a one-element parameter r and a branch of the
     same shape in fp32 / bf16 (dense or a view of padded rows).  dropout: the nn.Dropout the reference puts on
     the branch (DSwinT_arch.py:352, :355-357) or None; in training it is applied inside the residual kernel
     (forward and backward), in place of a dropout pass, its mask pass and their backward over the branch.  The
     keep decisions are a hash of a 64-bit seed - dropout_seed, or drawn from torch's CPU generator (reproducible
     under torch.manual_seed, replayed by activation checkpointing) - and the element's position: no mask tensor is
-    drawn, stored or read.  dropout_mask: an explicit uint8 mask [..., C] (0 = dropped) to use instead."""
+    drawn, stored or read.  dropout_mask: an explicit uint8 mask [..., C] (0 = dropped) to use instead.
+    pending: a PendingGrad that receives x's share of the gradient (dy itself) instead of autograd - the caller has
+    made sure that a later backward kernel of the same pass takes it (kernel path only; not together with a sink)."""
     C = x.shape[-1]
     ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and r.numel() == 1
           and branch.shape == x.shape and branch.dtype in (torch.float32, torch.bfloat16))
     if not ok:
         assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
+        if pending is not None and torch.is_grad_enabled() and x.requires_grad:
+            x = _ParkGradFn.apply(x, pending)
         return torch.addcmul(x, r, branch if dropout is None else dropout(branch))
     if dropout is None or not dropout.training or dropout.p == 0:
-        return _run(_RezeroFn, x, r, branch, sink)
+        return _run(_RezeroFn, x, r, branch, sink, None, 1.0, None, pending)
     p = float(dropout.p)
     if dropout_mask is None and p < 1.0:
         seed = draw_dropout_seed() if dropout_seed is None else int(dropout_seed)
-        return _run(_RezeroFn, x, r, branch, sink, None, 1.0, (p, seed))
+        return _run(_RezeroFn, x, r, branch, sink, None, 1.0, (p, seed), pending)
     if dropout_mask is None:        # p = 1: everything dropped
         dropout_mask = torch.zeros(x.numel() // C, C, dtype=torch.uint8, device=x.device)
     mask = dropout_mask.reshape(-1, C).contiguous()
-    return _run(_RezeroFn, x, r, branch, sink, mask, 1.0 / (1.0 - p) if p < 1.0 else 0.0)
+    return _run(_RezeroFn, x, r, branch, sink, mask, 1.0 / (1.0 - p) if p < 1.0 else 0.0, None, pending)
 
 
 def prenorm_sink(x, norm, r):
@@ -1590,6 +1632,45 @@ def prenorm_sink(x, norm, r):
     if not (torch.is_grad_enabled() and x.requires_grad and _norm_kernel_ok(x, norm) and r.numel() == 1):
         return None
     return GradSink(2)
+
+
+GRAD_MEETING = True   # False: the msft blocks leave the sums of their inputs' gradients to autograd (tests, comparisons)
+
+
+def layer_norm_sink(x, norm):
+    """prenorm_sink for y = x + dropout(f(layer_norm(x))) (msft_arch.py:163-165, the residual taken by rezero_residual
+    with a scale of one): None when no gradient is needed or the norm would not run in its kernel"""
+    if not (GRAD_MEETING and torch.is_grad_enabled() and x.requires_grad and _layer_norm_kernel_ok(x, norm)):
+        return None
+    return GradSink(2)
+
+
+class _ConcatPendingFn(torch.autograd.Function):
+    """cat([x, other], -1) whose backward parks x's share of the gradient - a view of the leading columns of the
+    incoming map - in a PendingGrad instead of returning it: the kernel that writes another gradient of x later in
+    the same pass (the input gradient of a projection of x that feeds `other`) reads it as an operand."""
+
+    @staticmethod
+    def forward(ctx, x, other, pending):
+        ctx.cx = x.shape[-1]
+        ctx.pending = pending
+        return torch.cat([x, other], dim=-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = g[..., :ctx.cx]
+        if ctx.needs_input_grad[0]:
+            ctx.pending.put(gx)
+        return None, (g[..., ctx.cx:] if ctx.needs_input_grad[1] else None), None
+
+
+def concat_pending(x, other, pending):
+    """torch.cat([x, other], dim=-1); with a PendingGrad, x's gradient through the concatenation is handed to it (the
+    caller has made sure that a projection of x with grad_extra=pending runs later in every backward pass: `other`
+    must depend on that projection's result)."""
+    if pending is None or not (torch.is_grad_enabled() and x.requires_grad and other.requires_grad):
+        return torch.cat([x, other], dim=-1)
+    return _ConcatPendingFn.apply(x, other, pending)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1828,7 +1909,7 @@ def conv3x3_nhwc_variant(x, conv, variant="plain"):
 # ---------------------------------------------------------------------------------------------
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, out_dtype, pad_out):
+    def forward(ctx, x, weight, bias, eps, out_dtype, pad_out, sink=None, pending=None):
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         M = x2.shape[0]
@@ -1842,36 +1923,80 @@ class _LayerNormFn(torch.autograd.Function):
              ldo, None if stats is None else ptr(stats[0]), None if stats is None else ptr(stats[1]), stream(x.device))
         if need_bwd:
             ctx.save_for_backward(x2, w32, stats)
-        ctx.meta = (x.shape, weight.dtype, None if bias is None else bias.dtype)
+        ctx.meta = (x.shape, weight.dtype, None if bias is None else bias.dtype, sink, pending)
         return out[:, :C].view(x.shape) if ldo != C else out.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w32, stats = ctx.saved_tensors
-        xshape, wdt, bdt = ctx.meta
+        xshape, wdt, bdt, sink, pending = ctx.meta
         M, C = x2.shape
         dy2 = dy.reshape(-1, C)
         if dy2.dtype not in (torch.float32, torch.bfloat16) or dy2.stride(1) != 1 or (M > 1 and dy2.stride(0) % 4) or \
                 dy2.data_ptr() % (4 * dy2.element_size()):
             dy2 = dy2.float().contiguous()
+        if not ctx.needs_input_grad[0]:
+            sink = pending = None
+        # the gradients that reached x around the norm, if they are already there: the residual's dy (a map of x's
+        # shape, through the sink) and one that covers x's first columns (pending); the kernel adds them as it writes dx
+        if sink is not None:
+            sink._same_pass()
+        prev = sink.buf if sink is not None else None
+        if prev is not None:
+            prev = prev.reshape(M, C)
+            if prev.dtype != torch.float32 or not prev.is_contiguous():
+                prev = prev.float().contiguous()
+        part = pending.take() if pending is not None else None
+        part2 = None
+        if part is not None:
+            part2 = _row_view_f32(part)
+            if part2 is None or part2.shape[0] != M or part2.shape[1] > C:
+                part2 = None
         dx = torch.empty(M, C, dtype=torch.float32, device=x2.device)
         nblk = _lib.load().dsw_rmsnorm_blocks(M)
         partial = torch.empty(nblk, 2 * C, dtype=torch.float32, device=x2.device)
         call("dsw_layernorm_bwd", ctypes.c_void_p(dy2.data_ptr()), dtype_code(dy2.dtype), dy2.stride(0) if M > 1 else C, ptr(x2), ptr(w32),
-             ptr(stats[0]), ptr(stats[1]), M, C, ptr(dx), ptr(partial), stream(x2.device))
+             ptr(stats[0]), ptr(stats[1]), M, C, ptr(dx), None if prev is None else ptr(prev), None if part2 is None else _dptr(part2),
+             0 if part2 is None else (part2.stride(0) if M > 1 else part2.shape[1]), 0 if part2 is None else part2.shape[1], ptr(partial),
+             stream(x2.device))
+        if part is not None and part2 is None:    # a form the kernel does not read: one pass of torch's
+            dx[:, :part.shape[-1]] += part.reshape(M, -1)
         dwb = colsum(partial)
         dw = dwb[:C].to(wdt) if ctx.needs_input_grad[1] else None
         db = dwb[C:].to(bdt) if bdt is not None and ctx.needs_input_grad[2] else None
-        return dx.view(xshape), dw, db, None, None, None
+        return _dx_deliver(sink, dx.view(xshape)), dw, db, None, None, None, None, None
 
 
-def layer_norm(x, norm, for_projection=False):
-    """`norm(x)` for an nn.LayerNorm over the last dimension of the fp32 stream; for_projection as in rms_norm."""
+def _row_view_f32(t):
+    """t [..., n] (fp32) as a 2-D view [rows, n] with unit column stride, a row stride that is a multiple of 4 and a
+    16-byte aligned start - a dense tensor or a slice of the leading columns of one; None when t is not of that form"""
+    if t.dtype != torch.float32 or t.dim() < 1 or t.shape[-1] % 4:
+        return None
+    n = t.shape[-1]
+    try:
+        t2 = t.view(-1, n)
+    except RuntimeError:
+        return None
+    if t2.stride(1) != 1 or (t2.shape[0] > 1 and t2.stride(0) % 4) or t2.data_ptr() % 16:
+        return None
+    return t2
+
+
+def _layer_norm_kernel_ok(x, norm):
     C = x.shape[-1]
-    ok = (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and _ceil_pad(C) <= 256
-          and norm.weight is not None and tuple(norm.normalized_shape) == (C,))
-    if not ok:
+    return (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and _ceil_pad(C) <= 256
+            and norm.weight is not None and tuple(norm.normalized_shape) == (C,))
+
+
+def layer_norm(x, norm, for_projection=False, sink=None, pending=None):
+    """`norm(x)` for an nn.LayerNorm over the last dimension of the fp32 stream; for_projection as in rms_norm.
+    sink (GradSink, see layer_norm_sink; kernel path only) and pending (PendingGrad holding a gradient for x's leading
+    columns): gradients of x that the norm's backward kernel adds as it writes its own."""
+    if not _layer_norm_kernel_ok(x, norm):
+        assert sink is None, "a gradient sink needs the kernel path (see layer_norm_sink)"
+        if pending is not None and torch.is_grad_enabled() and x.requires_grad:
+            x = _AddPendingFn.apply(x, pending)
         return norm(x)
     act = autocast_dtype(x.dtype)
     to_act = for_projection and act == torch.bfloat16
-    return _run(_LayerNormFn, x, norm.weight, norm.bias, norm.eps, act if to_act else torch.float32, to_act)
+    return _run(_LayerNormFn, x, norm.weight, norm.bias, norm.eps, act if to_act else torch.float32, to_act, sink, pending)

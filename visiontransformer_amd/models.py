@@ -379,7 +379,14 @@ class MSFBlock_3(nn.Module):
         is off.  No tensor changes layout inside the block."""
         B, H, W, C = x.shape
         maps = []
-        z = K.linear(x, _pointwise(self.init_ds))
+        # With autograd, x gets three gradients: the closing residual's dy, its share of the concatenation's and the
+        # first projection's.  They meet inside kernels instead of two additions over the stream: dy is read by the
+        # backward of the fusing block's first norm (which writes the concatenation's gradient), and the slice of
+        # that map by the first projection's input-gradient kernel.
+        train = K.GRAD_MEETING and torch.is_grad_enabled() and x.requires_grad
+        pend_cat = K.PendingGrad() if train else None
+        pend_res = K.PendingGrad() if train else None
+        z = K.linear(x, _pointwise(self.init_ds), grad_extra=pend_cat)
         for i in range(self.levels - 1):
             z = K.linear(z, _pointwise(self.level_ds[i]))
             merge, vit, unmerge = self.level_layer[i]
@@ -387,11 +394,11 @@ class MSFBlock_3(nn.Module):
             t = merge.forward_nhwc(z).float()
             maps.append(unmerge.forward_tokens(vit.forward_tokens(t, H // s, W // s), H // s, W // s))
         lv = _conv3x3_nhwc(maps[0] if len(maps) == 1 else torch.cat(maps, dim=-1), self.post_level_fuse)
-        t = self.fuse[0].forward_tokens(torch.cat([x, lv], dim=-1).view(B, H * W, -1), H, W)
+        t = self.fuse[0].forward_tokens(K.concat_pending(x, lv, pend_cat).view(B, H * W, -1), H, W, grad_extra=pend_res)
         close = _pointwise(self.fuse[1])
         y = K.linear_residual(t, close, x.view(B, H * W, C), self.rezero)
         if y is None:
-            y = K.rezero_residual(x.view(B, H * W, C), self.rezero, K.linear(t, close))
+            y = K.rezero_residual(x.view(B, H * W, C), self.rezero, K.linear(t, close), pending=pend_res)
         return y.view(B, H, W, C)
 
 

@@ -135,15 +135,20 @@ class ViTBlock(nn.Module):
         t = self.drop_path(self.mlp(K.layer_norm(t, self.ln2, for_projection=True))) + t
         return K.shuffle_nchw(t.view(B, H, W, C), 1)
 
-    def forward_tokens(self, t, H, W):
+    def forward_tokens(self, t, H, W, grad_extra=None):
         """The block on the fp32 token stream t [B, H*W, C] (what forward computes between its two layout copies).
         The residual additions and the block's drop_path are one kernel each (the keep decisions of the dropout are
         a seeded hash of the position: no mask tensor); under bf16 autocast the stream stays fp32, as the LayerNorm
-        outputs of the reference do."""
+        outputs of the reference do.  With autograd, the two gradients of each residual's input (the residual's dy
+        and the norm's) meet inside the norm's backward kernel, and grad_extra (a PendingGrad: a gradient for t's
+        leading columns that is there when the backward pass reaches the first norm) is added by that kernel too."""
         one = self._one(t.device)
-        n1 = K.layer_norm(t, self.ln1, for_projection=True)
-        t = K.rezero_residual(t, one, self.msa(n1, H, W), dropout=self.drop_path)
-        return K.rezero_residual(t, one, self.mlp(K.layer_norm(t, self.ln2, for_projection=True)), dropout=self.drop_path)
+        sink = K.layer_norm_sink(t, self.ln1)
+        n1 = K.layer_norm(t, self.ln1, for_projection=True, sink=sink, pending=grad_extra)
+        t = K.rezero_residual(t, one, self.msa(n1, H, W), sink=sink, dropout=self.drop_path)
+        sink = K.layer_norm_sink(t, self.ln2)
+        return K.rezero_residual(t, one, self.mlp(K.layer_norm(t, self.ln2, for_projection=True, sink=sink)), sink=sink,
+                                 dropout=self.drop_path)
 
     def _one(self, device):
         o = getattr(self, "_one_buf", None)
