@@ -324,6 +324,22 @@ int dsw_ema_update(int n, void *const *ema, const void *const *cur, const long l
 int dsw_linear_gated_silu(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                           const float *bias, void *out, long long ldo, void *stream);
 
+/* The first projection of msft's MLP with its activation (msft_arch.py:22-25 applied at :33: Linear, then
+ * nn.GELU() in its erf form): out = gelu(a W^T + bias) in one launch, bf16.  The pre-activation is rounded to bf16
+ * first - what dsw_linear would have stored - so out has the bits of dsw_linear followed by dsw_gelu_fwd.
+ *   a ... ncols, a_copy, lda_copy   as for dsw_linear (any K); ncols, ldo multiples of 8.
+ *   pre     bf16 [M][ld_pre] or NULL: receives the pre-activation (columns 0..ncols-1), which the backward needs.
+ * dsw_linear_gelu_bwd is the other half, on the way out of the second projection's input gradient
+ * (the backward of msft_arch.py:26 followed by that of :25): out = (a W^T) * gelu'(pre), bf16, where a is the
+ * gradient of the MLP's output, W the prepared transpose of the second projection's weight and pre what the
+ * forward call stored: the gradient of the pre-activation, with the bits of dsw_linear followed by dsw_gelu_bwd. */
+int dsw_linear_gelu(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                    const float *bias, int N, void *out, long long ldo, int ncols, void *pre, long long ld_pre,
+                    void *a_copy, long long lda_copy, void *stream);
+int dsw_linear_gelu_bwd(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
+                        int ldw, const void *pre, long long ld_pre, void *out, long long ldo, int ncols, void *a_copy,
+                        long long lda_copy, void *stream);
+
 /* Window attention with the q|k|v projection inside the kernel, forward only (inference): the nn.Linear of
  * DSwinT_arch.py:334 (WindowedMSA.qkv) or :303 (DeformableSparseWindowAttention.in_proj) followed by the
  * attention of :135-172 as ONE launch; the [tokens, 3C] q|k|v matrix is never written to memory.

@@ -372,6 +372,54 @@ def test_msft_block_with_the_gradient_sums_inside_the_kernels(cuda0, autocast):
         assert rel_err(gp1[n], gp0[n]) < tol, n
 
 
+@pytest.mark.parametrize("tokens,dim,scale", [(2 * 32 * 32, 216, 2), (1000, 96, 2), (515, 192, 4)])
+def test_msft_mlp_with_the_activation_inside_the_projections(cuda0, tokens, dim, scale):
+    """msft's MLP (msft_arch.py:19-33) under bf16 autocast with GELU in the epilogue of the first projection and its
+    slope in the epilogue of the second one's input gradient against the same module with the activation as kernels
+    of its own: the same bits, forward and backward (input and parameter gradients); and against the fp32 module."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd.msft import MLP
+    torch.manual_seed(dim)
+    mod = MLP(dim, ffn_scale=scale).to(cuda0)
+    x = torch.randn(tokens, dim, device=cuda0)
+    r = torch.randn(tokens, dim, device=cuda0)
+    calls = []
+    real_call = K.call
+
+    def spy(name, *args):
+        calls.append(name)
+        return real_call(name, *args)
+
+    res = []
+    for fuse in (True, False):
+        K.FUSE_GELU = fuse
+        K.call = spy
+        calls.clear()
+        try:
+            mod.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = mod(xg)
+            (y.float() * r).sum().backward()
+        finally:
+            K.FUSE_GELU = True
+            K.call = real_call
+        if fuse:
+            assert "dsw_linear_gelu" in calls and "dsw_linear_gelu_bwd" in calls and "dsw_gelu_fwd" not in calls and "dsw_gelu_bwd" not in calls
+        else:
+            assert "dsw_gelu_fwd" in calls and "dsw_gelu_bwd" in calls and "dsw_linear_gelu" not in calls
+        res.append((y.detach(), xg.grad.clone(), [p.grad.clone() for p in mod.parameters()]))
+    (y1, gx1, gp1), (y0, gx0, gp0) = res
+    assert y1.dtype == torch.bfloat16 and torch.equal(y1, y0)
+    assert torch.equal(gx1, gx0)
+    for a, b in zip(gp1, gp0):
+        assert torch.equal(a, b)
+    xr = x.clone().requires_grad_()
+    yr = mod.mlp(xr)
+    (yr * r).sum().backward()
+    assert rel_err(y1, yr) < 2e-2 and rel_err(gx1, xr.grad) < 2e-2
+
+
 def test_msft_wmsa_bf16(cuda0):
     """bf16 run of the msft attention against its own fp32 run (2e-2)."""
     from visiontransformer_amd.msft import WindowedMSA

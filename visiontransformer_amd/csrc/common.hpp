@@ -79,6 +79,39 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 // that both round alike
 __device__ __forceinline__ float gated_silu_value(float g, float c) { return g * (1.f / (1.f + __expf(-g))) * c; }
 
+// GELU in its erf form (nn.GELU() of msft's MLP, msft_arch.py:25), shared by the stand-alone kernels and the projection
+// epilogues so that both round alike.
+// fp32 tensors: the library's erff.  bf16 tensors: erf by the rational-times-Gaussian form 7.1.26 of Abramowitz and
+// Stegun (|error| <= 1.5e-7, far inside a bf16 rounding) - a dozen vector instructions without a branch, where erff's
+// piecewise evaluation made these element-wise kernels instruction-bound; the normal distribution function is taken
+// from the complementary side for negative arguments, so nothing cancels.
+template <typename T>
+__device__ __forceinline__ void gelu_terms(float x, float &cdf, float &gauss) {
+    if constexpr (sizeof(T) == 4) {
+        cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+        gauss = __expf(-0.5f * x * x);
+    } else {
+        const float u = fabsf(x) * 0.70710678118654752f;
+        const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * u);
+        gauss = __expf(-u * u);
+        const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+        const float half_erfc = 0.5f * p * gauss;
+        cdf = x < 0.f ? half_erfc : 1.f - half_erfc;
+    }
+}
+template <typename T>
+__device__ __forceinline__ float gelu_value(float x) {
+    float cdf, gauss;
+    gelu_terms<T>(x, cdf, gauss);
+    return x * cdf;
+}
+template <typename T>
+__device__ __forceinline__ float gelu_slope(float x) {
+    float cdf, gauss;
+    gelu_terms<T>(x, cdf, gauss);
+    return cdf + x * 0.3989422804014327f * gauss;
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -29,9 +29,13 @@ constexpr int LN_MAXACC_NARROW = 4;  // 256 columns: msft's 216-wide outputs in 
 template <int KS> struct LnCfg {
     static constexpr int LS = KS + 8;  // LDS row stride in elements: 16-byte reads of 32 rows fall on distinct banks
     static constexpr int NKS = KS / 16;
-    static constexpr int A_PIECES = 4 * (KS / 64);  // 8-element pieces per thread: A slab, weight chunk
+    // A slab wider than 192 (256: msft's 216-wide rows) passes through LDS in two halves - the rows only cross LDS
+    // on their way into registers - so that two workgroups still fit a CU; the weight chunk has the slab's full width.
+    static constexpr int AH = KS > 192 ? 2 : 1;
+    static constexpr int AW = KS / AH, ALS = AW + 8;
+    static constexpr int A_PIECES = 4 * (AW / 64);  // 8-element pieces per thread: half of an A slab, weight chunk
     static constexpr int B_PIECES = 2 * (KS / 64);
-    static constexpr size_t LDS = (size_t)(LN_BM + LN_CN) * LS * sizeof(bf16_t);
+    static constexpr size_t LDS = ((size_t)LN_BM * ALS + (size_t)LN_CN * LS) * sizeof(bf16_t);
 };
 
 // Buffer descriptors: loads past the end of the described range return zero, which takes care of the rows beyond M, of weight rows beyond the matrix and of an
@@ -128,13 +132,16 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
     long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
-    int convH, int convW, int gated, const int *__restrict__ live_units, int unit_rows) {
+    int convH, int convW, int gated, const int *__restrict__ live_units, int unit_rows, bf16_t *__restrict__ aux, long long ld_aux) {
+    // gated (the epilogue of a bf16 result): 1 = gated SiLU; 2 = GELU, the pre-activation values going to aux when it is
+    // given; 3 = the result times GELU's slope at aux's values (the backward of 2 on the way out of the input gradient)
     using cfg = LnCfg<KS>;
-    constexpr int LS = cfg::LS, NKS = cfg::NKS;
+    constexpr int LS = cfg::LS, NKS = cfg::NKS, AH = cfg::AH, AW = cfg::AW, ALS = cfg::ALS;
     constexpr bool PERSIST = NACC > 0;
+    static_assert(AH == 1 || !PERSIST, "a slab that is staged in halves is the only slab");
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t *As = reinterpret_cast<bf16_t *>(smem);
-    bf16_t *Bs = As + LN_BM * LS;
+    bf16_t *Bs = As + LN_BM * ALS;
     float *biasl = reinterpret_cast<float *>(Bs + LN_CN * LS);  // bias of this block's columns, zero where there is none
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
         const long long live_rows = (long long)*live_units * unit_rows;
         if (m0 >= live_rows) {
             if (resid == nullptr) {
-                const int c0 = nc0 * (gated ? LN_CN / 2 : LN_CN), c1 = min((nc0 + nch) * (gated ? LN_CN / 2 : LN_CN), gated ? ncols / 2 : ncols);
+                const int c0 = nc0 * (gated == 1 ? LN_CN / 2 : LN_CN), c1 = min((nc0 + nch) * (gated == 1 ? LN_CN / 2 : LN_CN), gated == 1 ? ncols / 2 : ncols);
                 const int cq = (c1 - c0) >> 2;
                 for (int i = tid; i < rows * cq; i += LN_THREADS) {
                     const int r = i / cq, c = c0 + ((i - r * cq) << 2);
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
         constexpr int TPP = SW / 32;          // 32-column tiles per pass: 2 (bf16), 1 (fp32)
         constexpr int PC = 16 / sizeof(TC);   // columns per 16-byte piece
         constexpr int SROW = 144;             // staging row stride in bytes
-        unsigned char *stg = reinterpret_cast<unsigned char *>(As + wave * 32 * LS);
+        unsigned char *stg = reinterpret_cast<unsigned char *>(As + wave * 32 * ALS);
         const int nb = (nc0 + chunk) * LN_CN;
         // the bias comes from LDS (staged once per block)
         float4 bv[2][4];
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) bv[t][g] = *reinterpret_cast<const float4 *>(biasl + chunk * LN_CN + 4 * hh + t * 32 + 8 * g);
         if constexpr (sizeof(TC) == 2) {
-            if (gated) {
+            if (gated == 1) {
                 // Gated-SiLU epilogue (DSwinT_arch.py:69): the chunk's first 32 weight rows are gate rows, the other 32
                 // the content rows of the same hidden columns, so a lane holds gate and content of one position in
                 // the same register of the two tiles.  Both are rounded to bf16 first - what the stand-alone
@@ -266,6 +273,16 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
             // the residual's values are asked for before the tile goes through LDS, so that their latency
             // overlaps the staging
             float4 ro[4];
+            uint4 hv[4];
+            if constexpr (sizeof(TC) == 2) {
+                if (gated == 3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = m0 + wave * 32 + i * 8 + (lane >> 3), col = nb + (lane & 7) * PC;
+                        hv[i] = (m < M && col + PC <= ncols) ? *reinterpret_cast<const uint4 *>(aux + (size_t)m * ld_aux + col) : make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+            }
             if constexpr (sizeof(TC) == 4) {
                 if (resid != nullptr) {
 #pragma unroll
@@ -299,6 +316,26 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 uint4 v = *reinterpret_cast<const uint4 *>(stg + row * SROW + (lane & 7) * 16);
                 if (sizeof(TC) == 2 && (i & 1)) v = make_uint4(v.z, v.w, v.x, v.y);
                 TC *dst = C + (size_t)m * ldc + col;
+                if constexpr (sizeof(TC) == 2) {
+                    if (gated == 2) {
+                        // v holds what the plain projection would have written: it goes to aux, its GELU to the result
+                        if (aux != nullptr && m < M && col + PC <= ncols) *reinterpret_cast<uint4 *>(aux + (size_t)m * ld_aux + col) = v;
+                        const unsigned in[4] = {v.x, v.y, v.z, v.w};
+                        unsigned o[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            o[q] = pack_bf16(gelu_value<bf16_t>(__uint_as_float(in[q] << 16)), gelu_value<bf16_t>(__uint_as_float(in[q] & 0xffff0000u)));
+                        v = make_uint4(o[0], o[1], o[2], o[3]);
+                    } else if (gated == 3) {
+                        const unsigned in[4] = {v.x, v.y, v.z, v.w}, hx[4] = {hv[i].x, hv[i].y, hv[i].z, hv[i].w};
+                        unsigned o[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            o[q] = pack_bf16(__uint_as_float(in[q] << 16) * gelu_slope<bf16_t>(__uint_as_float(hx[q] << 16)),
+                                             __uint_as_float(in[q] & 0xffff0000u) * gelu_slope<bf16_t>(__uint_as_float(hx[q] & 0xffff0000u)));
+                        v = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                }
                 if (m < M) {
                     if constexpr (sizeof(TC) == 4) {
                         if (resid != nullptr && col + PC <= ncols) {
@@ -332,8 +369,9 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     };
 
     for (int slab = 0; slab < nslab; ++slab) {
+        bf16x8 afr[NKS];  // this wave's 32 rows of the slab as MFMA operands
         {
-            a_piece<TA> ap[cfg::A_PIECES];
+            a_piece<TA> ap[AH][cfg::A_PIECES];
             const int tap = slab / kslabs, kslab = slab - tap * kslabs;
             const unsigned soff = (unsigned)(kslab * KS * sizeof(TA));
             if (conv) {
@@ -345,34 +383,37 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 }
             }
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int h = 0; h < AH; ++h)
 #pragma unroll
-                for (int j = 0; j < KS / 64; ++j) ap[p * (KS / 64) + j].load(rs_a, a_off[p] + j * 64 * (unsigned)sizeof(TA), soff, half16);
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int j = 0; j < AW / 64; ++j)
+                        ap[h][p * (AW / 64) + j].load(rs_a, a_off[p] + (h * AW + j * 64) * (unsigned)sizeof(TA), soff, half16);
             if (slab == 0) load_b(0, 0);
             if (slab == 0) LN_STAMP(1);
-            lds_barrier();  // the previous slab's reads of As / Bs are over
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int h = 0; h < AH; ++h) {
+                lds_barrier();  // the previous reads of As / Bs are over
 #pragma unroll
-                for (int j = 0; j < KS / 64; ++j) {
-                    const uint4 v = ap[p * (KS / 64) + j].pack(kslab * KS + j * 64 + scol, K);
-                    *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * LS + j * 64 + scol) = v;
-                    // (convolution: the centre tap's rows are the block's own rows)
-                    // (a half-empty last slab: the columns at and beyond the padded K are not part of the copy's rows)
-                    if (copy_row != nullptr && p * 32 + srow < rows && (!conv || tap == 4) && kslab * KS + j * 64 < ((K + 63) & ~63))
-                        *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + kslab * KS + j * 64) = v;
-                }
-            write_b();
-        }
-        if (slab == 0) LN_STAMP(2);
-        lds_barrier();
-        if (slab == 0) LN_STAMP(3);
-        // this wave's 32 rows of the slab as MFMA operands
-        bf16x8 afr[NKS];
-        {
-            const bf16_t *arow = As + (wave * 32 + l31) * LS + 8 * hh;
+                for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) afr[ks] = as_bf16x8(*reinterpret_cast<const uint4 *>(arow + ks * 16));
+                    for (int j = 0; j < AW / 64; ++j) {
+                        const int kc = kslab * KS + h * AW + j * 64;  // first column of this thread's group of 64
+                        const uint4 v = ap[h][p * (AW / 64) + j].pack(kc + scol, K);
+                        *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * ALS + j * 64 + scol) = v;
+                        // (convolution: the centre tap's rows are the block's own rows)
+                        // (a half-empty last slab: the columns at and beyond the padded K are not part of the copy's rows)
+                        if (copy_row != nullptr && p * 32 + srow < rows && (!conv || tap == 4) && kc < ((K + 63) & ~63))
+                            *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + kc) = v;
+                    }
+                if (h == AH - 1) write_b();
+                if (slab == 0 && h == AH - 1) LN_STAMP(2);
+                lds_barrier();
+                if (slab == 0 && h == AH - 1) LN_STAMP(3);
+                const bf16_t *arow = As + (wave * 32 + l31) * ALS + 8 * hh;
+#pragma unroll
+                for (int ks = 0; ks < NKS / AH; ++ks) afr[h * (NKS / AH) + ks] = as_bf16x8(*reinterpret_cast<const uint4 *>(arow + ks * 16));
+            }
         }
         for (int chunk = 0; chunk < nch; ++chunk) {
             if (slab == 0 && chunk == 1) LN_STAMP(4);
@@ -638,7 +679,8 @@ int set_lds(const void *kern, size_t lds, const char *who) {
 template <typename TA, typename TC, int KS>
 int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
                   void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, const float *resid, long long ld_resid,
-                  const float *rscale, int convH, int convW, int gated, const int *live_units, int unit_rows, hipStream_t st) {
+                  const float *rscale, int convH, int convW, int gated, const int *live_units, int unit_rows, hipStream_t st,
+                  void *aux = nullptr, long long ld_aux = 0) {
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
@@ -657,15 +699,19 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "dsw_linear: %d output columns per block need %zu bytes of LDS", cpb * LN_CN, lds);
     int rc;
     if (nslab > 1) {
-        auto kern = linear_nt_kernel<TA, TC, KS, NACC>;
-        if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows);
+        if constexpr (cfg::AH > 1) {
+            return fail(DSW_EUNSUPPORTED, "dsw_linear: slabs of %d columns are single", KS);
+        } else {
+            auto kern = linear_nt_kernel<TA, TC, KS, NACC>;
+            if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
+                               bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows, (bf16_t *)aux, ld_aux);
+        }
     } else {
         auto kern = linear_nt_kernel<TA, TC, KS, 0>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows, (bf16_t *)aux, ld_aux);
     }
     return check_launch("linear_nt_kernel");
 }
@@ -689,7 +735,7 @@ extern "C" int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w
 static int linear_impl(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                        const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
                        long long lda_copy, const float *resid, long long ld_resid, const float *rscale, void *stream, int gated = 0,
-                       const int *live_units = nullptr, int unit_rows = 0) {
+                       const int *live_units = nullptr, int unit_rows = 0, void *aux = nullptr, long long ld_aux = 0) {
     if (M <= 0 || M > 0x7fffff00LL || K <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
     DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
@@ -699,7 +745,7 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
                                       "base aligned to 4 elements (K=%d lda=%lld)", K, lda);
     if (ldw < Kp || ldw % 8 || ((uintptr_t)w_p & 15))
         return fail(DSW_EUNSUPPORTED, "dsw_linear: the weight needs rows of >= %d elements (K rounded up to 64), a multiple of 8 (ldw=%d)", Kp, ldw);
-    if (ncols % 4 || ldc < (gated ? ncols / 2 : ncols) || ldc % 4 || ((uintptr_t)c & 15))
+    if (ncols % 4 || ldc < (gated == 1 ? ncols / 2 : ncols) || ldc % 4 || ((uintptr_t)c & 15))
         return fail(DSW_EUNSUPPORTED, "dsw_linear: C needs ncols %% 4 == 0, ldc %% 4 == 0, ldc >= ncols, a 16-byte aligned base (ncols=%d ldc=%lld)",
                     ncols, ldc);
     if (bias != nullptr && (N <= 0 || N % 4 || N > ncols || ((uintptr_t)bias & 15)))
@@ -718,9 +764,16 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
     // of 128 with the last one half empty (A is masked at K, so what the weight rows hold there does not matter:
     // the next row's finite values, or zero past the end of the matrix) rather than twice as many slabs of 64,
     // each with its own round of barriers
-    const int KS = Kp % 192 == 0 ? 192 : (Kp % 128 == 0 || Kp > 192 ? 128 : 64);
+    // (a K of 193..256 is one slab of 256 whose rows cross LDS in two halves: no accumulators carried over slabs, every
+    // chunk stored as soon as it is complete)
+    static const bool no256 = getenv("DSW_LINEAR_NO256") != nullptr;   // experiments: the two-slab path for K of 193..256
+    const int KS = Kp % 192 == 0 ? 192 : (Kp == 256 && !no256) ? 256 : (Kp % 128 == 0 || Kp > 192 ? 128 : 64);
     const int nslab = (Kp + KS - 1) / KS;
-    if (gated && (nslab != 1 || c_dtype != DSW_BF16 || ncols % 64 || ldc % 8 || a_copy != nullptr || resid != nullptr || accumulate))
+    if (gated >= 2 && (c_dtype != DSW_BF16 || ncols % 8 || ldc % 8 || resid != nullptr || accumulate || live_units != nullptr ||
+                       (gated == 3 && aux == nullptr) || (aux != nullptr && (ld_aux < ncols || ld_aux % 8 || ((uintptr_t)aux & 15)))))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear_gelu: needs a bf16 result, ncols and the row strides multiples of 8, 16-byte aligned bases "
+                                      "(ncols=%d ldc=%lld ld_aux=%lld)", ncols, ldc, ld_aux);
+    if (gated == 1 && (nslab != 1 || c_dtype != DSW_BF16 || ncols % 64 || ldc % 8 || a_copy != nullptr || resid != nullptr || accumulate))
         return fail(DSW_EUNSUPPORTED, "dsw_linear_gated_silu: needs K <= 192 (or 128 / 64 exactly padded), a bf16 result with rows of a multiple of "
                                       "8 elements, whole chunks of 64 weight rows (K=%d rows=%d ldo=%lld)", K, ncols, ldc);
     if (live_units != nullptr && (unit_rows <= 0 || (resid != nullptr && !accumulate)))
@@ -729,9 +782,10 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
     int rc = DSW_OK;
 #define DSW_LINEAR_KS(KSV)                                                                                                     \
     DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
-        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, live_units, unit_rows, st); \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, live_units, unit_rows, st, aux, ld_aux); \
     }))
     if (KS == 192) DSW_LINEAR_KS(192);
+    else if (KS == 256) DSW_LINEAR_KS(256);
     else if (KS == 128) DSW_LINEAR_KS(128);
     else DSW_LINEAR_KS(64);
 #undef DSW_LINEAR_KS
@@ -757,6 +811,21 @@ extern "C" int dsw_linear_gated_silu(const void *a, int a_dtype, long long lda, 
                                      const float *bias, void *out, long long ldo, void *stream) {
     return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, wrows, out, DSW_BF16, ldo, wrows, 0, nullptr, 0, nullptr, 0, nullptr,
                        stream, 1);
+}
+
+extern "C" int dsw_linear_gelu(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                               const float *bias, int N, void *out, long long ldo, int ncols, void *pre, long long ld_pre, void *a_copy,
+                               long long lda_copy, void *stream) {
+    return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, N, out, DSW_BF16, ldo, ncols, 0, a_copy, lda_copy, nullptr, 0, nullptr,
+                       stream, 2, nullptr, 0, pre, ld_pre);
+}
+
+extern "C" int dsw_linear_gelu_bwd(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                                   const void *pre, long long ld_pre, void *out, long long ldo, int ncols, void *a_copy, long long lda_copy,
+                                   void *stream) {
+    DSW_REQUIRE(pre, "dsw_linear_gelu_bwd: null pointer");
+    return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, nullptr, 0, out, DSW_BF16, ldo, ncols, 0, a_copy, lda_copy, nullptr, 0, nullptr,
+                       stream, 3, nullptr, 0, const_cast<void *>(pre), ld_pre);
 }
 
 static int conv3x3_impl(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,

@@ -73,8 +73,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG *__restrict__
         const long long row = r0 + rloc;
         const bool ok = row < M;
         const float rs = ok ? rstd[row] : 0.f;
-        float4 xh[RN_MAXV], g[RN_MAXV];
+        float4 xh[RN_MAXV], g[RN_MAXV], av[RN_MAXV];
         float dot = 0.f;
+        // the gradient that reached x around the norm is asked for with the row's other operands, ahead of the reduction
+#pragma unroll
+        for (int i = 0; i < RN_MAXV; ++i)
+            av[i] = ok && dx_add != nullptr && sub + RN_LPR * i < nv
+                        ? *reinterpret_cast<const float4 *>(dx_add + (size_t)row * C + 4 * (sub + RN_LPR * i)) : f4zero();
 #pragma unroll
         for (int i = 0; i < RN_MAXV; ++i) {
             const bool live = ok && sub + RN_LPR * i < nv;
@@ -91,8 +96,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG *__restrict__
             for (int i = 0; i < RN_MAXV; ++i)
                 if (sub + RN_LPR * i < nv) {
                     const size_t at = (size_t)row * C + 4 * (sub + RN_LPR * i);
-                    const float4 v = (g[i] - xh[i] * dot) * rs;
-                    *reinterpret_cast<float4 *>(dx + at) = dx_add != nullptr ? *reinterpret_cast<const float4 *>(dx_add + at) + v : v;
+                    *reinterpret_cast<float4 *>(dx + at) = av[i] + (g[i] - xh[i] * dot) * rs;
                 }
         }
     }
@@ -243,11 +247,6 @@ extern "C" int dsw_gated_silu_bwd(const void *dout, int dout_dtype, long long ld
 namespace dsw {
 namespace {
 
-__device__ __forceinline__ float gelu_value(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_slope(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ x, long long ldx, int C, long long M, T *__restrict__ y,
                                                        long long ldy) {
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ x, 
         float4 r = f4zero();
         if (j < C) {
             const float4 v = io<T>::ld4(x + m * ldx + j);
-            r = make_float4(gelu_value(v.x), gelu_value(v.y), gelu_value(v.z), gelu_value(v.w));
+            r = make_float4(gelu_value<T>(v.x), gelu_value<T>(v.y), gelu_value<T>(v.z), gelu_value<T>(v.w));
         }
         io<T>::st4(y + m * ldy + j, r);
     }
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T *__restrict__ dy,
         float4 r = f4zero();
         if (j < C) {
             const float4 v = io<T>::ld4(x + m * ldx + j), g = io<T>::ld4(dy + m * ld_dy + j);
-            r = make_float4(g.x * gelu_slope(v.x), g.y * gelu_slope(v.y), g.z * gelu_slope(v.z), g.w * gelu_slope(v.w));
+            r = make_float4(g.x * gelu_slope<T>(v.x), g.y * gelu_slope<T>(v.y), g.z * gelu_slope<T>(v.z), g.w * gelu_slope<T>(v.w));
         }
         io<T>::st4(dx + m * ld_dx + j, r);
     }
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(256) void shuffle2_gelu_kernel(const T *__restrict_
         const long long b = t / (2 * H);
         const long long src = ((((b * H + (oh >> 1)) * W + (ow >> 1)) * 4 + (oh & 1) * 2 + (ow & 1)) * (long long)c) + 4 * j;
         const float4 v = io<T>::ld4(x + src);
-        io<T>::st4(y + it * 4, make_float4(gelu_value(v.x), gelu_value(v.y), gelu_value(v.z), gelu_value(v.w)));
+        io<T>::st4(y + it * 4, make_float4(gelu_value<T>(v.x), gelu_value<T>(v.y), gelu_value<T>(v.z), gelu_value<T>(v.w)));
     }
 }
 }  // namespace
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(256) void shuffle2_gelu_bwd_kernel(const T *__restr
         const long long b = t / (2 * H);
         const long long src = ((((b * H + (oh >> 1)) * W + (ow >> 1)) * 4 + (oh & 1) * 2 + (ow & 1)) * (long long)c) + 4 * j;
         const float4 v = io<T>::ld4(x + src), g = io<T>::ld4(dy + it * 4);
-        io<T>::st4(dx + src, make_float4(g.x * gelu_slope(v.x), g.y * gelu_slope(v.y), g.z * gelu_slope(v.z), g.w * gelu_slope(v.w)));
+        io<T>::st4(dx + src, make_float4(g.x * gelu_slope<T>(v.x), g.y * gelu_slope<T>(v.y), g.z * gelu_slope<T>(v.z), g.w * gelu_slope<T>(v.w)));
     }
 }
 }  // namespace
@@ -614,8 +613,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG *__restrict
         const long long row = r0 + rloc;
         const bool ok = row < M;
         const float rs = ok ? rstd[row] : 0.f, mu = ok ? mean[row] : 0.f;
-        float4 xh[RN_MAXV], g[RN_MAXV];
+        float4 xh[RN_MAXV], g[RN_MAXV], av[RN_MAXV];
         float s1 = 0.f, s2 = 0.f;
+        // gradients that reached x by other ways - a map of x's shape, and one that covers the first cols2 columns - are
+        // asked for with the row's other operands, ahead of the reductions
+#pragma unroll
+        for (int i = 0; i < RN_MAXV; ++i) {
+            const int c = 4 * (sub + RN_LPR * i);
+            const bool live = ok && sub + RN_LPR * i < nv;
+            av[i] = live && dx_add != nullptr ? *reinterpret_cast<const float4 *>(dx_add + row * C + c) : f4zero();
+            if (live && dx_add2 != nullptr && c < cols2) av[i] = av[i] + *reinterpret_cast<const float4 *>(dx_add2 + row * ld_add2 + c);
+        }
 #pragma unroll
         for (int i = 0; i < RN_MAXV; ++i) {
             const bool live = ok && sub + RN_LPR * i < nv;
@@ -635,12 +643,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG *__restrict
             for (int i = 0; i < RN_MAXV; ++i)
                 if (sub + RN_LPR * i < nv) {
                     const int c = 4 * (sub + RN_LPR * i);
-                    float4 v = make_float4((g[i].x - s1 - xh[i].x * s2) * rs, (g[i].y - s1 - xh[i].y * s2) * rs, (g[i].z - s1 - xh[i].z * s2) * rs,
-                                           (g[i].w - s1 - xh[i].w * s2) * rs);
-                    // gradients that reached x by other ways: a map of x's shape, and one that covers the first cols2 columns
-                    if (dx_add != nullptr) v = v + *reinterpret_cast<const float4 *>(dx_add + row * C + c);
-                    if (dx_add2 != nullptr && c < cols2) v = v + *reinterpret_cast<const float4 *>(dx_add2 + row * ld_add2 + c);
-                    *reinterpret_cast<float4 *>(dx + row * C + c) = v;
+                    *reinterpret_cast<float4 *>(dx + row * C + c) =
+                        av[i] + make_float4((g[i].x - s1 - xh[i].x * s2) * rs, (g[i].y - s1 - xh[i].y * s2) * rs, (g[i].z - s1 - xh[i].z * s2) * rs,
+                                            (g[i].w - s1 - xh[i].w * s2) * rs);
                 }
         }
     }

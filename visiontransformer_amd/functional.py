@@ -1088,6 +1088,18 @@ def _one(device):
     return t
 
 
+class GeluLink:
+    """What ties the two projections of y = fc2(gelu(fc1(x))) (msft's MLP, msft_arch.py:19-33) together when the
+    activation lives in their epilogues: fc1's kernel writes gelu(h) as its result and h on the side (kept here for
+    the backward), and fc2's input-gradient kernel multiplies dy W2 by gelu'(h) on its way out, so that what
+    reaches fc1's backward is dh already.  `done` records the backward pass in which fc2's kernel did that; in a
+    pass where it did not (another path computed fc2's input gradient), fc1's backward applies the slope itself."""
+
+    def __init__(self):
+        self.h = None
+        self.done = None
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b for the projections of the attention modules.
 
@@ -1107,7 +1119,9 @@ class _LinearFn(torch.autograd.Function):
       chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act_dtype, pad_out, live=None, resid=None, pending_out=None, pending_in=None):
+    def forward(ctx, x, weight, bias, act_dtype, pad_out, live=None, resid=None, pending_out=None, pending_in=None, gelu=None):
+        # gelu = ("out", GeluLink): the result is gelu(x W^T + b) (the caller has checked that the kernel takes the call);
+        # gelu = ("in", GeluLink): x is such a result, and the input gradient leaves as the gradient of the link's h
         # resid (fp32, the result's shape): the result is resid + (x W^T + b) as fp32, one kernel (the caller has
         # checked that the kernel takes the call); its gradient share, dy itself, goes to pending_out when given.
         # pending_in: a PendingGrad whose gradient the input-gradient kernel adds to dx as it writes it.
@@ -1143,6 +1157,16 @@ class _LinearFn(torch.autograd.Function):
                     call("dsw_linear_residual", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K,
                          ptr(w_p), w_p.shape[0], w_p.shape[1], None if b32 is None else ptr(b32), N, ptr(resid), N, ptr(_one(x2.device)),
                          ptr(y_p), N, N, stream(x2.device))
+                elif gelu is not None and gelu[0] == "out":
+                    assert live is None and Nout % 8 == 0
+                    y_p = torch.empty(T, Nout, dtype=act_dtype, device=x2.device)
+                    keep_h = any(ctx.needs_input_grad[:3])
+                    h = _mark_padded(torch.empty(T, Nout, dtype=act_dtype, device=x2.device)) if keep_h else None
+                    call("dsw_linear_gelu", ctypes.c_void_p(a2.data_ptr()), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K,
+                         ptr(w_p), w_p.shape[0], w_p.shape[1], None if b32 is None else ptr(b32), N, ptr(y_p), Nout, Nout,
+                         None if h is None else ptr(h), Nout, None if a_copy is None else ptr(a_copy),
+                         0 if a_copy is None else a_copy.shape[1], stream(x2.device))
+                    gelu[1].h = h
                 else:
                     y_p = torch.empty(T, Nout, dtype=act_dtype, device=x2.device)
                     _mfma_linear(a2, K, w_p, b32, N, y_p, Nout, a_copy, live=live)
@@ -1166,6 +1190,8 @@ class _LinearFn(torch.autograd.Function):
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, N, Kd, mfma)
         ctx.live = live if mfma else None
         ctx.pending = (pending_out, pending_in)
+        ctx.gelu = gelu if mfma else None
+        assert gelu is None or mfma
         return y_p[:, :N].view(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -1176,6 +1202,18 @@ class _LinearFn(torch.autograd.Function):
         Np, Kp = _ceil_pad(N), _ceil_pad(Kd)
         need_dx = ctx.needs_input_grad[0]
         need_dw = ctx.needs_input_grad[1] or (bdt is not None and ctx.needs_input_grad[2])
+        gelu = ctx.gelu
+        if gelu is not None and gelu[0] == "out":
+            link = gelu[1]
+            if link.done != torch._C._current_graph_task_id():
+                # the gradient of gelu(h) arrived, not that of h: the slope is applied here
+                h = link.h[:, :N]
+                d2, ldg = _row_view4(dy.to(h.dtype), N)
+                dh = _mark_padded(torch.empty_like(link.h))
+                call("dsw_gelu_bwd", _dptr(d2), ldg, ptr(link.h), dtype_code(h.dtype), link.h.shape[1], N, h.shape[0], ptr(dh), dh.shape[1],
+                     stream(dh.device))
+                dy = dh[:, :N].view(dy.shape)
+            link.done = None
         with torch.autocast("cuda", enabled=False):
             dy2 = dy.reshape(-1, N)
             T = dy2.shape[0]
@@ -1201,7 +1239,15 @@ class _LinearFn(torch.autograd.Function):
                         K = Np
                 if xdt == act:
                     dx_p = _mark_padded(torch.empty(T, Kp, dtype=act, device=dy2.device))
-                    _mfma_linear(a2, K, w_s, None, 0, dx_p, Kp, a_copy, live=ctx.live)
+                    link = gelu[1] if gelu is not None and gelu[0] == "in" else None
+                    if link is not None and link.h is not None and link.h.shape == (T, Kp) and ctx.live is None and act == torch.bfloat16:
+                        # dh = (dy W) * gelu'(h) in the kernel's epilogue
+                        call("dsw_linear_gelu_bwd", ctypes.c_void_p(a2.data_ptr()), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1],
+                             T, K, ptr(w_s), w_s.shape[0], w_s.shape[1], ptr(link.h), Kp, ptr(dx_p), Kp, Kp,
+                             None if a_copy is None else ptr(a_copy), 0 if a_copy is None else a_copy.shape[1], stream(dy2.device))
+                        link.done = torch._C._current_graph_task_id()
+                    else:
+                        _mfma_linear(a2, K, w_s, None, 0, dx_p, Kp, a_copy, live=ctx.live)
                     dx = dx_p[:, :Kd].view(xshape) if Kp != Kd else dx_p.view(xshape)
                 else:
                     dx = torch.empty(T, Kd, dtype=xdt, device=dy2.device)
@@ -1262,7 +1308,7 @@ class _LinearFn(torch.autograd.Function):
                 ctx.pending[0].put(dy)
             else:
                 d_resid = dy
-        return dx, dw, db, None, None, None, d_resid, None, None
+        return dx, dw, db, None, None, None, d_resid, None, None, None
 
 
 def linear_plus_residual(a, lin, resid, pending=None):
@@ -1280,7 +1326,7 @@ def linear_plus_residual(a, lin, resid, pending=None):
         return None
     if _padded_rows(a.reshape(-1, Kd), torch.bfloat16) is None:
         return None
-    return _run(_LinearFn, a, weight, lin.bias, torch.bfloat16, False, None, resid, pending, None)
+    return _run(_LinearFn, a, weight, lin.bias, torch.bfloat16, False, None, resid, pending, None, None)
 
 
 def linear(x, lin, pad_out=False, live=None, grad_extra=None):
@@ -1293,7 +1339,27 @@ def linear(x, lin, pad_out=False, live=None, grad_extra=None):
     grad_extra: a PendingGrad; what it holds when the backward pass gets here is added to x's gradient by the kernel
     that writes it."""
     act = autocast_dtype(x.dtype)
-    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out), live, None, None, grad_extra)
+    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out), live, None, None, grad_extra, None)
+
+
+FUSE_GELU = True   # False: mlp_gelu always declines
+
+
+def mlp_gelu(x, fc1, fc2):
+    """fc2(gelu(fc1(x))) of msft's MLP (msft_arch.py:19-33) with the activation inside the projection kernels: fc1's
+    epilogue writes gelu(h) (and h on the side when a backward will want it), fc2's input-gradient kernel applies
+    gelu'(h) as it writes dh - no pass over the hidden rows for the activation, forward or backward.  bf16 autocast
+    only; None when the call is not one the kernels take (the caller composes linear / gelu / linear)."""
+    w1, w2 = fc1.weight, fc2.weight
+    Hd, Kd = w1.shape
+    ok = (FUSE_GELU and autocast_dtype(None) == torch.bfloat16 and x.is_cuda and x.numel() > 0 and x.dtype in (torch.float32, torch.bfloat16)
+          and Hd % 4 == 0 and w2.shape[1] == Hd and w2.shape[0] % 4 == 0
+          and all(w.is_contiguous() and w.dtype in (torch.float32, torch.bfloat16) and w.data_ptr() % 16 == 0 for w in (w1, w2)))
+    if not ok:
+        return None
+    link = GeluLink()
+    g = _run(_LinearFn, x, w1, fc1.bias, torch.bfloat16, True, None, None, None, None, ("out", link))
+    return _run(_LinearFn, g, w2, fc2.bias, torch.bfloat16, False, None, None, None, None, ("in", link))
 
 
 def linear_residual(a, lin, resid, r):

@@ -110,8 +110,12 @@ class MLP(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             return self.mlp(x)
-        # the two Linears through the projection kernels (they read the LayerNorm's fp32 output where it lies)
-        return self.mlp[3](K.linear(K.gelu(K.linear(x, self.mlp[0], pad_out=True), pad_out=True), self.mlp[2]))
+        # the two Linears through the projection kernels (they read the LayerNorm's fp32 output where it lies), the
+        # activation in their epilogues under bf16 autocast
+        y = K.mlp_gelu(x, self.mlp[0], self.mlp[2])
+        if y is None:
+            y = K.linear(K.gelu(K.linear(x, self.mlp[0], pad_out=True), pad_out=True), self.mlp[2])
+        return self.mlp[3](y)
 
 
 class ViTBlock(nn.Module):
