@@ -407,6 +407,11 @@ int dsw_cast_rows(const void *src, int src_dtype, long long src_ld, void *dst, i
  *           zeroed (the operand the weight-gradient GEMM wants), saving a separate cast pass.
  * K <= 192 takes any ncols; K > 192 is run in slabs of 64/128/192 columns of a. */
 int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w_p, void *w_pt, void *stream);
+/* dsw_weight_prep for n weights in ceil(n / 48) launches (the weights of a network after an optimizer step: the
+ * Linear layers named above in every block).  w, w_dtype, N, K, w_p, w_pt: HOST arrays of n entries (read during
+ * the call only), each entry as the argument of the same name of dsw_weight_prep. */
+int dsw_weight_prep_batch(int n, const void *const *w, const int *w_dtype, const int *N, const int *K,
+                          void *const *w_p, void *const *w_pt, void *stream);
 int dsw_linear(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
                int ldw, const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols,
                int accumulate, void *a_copy, long long lda_copy, const int *live_units, int unit_rows, void *stream);

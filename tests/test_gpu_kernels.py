@@ -706,6 +706,65 @@ def test_gelu_rows(cuda0, dtype, M, C, padded_in, pad_out):
 
 
 @pytest.mark.gpu
+def test_weight_prep_batch_and_the_kept_operands(cuda0):
+    """dsw_weight_prep_batch against dsw_weight_prep, weight by weight (more weights than one launch holds, both
+    dtypes), and the bookkeeping above it: a kept operand pair is reused while its parameter is unchanged, and the
+    first projection after an in-place update (an optimizer step) refreshes the pairs of every modified parameter
+    - 1x1 convolution weights taken as matrices included - in one call, as new tensors with the new values."""
+    import ctypes
+    from visiontransformer_amd import _lib, functional as K
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(180, 180), (540, 180), (96, 288), (30, 44), (216, 648), (64, 64), (7, 500)] * 8      # 56 > 48 per launch
+    ws = [torch.randn(n, k, generator=gen).to(torch.bfloat16 if i % 3 == 0 else torch.float32).to(cuda0) for i, (n, k) in enumerate(shapes)]
+    singles, batch = [], []
+    for w in ws:
+        n, k = w.shape
+        a = torch.full((_ceil64(n), _ceil64(k)), float("nan"), device=cuda0, dtype=torch.bfloat16)
+        b = torch.full((_ceil64(k), _ceil64(n)), float("nan"), device=cuda0, dtype=torch.bfloat16)
+        _lib.call("dsw_weight_prep", _lib.ptr(w), _lib.dtype_code(w.dtype), n, k, _lib.ptr(a), _lib.ptr(b), _lib.stream(cuda0))
+        singles.append((a, b))
+        batch.append((torch.full_like(a, float("nan")), torch.full_like(b, float("nan"))))
+    cnt = len(ws)
+    vp, ip = ctypes.c_void_p * cnt, ctypes.c_int * cnt
+    tabs = (vp(*[w.data_ptr() for w in ws]), ip(*[_lib.dtype_code(w.dtype) for w in ws]), ip(*[w.shape[0] for w in ws]),
+            ip(*[w.shape[1] for w in ws]), vp(*[a.data_ptr() for a, _ in batch]), vp(*[b.data_ptr() for _, b in batch]))
+    _lib.call("dsw_weight_prep_batch", cnt, *[ctypes.cast(t, ctypes.c_void_p) for t in tabs], _lib.stream(cuda0))
+    for (a, b), (a2, b2), w in zip(singles, batch, ws):
+        assert torch.equal(a, a2) and torch.equal(b, b2)
+        assert torch.equal(a[:w.shape[0], :w.shape[1]], w.to(torch.bfloat16)) and torch.equal(a.t(), b)
+
+    lins = [torch.nn.Linear(180, 540).to(cuda0), torch.nn.Linear(96, 96, bias=False).to(cuda0)]
+    conv = torch.nn.Conv2d(192, 96, 1).to(cuda0)
+    mats = [lins[0].weight, lins[1].weight, conv.weight.view(96, 192)]
+    first = [K._weight_operands(m) for m in mats]
+    again = [K._weight_operands(conv.weight.view(96, 192) if i == 2 else m) for i, m in enumerate(mats)]
+    for (a, b), (a2, b2) in zip(first, again):
+        assert a2 is a and b2 is b                                 # reused, the fresh view of the convolution's weight too
+    with torch.no_grad():
+        for m in (lins[0].weight, conv.weight):
+            m.mul_(0.5)                                            # what an optimizer step does to the version counters
+    calls = []
+    real_call = K.call
+
+    def spy(name, *args):
+        calls.append(name)
+        return real_call(name, *args)
+
+    K.call = spy
+    try:
+        after = [K._weight_operands(m) for m in (lins[0].weight, lins[1].weight, conv.weight.view(96, 192))]
+    finally:
+        K.call = real_call
+    assert calls == ["dsw_weight_prep_batch"]                      # one call for both modified parameters
+    assert after[1][0] is first[1][0]                              # the untouched one is still the kept pair
+    for i, w in ((0, lins[0].weight), (2, conv.weight.view(96, 192))):
+        assert after[i][0] is not first[i][0] and after[i][1] is not first[i][1]
+        assert torch.equal(after[i][0][:w.shape[0], :w.shape[1]], w.detach().to(torch.bfloat16))
+        assert torch.equal(after[i][0].t(), after[i][1])
+        assert torch.equal(first[i][0][:w.shape[0], :w.shape[1]].float(), (w.detach() * 2).to(torch.bfloat16).float())   # the old pair is untouched
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N", [(300, 180, 540), (1000, 96, 100), (4096 + 24, 192, 64), (128 * 300 + 5, 180, 180),
                                    (2000, 360, 180), (3000, 216, 648), (700, 432, 216)])
 def test_linear_wgrad_kernel(cuda0, M, K, N):

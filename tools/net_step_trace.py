@@ -2,7 +2,8 @@
 """Training steps of the DSWT default / MSFT config C network (batch 32 x 64x64, bf16 autocast, L1 loss, the package's
 Adam) for a rocprofv3 kernel trace: rocprofv3 --kernel-trace --output-format csv -- python3 tools/net_step_trace.py
 [dswt|msft] [steps]  (tools/trace_summary.py reads the trace).  Prints the time per step of the steps after the first
-four.  DSW_FUSE_GELU=0: the MLP's activation as kernels of its own."""
+four.  DSW_FUSE_GELU=0: the MLP's activation as kernels of its own; DSW_BATCH_PREP=0: one weight-preparation launch per
+projection."""
 import os
 import sys
 
@@ -22,6 +23,7 @@ x = torch.rand(32, 3, 64, 64, device=dev) * 2 - 1
 tgt = torch.rand(32, 3, 256, 256, device=dev) * 2 - 1
 from visiontransformer_amd import functional as K  # noqa: E402
 K.FUSE_GELU = os.environ.get("DSW_FUSE_GELU", "1") != "0"
+K.BATCH_WEIGHT_PREP = os.environ.get("DSW_BATCH_PREP", "1") != "0"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 t0 = None
 for i in range(steps):
@@ -35,4 +37,5 @@ for i in range(steps):
     opt.zero_grad(set_to_none=True)
 torch.cuda.synchronize()
 if t0 is not None:
-    print("%s: %.2f ms per step (FUSE_GELU=%s)" % (which, (time.perf_counter() - t0) / (steps - 4) * 1e3, K.FUSE_GELU), flush=True)
+    print("%s: %.2f ms per step (FUSE_GELU=%s BATCH_WEIGHT_PREP=%s)" % (which, (time.perf_counter() - t0) / (steps - 4) * 1e3, K.FUSE_GELU,
+                                                                        K.BATCH_WEIGHT_PREP), flush=True)

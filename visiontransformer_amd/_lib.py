@@ -50,6 +50,7 @@ SIGNATURES = {
     "dsw_cast_rows": (_I, [_P, _I, ctypes.c_longlong, _P, _I, ctypes.c_longlong, ctypes.c_longlong,
                            ctypes.c_longlong, _I, _I, _P]),
     "dsw_weight_prep": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "dsw_weight_prep_batch": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "dsw_linear": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P,
                         ctypes.c_longlong, _P, _I, _P]),
     "dsw_linear_gated_silu": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _P, ctypes.c_longlong, _P]),

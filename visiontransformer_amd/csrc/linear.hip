@@ -461,6 +461,30 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const TW *__restrict__
     if (wpt != nullptr) wpt[(size_t)k * Np + n] = v;
 }
 
+// the same for many weights in one launch: a block finds its weight by the first-block table (a scalar loop)
+constexpr int WP_BATCH = 48;
+struct WpBatch {
+    const void *w[WP_BATCH];
+    bf16_t *wp[WP_BATCH], *wpt[WP_BATCH];
+    int N[WP_BATCH], K[WP_BATCH], first_block[WP_BATCH + 1];
+    unsigned long long is_bf16;  // bit i: weight i is bf16 (else fp32)
+    int n;
+};
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const WpBatch b) {
+    int t = 0;
+    while (t + 1 < b.n && (int)blockIdx.x >= b.first_block[t + 1]) ++t;
+    const int N = b.N[t], K = b.K[t], Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64;
+    const int i = ((int)blockIdx.x - b.first_block[t]) * 256 + threadIdx.x;
+    if (i >= Np * Kp) return;
+    const int n = i / Kp, k = i - n * Kp;
+    bf16_t v = 0;
+    if (n < N && k < K)
+        v = (b.is_bf16 >> t) & 1ull ? static_cast<const bf16_t *>(b.w[t])[(size_t)n * K + k]
+                                     : f32_to_bf16(static_cast<const float *>(b.w[t])[(size_t)n * K + k]);
+    if (b.wp[t] != nullptr) b.wp[t][i] = v;
+    if (b.wpt[t] != nullptr) b.wpt[t][(size_t)k * Np + n] = v;
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------
 // dW[n][k] = sum_m dY[m][n] X[m][k]: a tiny output and a reduction over every token.  A workgroup
 // (6 waves) owns a 192 x 192 output block in its accumulators and walks its share of the rows in
@@ -730,6 +754,39 @@ extern "C" int dsw_weight_prep(const void *w, int w_dtype, int N, int K, void *w
                            Kp, (bf16_t *)w_p, (bf16_t *)w_pt);
     });
     return check_launch("weight_prep_kernel");
+}
+
+extern "C" int dsw_weight_prep_batch(int n, const void *const *w, const int *w_dtype, const int *N, const int *K, void *const *w_p,
+                                     void *const *w_pt, void *stream) {
+    if (n < 0) return fail(DSW_EINVAL, "dsw_weight_prep_batch: n=%d", n);
+    DSW_REQUIRE(n == 0 || (w && w_dtype && N && K && w_p && w_pt), "dsw_weight_prep_batch: null pointer");
+    for (int i = 0; i < n; ++i) {
+        if (N[i] <= 0 || K[i] <= 0 || (long long)((N[i] + 63) / 64 * 64) * ((K[i] + 63) / 64 * 64) > 0x7fffffffLL)
+            return fail(DSW_EINVAL, "dsw_weight_prep_batch: bad sizes N=%d K=%d (weight %d)", N[i], K[i], i);
+        if (w_dtype[i] != DSW_F32 && w_dtype[i] != DSW_BF16) return fail(DSW_EUNSUPPORTED, "dsw_weight_prep_batch: weight %d: fp32 or bf16", i);
+        DSW_REQUIRE(w[i] && (w_p[i] || w_pt[i]), "dsw_weight_prep_batch: null pointer (weight %d)", i);
+    }
+    for (int i0 = 0; i0 < n; i0 += WP_BATCH) {
+        WpBatch b{};
+        b.n = n - i0 < WP_BATCH ? n - i0 : WP_BATCH;
+        int blocks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const int i = i0 + j;
+            b.w[j] = w[i];
+            b.wp[j] = (bf16_t *)w_p[i];
+            b.wpt[j] = (bf16_t *)w_pt[i];
+            b.N[j] = N[i];
+            b.K[j] = K[i];
+            if (w_dtype[i] == DSW_BF16) b.is_bf16 |= 1ull << j;
+            b.first_block[j] = blocks;
+            blocks += (((N[i] + 63) / 64 * 64) * ((K[i] + 63) / 64 * 64) + 255) / 256;
+        }
+        b.first_block[b.n] = blocks;
+        hipLaunchKernelGGL(weight_prep_batch_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), b);
+        int rc = check_launch("weight_prep_batch_kernel");
+        if (rc) return rc;
+    }
+    return DSW_OK;
 }
 
 static int linear_impl(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,

@@ -1032,26 +1032,68 @@ def _may_keep_operands():
     return not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
 
 
+BATCH_WEIGHT_PREP = True   # False: every weight is prepared by a launch of its own when a projection first needs it
+
+
 def _weight_operands(weight):
-    """nn.Linear weight [N, K] -> zero-padded bf16 [ceil64(N), ceil64(K)] and its transpose (one launch).
-    Without autograd (inference) the pair is kept per parameter and reused until the parameter is
-    modified in place or replaced; with autograd the weights change every step and nothing is kept."""
+    """nn.Linear weight [N, K] -> zero-padded bf16 [ceil64(N), ceil64(K)] and its transpose.  For a parameter (or a
+    whole-tensor view of one: a 1x1 convolution's weight as a matrix) the pair is kept and reused until the
+    parameter is modified in place (its version counter moves: an optimizer step, a load_state_dict) or replaced.
+    When a kept pair has gone stale, every other kept pair whose parameter has moved on is refreshed in the same
+    launch (dsw_weight_prep_batch): after an optimizer step the first projection of the next forward prepares the
+    whole network's weights, 48 per launch, instead of one launch per projection.  Under stream capture nothing is
+    kept or reused (see _may_keep_operands); a weight computed inside autograd (not a leaf) is prepared per call."""
     N, Kd = weight.shape
-    caching = _may_keep_operands()
-    if caching:
-        e = _PREP_CACHE.get(id(weight))
-        if e is not None and e[0]() is weight and e[1] == weight._version and e[2] == weight.data_ptr():
+    owner = weight._base if weight._base is not None else weight
+    keep = (owner.is_leaf and owner.numel() == N * Kd and owner.data_ptr() == weight.data_ptr() and weight.is_contiguous()
+            and not (weight.is_cuda and torch.cuda.is_current_stream_capturing()))
+    key = (id(owner), N, Kd)
+    e = _PREP_CACHE.get(key) if keep else None
+    if e is not None and e[0]() is owner and e[2] == owner.data_ptr():
+        if e[1] == owner._version:
+            return e[3], e[4]
+        if BATCH_WEIGHT_PREP:
+            _refresh_stale_operands(weight.device)
+            e = _PREP_CACHE[key]
             return e[3], e[4]
     Np, Kp = _ceil_pad(N), _ceil_pad(Kd)
     w = weight.detach()
     w_p = torch.empty(Np, Kp, dtype=torch.bfloat16, device=w.device)
     w_pt = torch.empty(Kp, Np, dtype=torch.bfloat16, device=w.device)
     call("dsw_weight_prep", ptr(w), dtype_code(w.dtype), N, Kd, ptr(w_p), ptr(w_pt), stream(w.device))
-    if caching:
+    if keep:
         if len(_PREP_CACHE) > 4096:
             _PREP_CACHE.clear()
-        _PREP_CACHE[id(weight)] = (weakref.ref(weight), weight._version, weight.data_ptr(), w_p, w_pt)
+        _PREP_CACHE[key] = (weakref.ref(owner), owner._version, owner.data_ptr(), w_p, w_pt)
     return w_p, w_pt
+
+
+def _refresh_stale_operands(device):
+    """New operand pairs for every kept Linear weight on `device` whose parameter has been modified since its pair was
+    made.  The pairs are new tensors, not the old ones overwritten: a backward pass that is still to run may hold
+    the old transpose (saved by the forward that used it)."""
+    stale = []
+    for key, e in list(_PREP_CACHE.items()):
+        if len(key) != 3:      # other kinds of kept operands (3x3 convolutions)
+            continue
+        w = e[0]()
+        if w is None or e[2] != w.data_ptr():
+            del _PREP_CACHE[key]
+        elif w.device == device and e[1] != w._version and w.dtype in (torch.float32, torch.bfloat16):
+            stale.append((key, w))
+    if not stale:
+        return
+    n = len(stale)
+    pairs = []
+    for (_, N, Kd), _w in stale:
+        Np, Kp = _ceil_pad(N), _ceil_pad(Kd)
+        pairs.append((torch.empty(Np, Kp, dtype=torch.bfloat16, device=device), torch.empty(Kp, Np, dtype=torch.bfloat16, device=device)))
+    vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+    tabs = (vp(*[w.data_ptr() for _, w in stale]), ip(*[dtype_code(w.dtype) for _, w in stale]), ip(*[k[1] for k, _ in stale]),
+            ip(*[k[2] for k, _ in stale]), vp(*[a.data_ptr() for a, _ in pairs]), vp(*[b.data_ptr() for _, b in pairs]))
+    call("dsw_weight_prep_batch", n, *[ctypes.cast(t, ctypes.c_void_p) for t in tabs], stream(device))
+    for (key, w), (a, b) in zip(stale, pairs):
+        _PREP_CACHE[key] = (weakref.ref(w), w._version, w.data_ptr(), a, b)
 
 
 def _mfma_operand(t2):
