@@ -1551,7 +1551,7 @@ def rms_norm(x, norm, for_projection=False, sink=None, dense_act=False):
     trip) and returned as a view of the first C columns.  dense_act: under bf16 autocast the result is a dense
     bf16 tensor (for a consumer whose kernels round their input to bf16 anyway and want NHWC rows of C)."""
     if not _norm_kernel_ok(x, norm):
-        assert sink is None and pending is None, "a gradient sink needs the kernel path (see prenorm_sink)"
+        assert sink is None, "a gradient sink needs the kernel path (see prenorm_sink)"
         return norm(x)
     eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
     act = autocast_dtype(x.dtype)
