@@ -324,6 +324,19 @@ int dsw_ema_update(int n, void *const *ema, const void *const *cur, const long l
 int dsw_linear_gated_silu(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                           const float *bias, void *out, long long ldo, void *stream);
 
+/* dsw_linear / dsw_linear_gated_silu with the nn.RMSNorm in front of them folded in (DSwinT_arch.py:343-345 applied
+ * at :355 and :357: wmsa(ln1(x)), mlp1(ln2(x))), inference: c = (a W'^T) / sqrt(mean_k a^2 + eps) + bias per row,
+ * where W' = W diag(norm weight) has been prepared by the caller in place of W.  The mean runs over the K values
+ * of the row as they lie in memory (fp32 for the fp32 stream), the product over their bf16 roundings: the result
+ * differs from norm-then-project by bf16 roundings only (the norm's output is rounded to bf16 there, the scaled
+ * weight here).  K <= 192; other arguments as for the plain entry points; no a_copy, no live-row counter. */
+int dsw_linear_rmsnorm(const void *a, int a_dtype, long long lda, long long M, int K, float eps, const void *w_p,
+                       int wrows, int ldw, const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols,
+                       void *stream);
+int dsw_linear_rmsnorm_gated_silu(const void *a, int a_dtype, long long lda, long long M, int K, float eps,
+                                  const void *w_p, int wrows, int ldw, const float *bias, void *out, long long ldo,
+                                  void *stream);
+
 /* The first projection of msft's MLP with its activation (msft_arch.py:22-25 applied at :33: Linear, then
  * nn.GELU() in its erf form): out = gelu(a W^T + bias) in one launch, bf16.  The pre-activation is rounded to bf16
  * first - what dsw_linear would have stored - so out has the bits of dsw_linear followed by dsw_gelu_fwd.

@@ -295,7 +295,11 @@ def test_default_width_dswt_bf16_every_attention_layer_against_the_oracle(cuda0)
         assert res is not None, "the fused inference path hands the residual to the branch"
         stream, rz = res
         sel = getattr(mod, "last_selection", None)
-        records.append((mod, args[0].detach().float().cpu(), stream.detach().float().cpu(), float(rz), out.detach().float().cpu(),
+        xin = args[0].detach().float()
+        pre = kwargs.get("prenorm")
+        if pre is not None:        # the norm in front of the module runs inside its first kernel: the oracle gets norm(x) in fp32
+            xin = torch.nn.functional.rms_norm(xin, pre.normalized_shape, pre.weight.detach().float(), pre.eps)
+        records.append((mod, xin.cpu(), stream.detach().float().cpu(), float(rz), out.detach().float().cpu(),
                         None if sel is None else sel))
     hooks = [sub.register_forward_hook(hook, with_kwargs=True) for sub in net.modules()
              if isinstance(sub, (dswin.WindowedMSA, dswin.DeformableSparseWindowAttention))]

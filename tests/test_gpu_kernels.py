@@ -706,6 +706,40 @@ def test_gelu_rows(cuda0, dtype, M, C, padded_in, pad_out):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,C,N", [(1000, 180, 540), (515, 96, 288), (4099, 192, 64), (300, 60, 180)])
+def test_linear_with_the_rmsnorm_inside(cuda0, T, C, N):
+    """lin(norm(x)) for nn.RMSNorm + nn.Linear (DSwinT_arch.py:355 with :334) in one kernel, inference under bf16
+    autocast: against the fp32 modules within the bf16 bar, and against the two-kernel path (norm to bf16, then the
+    projection) within a few bf16 roundings; the same for the gated first projection of the MLP (:357 with :69)."""
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(T + C)
+    norm = torch.nn.RMSNorm(C).to(cuda0)
+    lin = torch.nn.Linear(C, N).to(cuda0)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.3 * torch.randn(C, device=cuda0))
+    x = torch.randn(3, T, C, device=cuda0) * torch.rand(3, T, 1, device=cuda0) * 4     # rows of very different norms
+    ref = lin(norm(x))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = K.linear_prenorm(x, norm, lin, pad_out=True)
+        y2 = K.linear(K.rms_norm(x, norm, for_projection=True), lin, pad_out=True)
+        assert K.linear_prenorm(x.double(), norm, lin) is None
+    assert y is not None and y.dtype == torch.bfloat16 and y.shape == ref.shape
+    assert rel_err(y, ref) < 1e-2 and rel_err(y, y2) < 6e-3
+    if N % 64:
+        whole = torch.as_strided(y, (3 * T, _ceil64(N)), (_ceil64(N), 1), y.storage_offset())
+        assert whole[:, N:].abs().max().item() == 0
+    H = 2 * C                                   # the MLP's hidden width (ffn_scale 2): 360, 192, 384, 120
+    if (H + 31) // 32 * 32 == _ceil64(H):
+        gate, cont = torch.nn.Linear(C, H).to(cuda0), torch.nn.Linear(C, H).to(cuda0)
+        iw, ib = K.interleave_gate_content(gate.weight, cont.weight, gate.bias, cont.bias)
+        xn = norm(x)
+        ref_g = torch.nn.functional.silu(gate(xn)) * cont(xn)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            g = K.linear_gated_silu(x, iw, ib, H, prenorm=norm)
+        assert g is not None and g.shape == ref_g.shape and rel_err(g, ref_g) < 1e-2
+
+
+@pytest.mark.gpu
 def test_weight_prep_batch_and_the_kept_operands(cuda0):
     """dsw_weight_prep_batch against dsw_weight_prep, weight by weight (more weights than one launch holds, both
     dtypes), and the bookkeeping above it: a kept operand pair is reused while its parameter is unchanged, and the

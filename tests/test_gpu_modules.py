@@ -651,6 +651,52 @@ def test_vitblock_inference_fuses_the_residual_into_the_projections(cuda0):
 
 
 @pytest.mark.gpu
+def test_inference_with_the_rmsnorm_inside_the_projections(cuda0):
+    """Without autograd the DSWT block's norms in front of WindowedMSA and the MLP (DSwinT_arch.py:355, :357) run inside
+    the kernels of the q|k|v projection and of fc1: the network's output stays within a few bf16 roundings of the run
+    with the norms as passes of their own, and the folded entry points are the ones that ran."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd import models
+    torch.manual_seed(0)
+    cfg = dict(models.DSWT_DEFAULT)
+    cfg.update(n_blocks=1, n_sub_blocks=2)
+    model = models.DSWTransformer(**cfg)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "rezero" in n:
+                p.fill_(0.5)
+            if n.endswith(("ln1.weight", "ln2.weight", "ln3.weight")):
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+    model = model.to(cuda0).eval()
+    x = torch.rand(2, 3, 64, 64).to(cuda0) * 2 - 1
+    calls = []
+    real_call = K.call
+
+    def spy(name, *args):
+        calls.append(name)
+        return real_call(name, *args)
+
+    outs = {}
+    for fold in (True, False):
+        K.FOLD_RMSNORM = fold
+        calls.clear()
+        K.call = spy
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                outs[fold] = model(x).float()
+        finally:
+            K.call = real_call
+            K.FOLD_RMSNORM = True
+        if fold:
+            assert calls.count("dsw_linear_rmsnorm") == 2 and calls.count("dsw_linear_rmsnorm_gated_silu") == 2
+            assert calls.count("dsw_rmsnorm_fwd") == 2               # DS-MSA's norm: its first kernels are convolutions
+        else:
+            assert "dsw_linear_rmsnorm" not in calls and calls.count("dsw_rmsnorm_fwd") == 6
+    assert torch.isfinite(outs[True]).all()
+    assert rel_err(outs[True], outs[False]) < 5e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("window", [8, 16])
 def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window):
     """Without autograd the DSWT attention modules project q|k|v inside the attention kernel
@@ -679,10 +725,11 @@ def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window
         return real_call(name, *args)
 
     outs = {}
-    grid_d30 = K.FUSE_PROJECTION_GRID_D30
+    grid_d30, fold = K.FUSE_PROJECTION_GRID_D30, K.FOLD_RMSNORM
     for fuse in (True, False):
         K.FUSE_PROJECTION = K.FUSE_GATED_SILU = fuse
         K.FUSE_PROJECTION_GRID_D30 = True   # off by default: at 16x16 windows of head dim 30 the separate kernels are faster
+        K.FOLD_RMSNORM = False              # the norm as a pass of its own on both sides (its fold into the projections has its own test)
         calls.clear()
         K.call = spy
         try:
@@ -691,7 +738,7 @@ def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window
         finally:
             K.call = real_call
             K.FUSE_PROJECTION = K.FUSE_GATED_SILU = True
-            K.FUSE_PROJECTION_GRID_D30 = grid_d30
+            K.FUSE_PROJECTION_GRID_D30, K.FOLD_RMSNORM = grid_d30, fold
         n_fused = calls.count("dsw_win_attn_proj_fwd")
         assert (n_fused > 0 and "dsw_win_attn_fwd" not in calls) if fuse else (n_fused == 0 and "dsw_win_attn_fwd" in calls)
         n_gate = calls.count("dsw_linear_gated_silu")               # fc1 of the MLP with the gate in its epilogue

@@ -67,6 +67,13 @@ template <> struct a_piece<float> {
         v.w = h ? pack_bf16(__uint_as_float(hi.z), __uint_as_float(hi.w)) : 0u;
         return v;
     }
+    // sum of the squares of the elements in front of column K (the fp32 values as they are in memory)
+    __device__ __forceinline__ float sumsq(int k, int K) const {
+        const bool l = k + 4 <= K, h = k + 8 <= K;
+        const float a0 = __uint_as_float(lo.x), a1 = __uint_as_float(lo.y), a2 = __uint_as_float(lo.z), a3 = __uint_as_float(lo.w);
+        const float b0 = __uint_as_float(hi.x), b1 = __uint_as_float(hi.y), b2 = __uint_as_float(hi.z), b3 = __uint_as_float(hi.w);
+        return (l ? a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 : 0.f) + (h ? b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 : 0.f);
+    }
 };
 template <> struct a_piece<bf16_t> {
     uint4 v;
@@ -83,6 +90,17 @@ template <> struct a_piece<bf16_t> {
     __device__ __forceinline__ uint4 pack(int k, int K) const {
         const bool l = k + 4 <= K, h = k + 8 <= K;
         return make_uint4(l ? v.x : 0u, l ? v.y : 0u, h ? v.z : 0u, h ? v.w : 0u);
+    }
+    __device__ __forceinline__ float sumsq(int k, int K) const {
+        const bool l = k + 4 <= K, h = k + 8 <= K;
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = __uint_as_float(u[q] << 16), b = __uint_as_float(u[q] & 0xffff0000u);
+            s += (q < 2 ? l : h) ? a * a + b * b : 0.f;
+        }
+        return s;
     }
 };
 
@@ -132,7 +150,11 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
     long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
-    int convH, int convW, int gated, const int *__restrict__ live_units, int unit_rows, bf16_t *__restrict__ aux, long long ld_aux) {
+    int convH, int convW, int gated, const int *__restrict__ live_units, int unit_rows, bf16_t *__restrict__ aux, long long ld_aux,
+    float norm_eps) {
+    // norm_eps >= 0 (one slab only): the rows of A are RMS-normalised on the way (nn.RMSNorm in front of the projection,
+    // DSwinT_arch.py:355 / :357 with :343-345): C = (A W^T) / sqrt(mean_k A^2 + eps) + bias per row, the norm's weight
+    // having been multiplied into W's columns by the caller.  The mean runs over the fp32 values as they are loaded.
     // gated (the epilogue of a bf16 result): 1 = gated SiLU; 2 = GELU, the pre-activation values going to aux when it is
     // given; 3 = the result times GELU's slope at aux's values (the backward of 2 on the way out of the input gradient)
     using cfg = LnCfg<KS>;
@@ -143,6 +165,8 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     bf16_t *As = reinterpret_cast<bf16_t *>(smem);
     bf16_t *Bs = As + LN_BM * ALS;
     float *biasl = reinterpret_cast<float *>(Bs + LN_CN * LS);  // bias of this block's columns, zero where there is none
+    float *rstdl = biasl + chunks_per_block * LN_CN;            // 1 / rms of the block's rows (norm_eps >= 0)
+    const bool prenorm = !PERSIST && AH == 1 && norm_eps >= 0.f;  // the single-slab kernels of K <= 192 only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     LN_STAMP(0);
@@ -230,6 +254,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
         constexpr int SROW = 144;             // staging row stride in bytes
         unsigned char *stg = reinterpret_cast<unsigned char *>(As + wave * 32 * ALS);
         const int nb = (nc0 + chunk) * LN_CN;
+        const float rn = prenorm ? rstdl[wave * 32 + l31] : 1.f;  // a lane's accumulators all belong to one row of A
         // the bias comes from LDS (staged once per block)
         float4 bv[2][4];
 #pragma unroll
@@ -250,8 +275,8 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                     for (int j = 0; j < 4; ++j) {
                         const float bg = j == 0 ? bv[0][g].x : j == 1 ? bv[0][g].y : j == 2 ? bv[0][g].z : bv[0][g].w;
                         const float bc = j == 0 ? bv[1][g].x : j == 1 ? bv[1][g].y : j == 2 ? bv[1][g].z : bv[1][g].w;
-                        const float gate = bf16_to_f32(f32_to_bf16(a[0][4 * g + j] + bg));
-                        const float cont = bf16_to_f32(f32_to_bf16(a[1][4 * g + j] + bc));
+                        const float gate = bf16_to_f32(f32_to_bf16(a[0][4 * g + j] * rn + bg));
+                        const float cont = bf16_to_f32(f32_to_bf16(a[1][4 * g + j] * rn + bc));
                         y[j] = gated_silu_value(gate, cont);
                     }
                     io<bf16_t>::st4(reinterpret_cast<bf16_t *>(stg + l31 * SROW) + 8 * g + 4 * hh, make_float4(y[0], y[1], y[2], y[3]));
@@ -298,8 +323,8 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 const int t = ps * TPP + tt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 v = make_float4(a[t][4 * g] + bv[t][g].x, a[t][4 * g + 1] + bv[t][g].y, a[t][4 * g + 2] + bv[t][g].z,
-                                                 a[t][4 * g + 3] + bv[t][g].w);
+                    const float4 v = make_float4(a[t][4 * g] * rn + bv[t][g].x, a[t][4 * g + 1] * rn + bv[t][g].y, a[t][4 * g + 2] * rn + bv[t][g].z,
+                                                 a[t][4 * g + 3] * rn + bv[t][g].w);
                     // bf16: a lane stores 8 bytes, and the rows 8 apart that one store instruction's 16-lane groups hold
                     // are 288 dwords apart - the same banks.  Rows 8-15 and 24-31 therefore keep the two halves of
                     // every 16-byte piece swapped (the reader below swaps them back in registers, for free: which
@@ -391,6 +416,21 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                         ap[h][p * (AW / 64) + j].load(rs_a, a_off[p] + (h * AW + j * 64) * (unsigned)sizeof(TA), soff, half16);
             if (slab == 0) load_b(0, 0);
             if (slab == 0) LN_STAMP(1);
+            if (prenorm) {
+                // a row's columns lie with 8 neighbouring lanes (all halves and column groups of the slab)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int h = 0; h < AH; ++h)
+#pragma unroll
+                        for (int j = 0; j < AW / 64; ++j) ss += ap[h][p * (AW / 64) + j].sumsq(h * AW + j * 64 + scol, K);
+                    ss += __shfl_xor(ss, 1, 64);
+                    ss += __shfl_xor(ss, 2, 64);
+                    ss += __shfl_xor(ss, 4, 64);
+                    if ((tid & 7) == 0) rstdl[p * 32 + srow] = rsqrtf(ss / (float)K + norm_eps);
+                }
+            }
 #pragma unroll
             for (int h = 0; h < AH; ++h) {
                 lds_barrier();  // the previous reads of As / Bs are over
@@ -704,7 +744,7 @@ template <typename TA, typename TC, int KS>
 int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
                   void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, const float *resid, long long ld_resid,
                   const float *rscale, int convH, int convW, int gated, const int *live_units, int unit_rows, hipStream_t st,
-                  void *aux = nullptr, long long ld_aux = 0) {
+                  void *aux = nullptr, long long ld_aux = 0, float norm_eps = -1.f) {
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
@@ -719,7 +759,7 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
         cpb = (total + gy - 1) / gy;
     }
     const dim3 grid(mt, (total + cpb - 1) / cpb);
-    const size_t lds = cfg::LDS + (size_t)cpb * LN_CN * sizeof(float);
+    const size_t lds = cfg::LDS + ((size_t)cpb * LN_CN + LN_BM) * sizeof(float);
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "dsw_linear: %d output columns per block need %zu bytes of LDS", cpb * LN_CN, lds);
     int rc;
     if (nslab > 1) {
@@ -729,13 +769,13 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
             auto kern = linear_nt_kernel<TA, TC, KS, NACC>;
             if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
             hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                               bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows, (bf16_t *)aux, ld_aux);
+                               bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows, (bf16_t *)aux, ld_aux, norm_eps);
         }
     } else {
         auto kern = linear_nt_kernel<TA, TC, KS, 0>;
         if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows, (bf16_t *)aux, ld_aux);
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows, (bf16_t *)aux, ld_aux, norm_eps);
     }
     return check_launch("linear_nt_kernel");
 }
@@ -792,7 +832,7 @@ extern "C" int dsw_weight_prep_batch(int n, const void *const *w, const int *w_d
 static int linear_impl(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                        const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
                        long long lda_copy, const float *resid, long long ld_resid, const float *rscale, void *stream, int gated = 0,
-                       const int *live_units = nullptr, int unit_rows = 0, void *aux = nullptr, long long ld_aux = 0) {
+                       const int *live_units = nullptr, int unit_rows = 0, void *aux = nullptr, long long ld_aux = 0, float norm_eps = -1.f) {
     if (M <= 0 || M > 0x7fffff00LL || K <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
     DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
@@ -826,6 +866,8 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
     static const bool no256 = getenv("DSW_LINEAR_NO256") != nullptr;   // experiments: the two-slab path for K of 193..256
     const int KS = Kp % 192 == 0 ? 192 : (Kp == 256 && !no256) ? 256 : (Kp % 128 == 0 || Kp > 192 ? 128 : 64);
     const int nslab = (Kp + KS - 1) / KS;
+    if (norm_eps >= 0.f && (nslab != 1 || KS > 192 || live_units != nullptr))
+        return fail(DSW_EUNSUPPORTED, "dsw_linear_rmsnorm: the normalised rows must fit one slab of K <= 192, no live-row counter (K=%d)", K);
     if (gated >= 2 && (c_dtype != DSW_BF16 || ncols % 8 || ldc % 8 || resid != nullptr || accumulate || live_units != nullptr ||
                        (gated == 3 && aux == nullptr) || (aux != nullptr && (ld_aux < ncols || ld_aux % 8 || ((uintptr_t)aux & 15)))))
         return fail(DSW_EUNSUPPORTED, "dsw_linear_gelu: needs a bf16 result, ncols and the row strides multiples of 8, 16-byte aligned bases "
@@ -839,7 +881,7 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
     int rc = DSW_OK;
 #define DSW_LINEAR_KS(KSV)                                                                                                     \
     DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
-        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, live_units, unit_rows, st, aux, ld_aux); \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, live_units, unit_rows, st, aux, ld_aux, norm_eps); \
     }))
     if (KS == 192) DSW_LINEAR_KS(192);
     else if (KS == 256) DSW_LINEAR_KS(256);
@@ -868,6 +910,20 @@ extern "C" int dsw_linear_gated_silu(const void *a, int a_dtype, long long lda, 
                                      const float *bias, void *out, long long ldo, void *stream) {
     return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, wrows, out, DSW_BF16, ldo, wrows, 0, nullptr, 0, nullptr, 0, nullptr,
                        stream, 1);
+}
+
+extern "C" int dsw_linear_rmsnorm(const void *a, int a_dtype, long long lda, long long M, int K, float eps, const void *w_p, int wrows, int ldw,
+                                  const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, void *stream) {
+    if (!(eps >= 0.f)) return fail(DSW_EINVAL, "dsw_linear_rmsnorm: eps=%g", (double)eps);
+    return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, N, c, c_dtype, ldc, ncols, 0, nullptr, 0, nullptr, 0, nullptr, stream, 0,
+                       nullptr, 0, nullptr, 0, eps);
+}
+
+extern "C" int dsw_linear_rmsnorm_gated_silu(const void *a, int a_dtype, long long lda, long long M, int K, float eps, const void *w_p, int wrows,
+                                             int ldw, const float *bias, void *out, long long ldo, void *stream) {
+    if (!(eps >= 0.f)) return fail(DSW_EINVAL, "dsw_linear_rmsnorm_gated_silu: eps=%g", (double)eps);
+    return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, wrows, out, DSW_BF16, ldo, wrows, 0, nullptr, 0, nullptr, 0, nullptr,
+                       stream, 1, nullptr, 0, nullptr, 0, eps);
 }
 
 extern "C" int dsw_linear_gelu(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,

@@ -106,13 +106,21 @@ class WindowedMSA(WindowedAttention):
         # the tensor is not contiguous.  False: always return a contiguous tensor.
         self.padded_output = True
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, prenorm=None):
         """residual = (stream, r): returns stream + r * attention(x) - the caller's residual (DSwinT_arch.py:355) -
         instead of attention(x), with the residual taken inside out_proj's kernel where that is possible: without
         autograd for any r (ReZero), with autograd for a plain residual (r None or 1.0).  When the stream is x itself
         (y = x + attention(x)), its gradient dy is not added to the projection's input gradient by a pass of its own:
-        the kernel that writes that gradient reads it as one more operand (functional.PendingGrad)."""
+        the kernel that writes that gradient reads it as one more operand (functional.PendingGrad).
+        prenorm (inference): the nn.RMSNorm the caller applies in front of the module (DSwinT_arch.py:355); x is then
+        the stream itself, and the norm runs inside the q|k|v projection's kernel where that is possible."""
         B, H, W, C = x.shape
+        qkv = None
+        if prenorm is not None:
+            if not (K.FUSE_PROJECTION_GRID_D30 or not (self.win == 16 and C // self.num_heads == 30)) or (self.training and self.attn_drop):
+                qkv = K.linear_prenorm(x, prenorm, self.qkv, pad_out=True)
+            if qkv is None:
+                x = K.rms_norm(x, prenorm, for_projection=True)
         # attention dropout as F.dropout(..., training=self.training) applies it (DSwinT_arch.py:172), inside the kernels
         drop_p = self.attn_drop if self.training else 0.0
         plain = residual is not None and (residual[1] is None or (isinstance(residual[1], (int, float)) and residual[1] == 1))
@@ -120,11 +128,12 @@ class WindowedMSA(WindowedAttention):
                                    and x.dtype == torch.float32 and x.is_contiguous()) else None
         z = None
         # without autograd: projection and attention in one kernel, q|k|v never written - where that is the faster form
-        if drop_p == 0.0 and (K.FUSE_PROJECTION_GRID_D30 or not (self.win == 16 and C // self.num_heads == 30)):
+        if qkv is None and drop_p == 0.0 and (K.FUSE_PROJECTION_GRID_D30 or not (self.win == 16 and C // self.num_heads == 30)):
             z = K.projected_window_attention(x, self.qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED,
                                              grid=(B, H, W), pad_out=True)
         if z is None:
-            qkv = K.linear(x, self.qkv, pad_out=True, grad_extra=pend)
+            if qkv is None:
+                qkv = K.linear(x, self.qkv, pad_out=True, grad_extra=pend)
             z = K.window_attention(qkv, self.pe.table(), self.win, self.num_heads, QKV_INTERLEAVED, grid=(B, H, W),
                                    pad_out=True, dropout_p=drop_p, dropout_seed=self.dropout_seed)
         if plain:

@@ -1457,15 +1457,75 @@ def interleave_gate_content(gate_w, content_w, gate_b, content_b):
     return w.reshape(2 * Hp, Kd), b.reshape(2 * Hp)
 
 
-def linear_gated_silu(x, inter_w, inter_b, H):
+FOLD_RMSNORM = True   # False: linear_prenorm declines and linear_gated_silu declines a prenorm (the norm runs as a pass of its own)
+_FOLD_CACHE = {}
+
+
+def _folded_weight(weight, norm_weight):
+    """weight [N, K] with the RMSNorm weight [K] multiplied into its columns (fp32), kept until either changes"""
+    key = (id(weight), id(norm_weight))
+    e = _FOLD_CACHE.get(key)
+    if (e is not None and e[0]() is weight and e[1]() is norm_weight and e[2] == (weight._version, norm_weight._version,
+                                                                                weight.data_ptr(), norm_weight.data_ptr())):
+        return e[3]
+    f = (weight.detach().float() * norm_weight.detach().float()[None, :]).contiguous()
+    if not torch.cuda.is_current_stream_capturing():
+        if len(_FOLD_CACHE) > 4096:
+            _FOLD_CACHE.clear()
+        _FOLD_CACHE[key] = (weakref.ref(weight), weakref.ref(norm_weight),
+                            (weight._version, norm_weight._version, weight.data_ptr(), norm_weight.data_ptr()), f)
+    return f
+
+
+def _prenorm_ok(x, norm, Kd):
+    return (FOLD_RMSNORM and not torch.is_grad_enabled() and autocast_dtype(None) == torch.bfloat16 and _norm_kernel_ok(x, norm)
+            and x.shape[-1] == Kd and Kd <= 192 and x.numel() > 0 and x.data_ptr() % 16 == 0)
+
+
+def linear_prenorm(x, norm, lin, pad_out=False):
+    """lin(norm(x)) for an nn.RMSNorm `norm` and an nn.Linear `lin` in one kernel (dsw_linear_rmsnorm): the rows of the
+    fp32 stream are normalised as the projection loads them, the norm's weight sits in the prepared weight - no pass
+    over the stream for the norm, no normalised copy.  Inference under bf16 autocast, K <= 192; None when the call
+    is not one the kernel takes (the caller runs rms_norm() and linear())."""
+    weight = lin.weight
+    N, Kd = weight.shape
+    if not (_prenorm_ok(x, norm, Kd) and N % 4 == 0 and weight.is_contiguous() and weight.dtype in (torch.float32, torch.bfloat16)):
+        return None
+    a2 = x.reshape(-1, Kd)
+    T = a2.shape[0]
+    eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
+    w_p, _ = _weight_operands(_folded_weight(weight, norm.weight))
+    b32 = None if lin.bias is None else lin.bias.detach().float().contiguous()
+    Nout = _ceil_pad(N) if pad_out else N
+    out = _mark_padded(torch.empty(T, Nout, dtype=torch.bfloat16, device=x.device))
+    call("dsw_linear_rmsnorm", ptr(a2), dtype_code(a2.dtype), Kd, T, Kd, _c_float(eps), ptr(w_p), w_p.shape[0], w_p.shape[1],
+         None if b32 is None else ptr(b32), N, ptr(out), dtype_code(out.dtype), Nout, Nout, stream(x.device))
+    return out[:, :N].view(x.shape[:-1] + (N,))
+
+
+def linear_gated_silu(x, inter_w, inter_b, H, prenorm=None):
     """silu(fc1_gate(x)) * fc1_content(x) (DSwinT_arch.py:69) in the projection's own epilogue
     (dsw_linear_gated_silu): the [tokens, 2H] pre-activations are never written.  inter_w / inter_b from
     interleave_gate_content.  Inference under bf16 autocast only, K <= 192; returns the result as a view of the
     first H columns of zero-padded bf16 rows, or None when the call is not one the kernel takes (the caller then
-    composes linear() and gated_silu()).  Same bits as that composition."""
+    composes linear() and gated_silu()).  Same bits as that composition.  prenorm: an nn.RMSNorm to apply to x
+    first, inside the same kernel (see linear_prenorm); None is returned when that is not possible."""
     if not FUSE_GATED_SILU or torch.is_grad_enabled() or autocast_dtype(None) != torch.bfloat16:
         return None
     N2, Kd = inter_w.shape
+    if prenorm is not None:
+        Hp = N2 // 2
+        if not (_prenorm_ok(x, prenorm, Kd) and N2 % 64 == 0 and Hp == _ceil_pad(H) and inter_w.is_contiguous()
+                and inter_w.dtype in (torch.float32, torch.bfloat16)):
+            return None
+        a2 = x.reshape(-1, Kd)
+        T = a2.shape[0]
+        eps = prenorm.eps if prenorm.eps is not None else torch.finfo(x.dtype).eps
+        w_p, _ = _weight_operands(_folded_weight(inter_w, prenorm.weight))
+        out = _mark_padded(torch.empty(T, Hp, dtype=torch.bfloat16, device=x.device))
+        call("dsw_linear_rmsnorm_gated_silu", ptr(a2), dtype_code(a2.dtype), Kd, T, Kd, _c_float(eps), ptr(w_p), N2, w_p.shape[1],
+             ptr(inter_b), ptr(out), Hp, stream(x.device))
+        return out[:, :H].view(x.shape[:-1] + (H,))
     Hp = N2 // 2
     if not (x.is_cuda and Kd <= 192 and Kd % 4 == 0 and N2 % 64 == 0 and Hp == _ceil_pad(H) and inter_w.is_contiguous()
             and inter_w.dtype in (torch.float32, torch.bfloat16) and inter_w.data_ptr() % 16 == 0):

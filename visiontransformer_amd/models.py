@@ -85,14 +85,22 @@ class GatedMLP(nn.Module):
             object.__setattr__(self, "_kept_fc1_inter", kept)
         return kept[1]
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, prenorm=None):
         """residual = (stream, r), inference only: returns stream + r * mlp(x), the residual taken inside fc2's
-        kernel (the caller's ReZero residual, DSwinT_arch.py:357)."""
+        kernel (the caller's ReZero residual, DSwinT_arch.py:357).  prenorm (with residual): the nn.RMSNorm the caller
+        applies in front of the module; x is then the stream itself and the norm runs inside fc1's kernel where that
+        is possible."""
         if residual is not None:
             h = None
             Hd = self.fc1_gate.out_features
-            if K.FUSE_GATED_SILU and (self.fc1_gate.bias is None) == (self.fc1_content.bias is None) \
-                    and (Hd + 31) // 32 * 32 == (Hd + 63) // 64 * 64 and self.fc1_gate.in_features <= 192:
+            fused_ok = (K.FUSE_GATED_SILU and (self.fc1_gate.bias is None) == (self.fc1_content.bias is None)
+                        and (Hd + 31) // 32 * 32 == (Hd + 63) // 64 * 64 and self.fc1_gate.in_features <= 192)
+            if prenorm is not None:
+                if fused_ok:
+                    h = K.linear_gated_silu(x, *self._interleaved(), self.fc1_gate.out_features, prenorm=prenorm)
+                if h is None:
+                    x = K.rms_norm(x, prenorm, for_projection=True)
+            if h is None and fused_ok:
                 h = K.linear_gated_silu(x, *self._interleaved(), self.fc1_gate.out_features)   # fc1 and the gate in one kernel
             if h is None:
                 h = K.gated_silu(K.linear(x, self._stacked(), pad_out=True), pad_out=True)
@@ -139,7 +147,10 @@ class DSWTViTBlock(nn.Module):
                 # itself (no bf16 round trip of the branch, no residual pass)
                 # (DS-MSA's input in bf16: its convolutions and its gather round it to bf16 as their first step, and
                 # the map it writes back into is rounded to bf16 on its way into out_conv; half the bytes on every pass)
-                x = branch(K.rms_norm(x, norm, for_projection=proj, dense_act=DSMSA_BF16_INPUT and not proj), residual=(x, rz))
+                if proj:    # the norm inside the branch's first projection where its kernel takes it
+                    x = branch(x, residual=(x, rz), prenorm=norm)
+                else:
+                    x = branch(K.rms_norm(x, norm, dense_act=DSMSA_BF16_INPUT), residual=(x, rz))
                 continue
             sink = K.prenorm_sink(x, norm, rz)
             b = branch(K.rms_norm(x, norm, for_projection=proj, sink=sink))
