@@ -379,7 +379,7 @@ def dswt_flops_per_frame(cfg, H, W, pass_share=0.25):
 SR_LR = (540, 960)  # x4 -> 3840 x 2160
 
 
-def sr_inference(device, rank, world, grouped=False, iters=3):
+def sr_inference(device, rank, world, grouped=False, iters=5):
     """x4 super-resolution of one 960x540 frame by the DSWT default network (eval, bf16 autocast), the frame
     cut into the balanced tile plan for `world` ranks (one rank: the whole frame as one tile), every
     rank computing its tiles and one all-reduce assembling the image: output megapixels / s over
@@ -395,9 +395,11 @@ def sr_inference(device, rank, world, grouped=False, iters=3):
                 p_.fill_(0.2)    # the ReZero gates are zero at init: every block would add nothing to the stream and the tile check below would see the two ends only
     gen = torch.Generator(device=device).manual_seed(7)
     lr = torch.rand(1, 3, *SR_LR, device=device, generator=gen)
-    # the forward of a tile is captured once per tile shape (untimed, like building the model) and replayed: at
-    # 2+ ranks the tiles are small enough for ~1000 launches per forward to be bound by the host otherwise
-    runner = GraphedForward(model)
+    # at 2+ ranks the forward of a tile is captured once per tile shape (untimed, like building the model) and
+    # replayed: the tiles are small enough there for ~1000 launches per forward to be bound by the host otherwise.
+    # One rank takes the whole frame as one tile: its kernels are long, the host runs ahead of them, and the eager
+    # launches are the faster form (64.1 ms against 65.9 ms replayed, tools/infer_eager_vs_graph.py)
+    runner = GraphedForward(model) if world > 1 else model
 
     def run():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
@@ -405,7 +407,7 @@ def sr_inference(device, rank, world, grouped=False, iters=3):
 
     out = run()
     ok = bool(torch.isfinite(out).all())
-    # one 256 x 256 tile of the frame through the path timed below (fused kernels, replayed from a graph) against the
+    # one 256 x 256 tile of the frame through the path timed below (fused kernels; replayed from a graph at 2+ ranks) against the
     # same tile through the module-by-module path: separate projection and attention kernels, separate gate and
     # residual passes, stock convolutions at the two ends, DS-MSA reading its pass count on the host
     tile_err = None
@@ -429,6 +431,8 @@ def sr_inference(device, rank, world, grouped=False, iters=3):
                 for m_ in sd:
                     m_.static_inference = True
         tile_err = float((fused - plain).norm() / plain.norm())
+        del fused, plain
+    run()   # untimed: the tile check's other shapes have been through the caching allocator since the first frame
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
@@ -449,7 +453,7 @@ def sr_inference(device, rank, world, grouped=False, iters=3):
     flops = dswt_flops_per_frame(DSWT_DEFAULT, Hp, Wp)
     return {"metric": "x4 SR output megapixels/sec (fwd)", "value": out.shape[2] * out.shape[3] / 1e6 / dt, "unit": "MP/s",
             "n_gpus": world, "s_per_image": dt, "scaling": "strong", "dtype": "bf16", "data": "synthetic", "finite": ok,
-            "tile_check": {"rel_err_fused_graph_vs_module_by_module": tile_err,
+            "tile_check": {"rel_err_fused_vs_module_by_module": tile_err,
                            "tile": "256x256 LR at (128, 320) of the frame; both in bf16, ReZero gates at 0.2 (zero at init), window decisions may differ between the two"},
             "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, "flops_per_frame": flops,

@@ -418,10 +418,12 @@ def tiled_super_resolve(model, lr, scale, tile=256, halo=32, rank=0, world=1, re
         if i % world != rank:
             continue
         patch = _reflect_crop(lr, t.py0, t.py1, t.px0, t.px1)
-        sr = model(patch).to(out.dtype)
+        sr = model(patch)
         oy, ox = (t.y0 - t.py0) * scale, (t.x0 - t.px0) * scale
-        out[:, :, t.y0 * scale:t.y1 * scale, t.x0 * scale:t.x1 * scale] = \
-            sr[:, :, oy:oy + (t.y1 - t.y0) * scale, ox:ox + (t.x1 - t.x0) * scale]
+        # one pass from the network's output (bf16 under autocast, channels-last when the NHWC tail produced it) into
+        # the image: dtype, layout and crop in the same copy
+        out[:, :, t.y0 * scale:t.y1 * scale, t.x0 * scale:t.x1 * scale].copy_(
+            sr[:, :, oy:oy + (t.y1 - t.y0) * scale, ox:ox + (t.x1 - t.x0) * scale])
     if reduce and world > 1:
         dist.all_reduce(out, op=dist.ReduceOp.SUM)
     return out
