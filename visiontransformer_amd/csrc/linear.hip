@@ -145,13 +145,16 @@ __device__ unsigned long long g_linear_stamps[8 * 8192];
 #define LN_STAMP(i) ((void)0)
 #endif
 
-template <typename TA, typename TC, int KS, int NACC>
+// EXT: the instantiations that know the epilogues beyond bias / residual (gated SiLU, GELU and its slope) and the RMS
+// normalisation of A's rows; the plain ones carry none of their code or registers.
+template <typename TA, typename TC, int KS, int NACC, bool EXT>
 __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
     long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
-    int convH, int convW, int gated, const int *__restrict__ live_units, int unit_rows, bf16_t *__restrict__ aux, long long ld_aux,
+    int convH, int convW, int gated_arg, const int *__restrict__ live_units, int unit_rows, bf16_t *__restrict__ aux, long long ld_aux,
     float norm_eps) {
+    const int gated = EXT ? gated_arg : 0;
     // norm_eps >= 0 (one slab only): the rows of A are RMS-normalised on the way (nn.RMSNorm in front of the projection,
     // DSwinT_arch.py:355 / :357 with :343-345): C = (A W^T) / sqrt(mean_k A^2 + eps) + bias per row, the norm's weight
     // having been multiplied into W's columns by the caller.  The mean runs over the fp32 values as they are loaded.
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     bf16_t *Bs = As + LN_BM * ALS;
     float *biasl = reinterpret_cast<float *>(Bs + LN_CN * LS);  // bias of this block's columns, zero where there is none
     float *rstdl = biasl + chunks_per_block * LN_CN;            // 1 / rms of the block's rows (norm_eps >= 0)
-    const bool prenorm = !PERSIST && AH == 1 && norm_eps >= 0.f;  // the single-slab kernels of K <= 192 only
+    const bool prenorm = EXT && !PERSIST && AH == 1 && norm_eps >= 0.f;  // the single-slab kernels of K <= 192 only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     LN_STAMP(0);
@@ -762,20 +765,29 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
     const size_t lds = cfg::LDS + ((size_t)cpb * LN_CN + LN_BM) * sizeof(float);
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "dsw_linear: %d output columns per block need %zu bytes of LDS", cpb * LN_CN, lds);
     int rc;
+    const bool ext = gated != 0 || norm_eps >= 0.f;
+    auto go = [&](auto kern) -> int {
+        if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
+                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units,
+                           unit_rows, (bf16_t *)aux, ld_aux, norm_eps);
+        return DSW_OK;
+    };
+    if (ext && sizeof(TC) != 2) return fail(DSW_EUNSUPPORTED, "dsw_linear: the activation / normalisation forms write bf16");
     if (nslab > 1) {
         if constexpr (cfg::AH > 1) {
             return fail(DSW_EUNSUPPORTED, "dsw_linear: slabs of %d columns are single", KS);
+        } else if constexpr (sizeof(TC) == 2) {
+            if ((rc = ext ? go(linear_nt_kernel<TA, TC, KS, NACC, true>) : go(linear_nt_kernel<TA, TC, KS, NACC, false>))) return rc;
         } else {
-            auto kern = linear_nt_kernel<TA, TC, KS, NACC>;
-            if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
-            hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                               bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows, (bf16_t *)aux, ld_aux, norm_eps);
+            if ((rc = go(linear_nt_kernel<TA, TC, KS, NACC, false>))) return rc;
         }
     } else {
-        auto kern = linear_nt_kernel<TA, TC, KS, 0>;
-        if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
-                           bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units, unit_rows, (bf16_t *)aux, ld_aux, norm_eps);
+        if constexpr (sizeof(TC) == 2) {
+            if ((rc = ext ? go(linear_nt_kernel<TA, TC, KS, 0, true>) : go(linear_nt_kernel<TA, TC, KS, 0, false>))) return rc;
+        } else {
+            if ((rc = go(linear_nt_kernel<TA, TC, KS, 0, false>))) return rc;
+        }
     }
     return check_launch("linear_nt_kernel");
 }
