@@ -382,6 +382,9 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
 
     uint4 breg[cfg::B_PIECES];
     auto load_b = [&](int slab, int chunk) {
+#ifdef LN_NO_WLOAD
+        if (chunk > 0) return;   // timing experiment (wrong results): the weight chunks after the first are not read
+#endif
         const unsigned soff = (unsigned)(((size_t)(nc0 + chunk) * LN_CN * ldw + slab * KS) * sizeof(bf16_t));
 #pragma unroll
         for (int q = 0; q < 2; ++q)
