@@ -126,7 +126,11 @@ __device__ __forceinline__ void chunk_mfma(const bf16_t *brow, const bf16x8 (&af
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
+#ifdef LN_NO_MFMA   // timing experiment (wrong results): one MFMA per group of four
+                { if (j == 0 && t == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][2 * j + t], afr[2 * g + j], acc[t], 0, 0, 0); }
+#else
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][2 * j + t], afr[2 * g + j], acc[t], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
