@@ -59,8 +59,10 @@ const char *dswin_last_error_string(void);
  *   (equal logits: lower index first), cand_p [B,k] fp32 its probability; cand_pass [B,k] 0/1 =
  *   gate > 0.5;
  *   n_pass [1]; win_b / win_cell / win_h1 / win_w1 [B*k] for the passing windows in the
- *   reference's order (image ascending, then top-k rank), entries >= n_pass untouched;
- *   scores_delta / gates_delta [B*k] fp32 straight-through values ((1-p)+p and (1-g)+g);
+ *   reference's order (image ascending, then top-k rank), entries >= n_pass set to zero (a
+ *   harmless window for callers that run on all B*k slots without reading n_pass on the host);
+ *   scores_delta / gates_delta [B*k] fp32 straight-through values ((1-p)+p and (1-g)+g), zero
+ *   from n_pass on;
  *   cellmap [B,Hw,Ww] = compact window id of the window that started from that cell, or -1.
  */
 int dsw_select_fwd(const void *sd, const void *sig, int sd_dtype, const float *noise, float tau,

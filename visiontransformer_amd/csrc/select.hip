@@ -141,7 +141,19 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(
         }
         running += total;
     }
-    if (b == B - 1 && tid == 0) *n_pass = running;
+    if (b == B - 1) {
+        if (tid == 0) *n_pass = running;
+        // the slots behind the passing windows: a harmless window (image 0, corner (0, 0)) with zero straight-through
+        // values that the cell map never points to, for callers that run on all B * k slots without reading n_pass
+        for (int i = running + tid; i < B * k; i += SEL_THREADS) {
+            win_b[i] = 0;
+            win_cell[i] = 0;
+            win_h1[i] = 0;
+            win_w1[i] = 0;
+            scores_delta[i] = 0.f;
+            gates_delta[i] = 0.f;
+        }
+    }
 }
 
 // Backward: softmax Jacobian on the selected probabilities + gate pass-through.  grid B.

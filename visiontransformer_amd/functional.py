@@ -209,8 +209,8 @@ class _SelectStaticFn(torch.autograd.Function):
         cand_p = torch.empty(B, k, **f32)
         cand_pass = torch.empty(B, k, **i32)
         n_pass = torch.empty(1, **i32)
-        win = torch.zeros(4, B * k, **i32)
-        deltas = torch.zeros(2, B * k, **f32)
+        win = torch.empty(4, B * k, **i32)       # the kernel zeroes the slots behind the passing windows
+        deltas = torch.empty(2, B * k, **f32)
         cellmap = torch.empty(B, Hw, Ww, **i32)
         call("dsw_select_fwd", ptr(sd), None, dtype_code(sd.dtype), ptr(noise), _c_float(tau), B, Hw, Ww, k, w, H, W, ptr(probs),
              ptr(cand_idx), ptr(cand_p), ptr(cand_pass), ptr(n_pass), ptr(win[0]), ptr(win[1]), ptr(win[2]), ptr(win[3]),
@@ -1033,6 +1033,41 @@ def _may_keep_operands():
 
 
 BATCH_WEIGHT_PREP = True   # False: every weight is prepared by a launch of its own when a projection first needs it
+_WEIGHT_SCOPE = None
+
+
+@contextlib.contextmanager
+def weight_scope(module):
+    """Inside the context the prepared operands of every nn.Linear weight of `module` come from ONE preparation launch
+    made at entry (dsw_weight_prep_batch) instead of one launch per projection.  For code that cannot keep operands
+    between calls - a forward under stream capture, whose operands must be rebuilt inside the graph from the live
+    parameters: the pairs live as long as the context (and as what the forward saved for its backward)."""
+    global _WEIGHT_SCOPE
+    ws = []
+    for m in module.modules():
+        w = getattr(m, "weight", None) if isinstance(m, torch.nn.Linear) else None
+        if w is not None and w.is_cuda and w.dim() == 2 and w.is_contiguous() and w.dtype in (torch.float32, torch.bfloat16) \
+                and w._base is None and all(w is not o for o in ws):
+            ws.append(w)
+    scope = {}
+    by_dev = {}
+    for w in ws:
+        by_dev.setdefault(w.device, []).append(w)
+    for dev, group in by_dev.items():
+        n = len(group)
+        pairs = [(torch.empty(_ceil_pad(w.shape[0]), _ceil_pad(w.shape[1]), dtype=torch.bfloat16, device=dev),
+                  torch.empty(_ceil_pad(w.shape[1]), _ceil_pad(w.shape[0]), dtype=torch.bfloat16, device=dev)) for w in group]
+        vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+        tabs = (vp(*[w.data_ptr() for w in group]), ip(*[dtype_code(w.dtype) for w in group]), ip(*[w.shape[0] for w in group]),
+                ip(*[w.shape[1] for w in group]), vp(*[a.data_ptr() for a, _ in pairs]), vp(*[b.data_ptr() for _, b in pairs]))
+        call("dsw_weight_prep_batch", n, *[ctypes.cast(t, ctypes.c_void_p) for t in tabs], stream(dev))
+        for w, pr in zip(group, pairs):
+            scope[(id(w), w.shape[0], w.shape[1])] = (w, w._version, w.data_ptr()) + pr
+    prev, _WEIGHT_SCOPE = _WEIGHT_SCOPE, scope
+    try:
+        yield
+    finally:
+        _WEIGHT_SCOPE = prev
 
 
 def _weight_operands(weight):
@@ -1048,6 +1083,10 @@ def _weight_operands(weight):
     keep = (owner.is_leaf and owner.numel() == N * Kd and owner.data_ptr() == weight.data_ptr() and weight.is_contiguous()
             and not (weight.is_cuda and torch.cuda.is_current_stream_capturing()))
     key = (id(owner), N, Kd)
+    if _WEIGHT_SCOPE is not None:
+        e = _WEIGHT_SCOPE.get(key)
+        if e is not None and e[0] is owner and e[1] == owner._version and e[2] == owner.data_ptr():
+            return e[3], e[4]
     e = _PREP_CACHE.get(key) if keep else None
     if e is not None and e[0]() is owner and e[2] == owner.data_ptr():
         if e[1] == owner._version:

@@ -301,7 +301,7 @@ class _BlockwiseSumFn(torch.autograd.Function):
         return g.expand(ctx.shape), None     # as torch.sum's backward: a broadcast view, no pass over memory
 
 
-def graph_safe_sum(t, block=1024):
+def graph_safe_sum(t, block=4096):
     """Sum of all elements of t by reductions that each fit one workgroup (rows of `block` elements, then the row
     sums the same way), differentiable (the gradient is the broadcast of the incoming one, as for torch.sum).  For
     losses inside GraphedTrainStep: torch's reduction of a large tensor to one value runs over several workgroups
@@ -311,7 +311,7 @@ def graph_safe_sum(t, block=1024):
     return _BlockwiseSumFn.apply(t, block)
 
 
-def graph_safe_mean(t, block=1024):
+def graph_safe_mean(t, block=4096):
     """mean of all elements of t, see graph_safe_sum"""
     return graph_safe_sum(t, block) / t.numel()
 
@@ -397,7 +397,9 @@ class GraphedTrainStep:
             p.grad = None      # the captured backward then CREATES the gradients (in the graph's pool): no accumulate
         x.grad = None
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        from . import functional as K
+        # the operands of the projections are rebuilt inside the graph from the live parameters: one launch for all of them
+        with torch.cuda.graph(graph), K.weight_scope(self.model):
             static_loss = self._eager(x, *loss_args)
         grads = [(p, p.grad) for p in params if p.grad is not None]
         return graph, x, tuple(loss_args), static_loss, grads, x.grad
