@@ -149,15 +149,18 @@ __device__ unsigned long long g_linear_stamps[8 * 8192];
 #define LN_STAMP(i) ((void)0)
 #endif
 
-// EXT: the instantiations that know the epilogues beyond bias / residual (gated SiLU, GELU and its slope) and the RMS
-// normalisation of A's rows; the plain ones carry none of their code or registers.
-template <typename TA, typename TC, int KS, int NACC, bool EXT>
+// MODE 1 (EXT): the instantiations that know the epilogues beyond bias / residual (gated SiLU, GELU and its slope) and
+// the RMS normalisation of A's rows; the plain ones (MODE 0) carry none of their code or registers.
+// MODE 2 (CONV): the 3x3 convolution on NHWC pixels (several-slab kernels only), see the staging below.
+template <typename TA, typename TC, int KS, int NACC, int MODE>
 __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
     long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
     int convH, int convW, int gated_arg, const int *__restrict__ live_units, int unit_rows, bf16_t *__restrict__ aux, long long ld_aux,
     float norm_eps) {
+    constexpr bool EXT = MODE == 1, CONV = MODE == 2;
+    static_assert(!CONV || NACC > 0, "the convolution runs over several slabs");
     const int gated = EXT ? gated_arg : 0;
     // norm_eps >= 0 (one slab only): the rows of A are RMS-normalised on the way (nn.RMSNorm in front of the projection,
     // DSwinT_arch.py:355 / :357 with :343-345): C = (A W^T) / sqrt(mean_k A^2 + eps) + bias per row, the norm's weight
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     static_assert(AH == 1 || !PERSIST, "a slab that is staged in halves is the only slab");
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t *As = reinterpret_cast<bf16_t *>(smem);
-    bf16_t *Bs = As + LN_BM * ALS;
+    bf16_t *Bs = As + (LN_BM + (CONV ? 2 : 0)) * ALS;
     float *biasl = reinterpret_cast<float *>(Bs + LN_CN * LS);  // bias of this block's columns, zero where there is none
     float *rstdl = biasl + chunks_per_block * LN_CN;            // 1 / rms of the block's rows (norm_eps >= 0)
     const bool prenorm = EXT && !PERSIST && AH == 1 && norm_eps >= 0.f;  // the single-slab kernels of K <= 192 only
@@ -214,10 +217,13 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     // staging: 8 threads per row, 8 elements each = 64 columns; a slab is KS / 64 such column groups
     // (immediate offsets) over 4 (A: 128 rows) or 2 (weight chunk: 64 rows) row groups
     const int srow = tid >> 3, scol = (tid & 7) * 8;
-    // 3x3 convolution mode (convH > 0, several-slab kernel only): the rows are the pixels of NHWC images
-    // and slab s reads the rows shifted by tap s / kslabs, zero outside the image: the descriptor then
-    // covers the whole tensor, and a row that falls outside gets an offset beyond it (reads as zero).
-    const bool conv = PERSIST && convH > 0;
+    // 3x3 convolution (CONV): the rows are the pixels of NHWC images.  For every tap row dy and k slab the 130 pixels
+    // m0 - 1 .. m0 + 128 of the image row(s) shifted by dy go through LDS ONCE (rows of another image row, or outside
+    // the image, as zeros: the descriptor covers the whole tensor and such a row gets an offset beyond it), and the
+    // three taps dx = -1, 0, 1 read their MFMA operands from LDS rows r + dx: the input leaves L2 three times, not nine.
+    // A lane whose pixel sits on the image's left / right edge zeroes its operand for dx = -1 / +1 (the LDS row next
+    // to it belongs to the neighbouring image row).
+    constexpr bool conv = CONV;
     const __amdgpu_buffer_rsrc_t rs_a = conv ? make_rsrc(A, ((size_t)(M - 1) * lda + K) * sizeof(TA))
                                              : make_rsrc(A + (size_t)m0 * lda, ((size_t)(rows - 1) * lda + K) * sizeof(TA));
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(Wp, (size_t)wrows * ldw * sizeof(bf16_t));
@@ -229,13 +235,12 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     unsigned a_off[4], w_off[2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) a_off[p] = (unsigned)(((size_t)(p * 32 + srow) * lda + scol) * sizeof(TA));
-    int py[4], pxw[4];
-    if (conv) {
+    int py[5];   // CONV: image row of the pixel in LDS row p * 32 + srow (pixel m0 - 1 + that), -4 = no such pixel
+    if constexpr (CONV) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int px = m0 + p * 32 + srow;
-            pxw[p] = px % convW;
-            py[p] = px < M ? (px / convW) % convH : -4;  // rows beyond M: never inside
+        for (int p = 0; p < 5; ++p) {
+            const int px = m0 - 1 + p * 32 + srow;
+            py[p] = (px >= 0 && px < M && (p < 4 || srow < 2)) ? (px / convW) % convH : -4;
         }
     }
     const int kslabs = conv ? nslab / 9 : nslab;
@@ -403,27 +408,42 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 *reinterpret_cast<uint4 *>(Bs + (q * 32 + srow) * LS + j * 64 + scol) = breg[q * (KS / 64) + j];
     };
 
+    const int xw_lane = CONV ? (m0 + wave * 32 + l31) % convW : 0;  // CONV: image column of this lane's pixel
     for (int slab = 0; slab < nslab; ++slab) {
         bf16x8 afr[NKS];  // this wave's 32 rows of the slab as MFMA operands
-        {
-            a_piece<TA> ap[AH][cfg::A_PIECES];
-            const int tap = slab / kslabs, kslab = slab - tap * kslabs;
+        // CONV: slab = (tap row, k slab, tap column), the column innermost; wslab = the weight's slab (tap-major along K)
+        int wslab = slab, wslab_next = slab + 1, dxi = 0;
+        if constexpr (CONV) {
+            dxi = slab % 3;
+            const int t2 = slab / 3, s1 = slab + 1, t3 = s1 / 3;
+            wslab = ((t2 / kslabs) * 3 + dxi) * kslabs + t2 % kslabs;
+            wslab_next = ((t3 / kslabs) * 3 + s1 % 3) * kslabs + t3 % kslabs;
+        }
+        if (!CONV || dxi == 0) {
+            constexpr int NP = CONV ? 5 : 4;  // row groups of the staging: the strip's two extra rows make a fifth
+            a_piece<TA> ap[AH][NP * (AW / 64)];
+            const int tap = CONV ? 0 : slab / kslabs, kslab = CONV ? (slab / 3) % kslabs : slab - tap * kslabs;
+            const int dyi = CONV ? slab / 3 / kslabs : 1;
             const unsigned soff = (unsigned)(kslab * KS * sizeof(TA));
-            if (conv) {
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            unsigned offs[NP];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bool in = py[p] + dy >= 0 && py[p] + dy < convH && pxw[p] + dx >= 0 && pxw[p] + dx < convW;
-                    a_off[p] = in ? (unsigned)(((size_t)(m0 + p * 32 + srow + dy * convW + dx) * lda + scol) * sizeof(TA)) : 0x80000000u;
+            for (int p = 0; p < NP; ++p) {
+                if constexpr (CONV) {
+                    const int yy = py[p] + dyi - 1;
+                    offs[p] = (py[p] != -4 && yy >= 0 && yy < convH)
+                                  ? (unsigned)(((size_t)((long long)m0 - 1 + p * 32 + srow + (long long)(dyi - 1) * convW) * lda + scol) * sizeof(TA))
+                                  : 0x80000000u;
+                } else {
+                    offs[p] = a_off[p];
                 }
             }
 #pragma unroll
             for (int h = 0; h < AH; ++h)
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int j = 0; j < AW / 64; ++j)
-                        ap[h][p * (AW / 64) + j].load(rs_a, a_off[p] + (h * AW + j * 64) * (unsigned)sizeof(TA), soff, half16);
+                        ap[h][p * (AW / 64) + j].load(rs_a, offs[p] + (h * AW + j * 64) * (unsigned)sizeof(TA), soff, half16);
             if (slab == 0) load_b(0, 0);
             if (slab == 0) LN_STAMP(1);
             if (prenorm) {
@@ -445,24 +465,52 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
             for (int h = 0; h < AH; ++h) {
                 lds_barrier();  // the previous reads of As / Bs are over
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int j = 0; j < AW / 64; ++j) {
                         const int kc = kslab * KS + h * AW + j * 64;  // first column of this thread's group of 64
                         const uint4 v = ap[h][p * (AW / 64) + j].pack(kc + scol, K);
-                        *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * ALS + j * 64 + scol) = v;
-                        // (convolution: the centre tap's rows are the block's own rows)
-                        // (a half-empty last slab: the columns at and beyond the padded K are not part of the copy's rows)
-                        if (copy_row != nullptr && p * 32 + srow < rows && (!conv || tap == 4) && kc < ((K + 63) & ~63))
-                            *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + kc) = v;
+                        if (p < 4 || srow < 2) *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * ALS + j * 64 + scol) = v;
+                        // the bf16 copy of the block's own rows (CONV: the strip of the centre tap row holds them from its
+                        // second row on); a half-empty last slab: the columns at and beyond the padded K are not part of it
+                        if constexpr (CONV) {
+                            const int own = p * 32 + srow - 1;
+                            if (copy_row != nullptr && dyi == 1 && own >= 0 && own < rows && (p < 4 || srow < 2) && kc < ((K + 63) & ~63))
+                                *reinterpret_cast<uint4 *>(copy_row + ((long long)p * 32 - 1) * lda_copy + kc) = v;
+                        } else {
+                            if (copy_row != nullptr && p * 32 + srow < rows && kc < ((K + 63) & ~63))
+                                *reinterpret_cast<uint4 *>(copy_row + (size_t)p * 32 * lda_copy + kc) = v;
+                        }
                     }
                 if (h == AH - 1) write_b();
                 if (slab == 0 && h == AH - 1) LN_STAMP(2);
                 lds_barrier();
                 if (slab == 0 && h == AH - 1) LN_STAMP(3);
-                const bf16_t *arow = As + (wave * 32 + l31) * ALS + 8 * hh;
+                if constexpr (!CONV) {
+                    const bf16_t *arow = As + (wave * 32 + l31) * ALS + 8 * hh;
 #pragma unroll
-                for (int ks = 0; ks < NKS / AH; ++ks) afr[h * (NKS / AH) + ks] = as_bf16x8(*reinterpret_cast<const uint4 *>(arow + ks * 16));
+                    for (int ks = 0; ks < NKS / AH; ++ks) afr[h * (NKS / AH) + ks] = as_bf16x8(*reinterpret_cast<const uint4 *>(arow + ks * 16));
+                }
+            }
+        } else {
+            // CONV, the strip's second and third tap column: only the tap's first weight chunk is new
+            lds_barrier();
+            write_b();
+            lds_barrier();
+        }
+        if constexpr (CONV) {
+            // LDS row r holds pixel m0 - 1 + r: this lane's pixel shifted by dx = dxi - 1 is row wave * 32 + l31 + dxi
+            const bf16_t *arow = As + (wave * 32 + l31 + dxi) * ALS + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) afr[ks] = as_bf16x8(*reinterpret_cast<const uint4 *>(arow + ks * 16));
+            const bool edge = (dxi == 0 && xw_lane == 0) || (dxi == 2 && xw_lane == convW - 1);
+            if (__builtin_amdgcn_ballot_w64(edge) != 0ull) {  // uniform: a wave with a pixel on the image's edge (rare)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    uint4 v = *reinterpret_cast<uint4 *>(&afr[ks]);
+                    if (edge) v = make_uint4(0u, 0u, 0u, 0u);
+                    afr[ks] = as_bf16x8(v);
+                }
             }
         }
         for (int chunk = 0; chunk < nch; ++chunk) {
@@ -472,8 +520,8 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 write_b();
                 lds_barrier();
             }
-            if (chunk + 1 < nch) load_b(slab, chunk + 1);
-            else if (slab + 1 < nslab) load_b(slab + 1, 0);
+            if (chunk + 1 < nch) load_b(wslab, chunk + 1);
+            else if (slab + 1 < nslab) load_b(wslab_next, 0);
             const bf16_t *brow = Bs + l31 * LS + 8 * hh;
             if constexpr (PERSIST) {
                 // chunk is uniform; a switch keeps the accumulators in registers
@@ -772,28 +820,32 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
     const size_t lds = cfg::LDS + ((size_t)cpb * LN_CN + LN_BM) * sizeof(float);
     if (lds > 160 * 1024) return fail(DSW_EUNSUPPORTED, "dsw_linear: %d output columns per block need %zu bytes of LDS", cpb * LN_CN, lds);
     int rc;
-    const bool ext = gated != 0 || norm_eps >= 0.f;
+    const bool ext = gated != 0 || norm_eps >= 0.f, conv = convH > 0;
+    const size_t lds_k = lds + (conv ? 2 * (size_t)cfg::ALS * sizeof(bf16_t) : 0);   // the convolution's strip: two more rows of A
     auto go = [&](auto kern) -> int {
-        if ((rc = set_lds((const void *)kern, lds, "dsw_linear"))) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
+        if ((rc = set_lds((const void *)kern, lds_k, "dsw_linear"))) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds_k, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
                            bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units,
                            unit_rows, (bf16_t *)aux, ld_aux, norm_eps);
         return DSW_OK;
     };
     if (ext && sizeof(TC) != 2) return fail(DSW_EUNSUPPORTED, "dsw_linear: the activation / normalisation forms write bf16");
+    if (conv && (ext || nslab < 9 || cfg::AH > 1)) return fail(DSW_EINVAL, "dsw_conv3x3_nhwc: nine taps of whole slabs, no activation forms");
     if (nslab > 1) {
         if constexpr (cfg::AH > 1) {
             return fail(DSW_EUNSUPPORTED, "dsw_linear: slabs of %d columns are single", KS);
         } else if constexpr (sizeof(TC) == 2) {
-            if ((rc = ext ? go(linear_nt_kernel<TA, TC, KS, NACC, true>) : go(linear_nt_kernel<TA, TC, KS, NACC, false>))) return rc;
+            if ((rc = conv ? go(linear_nt_kernel<TA, TC, KS, NACC, 2>)
+                           : ext ? go(linear_nt_kernel<TA, TC, KS, NACC, 1>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>)))
+                return rc;
         } else {
-            if ((rc = go(linear_nt_kernel<TA, TC, KS, NACC, false>))) return rc;
+            if ((rc = conv ? go(linear_nt_kernel<TA, TC, KS, NACC, 2>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>))) return rc;
         }
     } else {
         if constexpr (sizeof(TC) == 2) {
-            if ((rc = ext ? go(linear_nt_kernel<TA, TC, KS, 0, true>) : go(linear_nt_kernel<TA, TC, KS, 0, false>))) return rc;
+            if ((rc = ext ? go(linear_nt_kernel<TA, TC, KS, 0, 1>) : go(linear_nt_kernel<TA, TC, KS, 0, 0>))) return rc;
         } else {
-            if ((rc = go(linear_nt_kernel<TA, TC, KS, 0, false>))) return rc;
+            if ((rc = go(linear_nt_kernel<TA, TC, KS, 0, 0>))) return rc;
         }
     }
     return check_launch("linear_nt_kernel");
