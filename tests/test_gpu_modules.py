@@ -515,9 +515,13 @@ def test_msft_model_bf16_stream_against_fp32(cuda0, monkeypatch):
     assert set(g16) == set(g32)
     worst = max((rel_err(g16[n], g32[n]), n) for n in g32 if g32[n].abs().max() > 0)
     # the gradients have crossed every block in bf16: the bar is what the module-by-module path itself shows under
-    # the same autocast (stock convolutions and LayerNorms on a bf16 stream), with 6e-2 as the floor
+    # the same autocast (stock convolutions and LayerNorms on a bf16 stream), with 8e-2 as the floor.  Both paths end
+    # in MIOpen's bf16 convolutions (stem and reconstruction tail), whose choice of algorithm differs between runs: the
+    # module-by-module path's own worst error was seen between 0.044 and 0.073 on the same inputs, this path's between
+    # 0.059 and 0.063 (bias gradients of the 1x1 convolutions, tools/msft_bf16_probe.py) - a floor of 6e-2 sat inside
+    # that spread.
     worst_nchw = max((rel_err(g16n[n], g32[n]), n) for n in g32 if g32[n].abs().max() > 0)
-    assert worst[0] < max(6e-2, 1.25 * worst_nchw[0]), (worst, worst_nchw)
+    assert worst[0] < max(8e-2, 1.25 * worst_nchw[0]), (worst, worst_nchw)
 
 
 def test_prepared_weights_follow_the_parameters(cuda0):

@@ -151,7 +151,8 @@ __device__ unsigned long long g_linear_stamps[8 * 8192];
 
 // MODE 1 (EXT): the instantiations that know the epilogues beyond bias / residual (gated SiLU, GELU and its slope) and
 // the RMS normalisation of A's rows; the plain ones (MODE 0) carry none of their code or registers.
-// MODE 2 (CONV): the 3x3 convolution on NHWC pixels (several-slab kernels only), see the staging below.
+// MODE 2 (CONV): the 3x3 convolution on NHWC pixels (several-slab kernels only), see the staging below.  MODE 3: the
+// normalisation alone (single-slab kernels).
 template <typename TA, typename TC, int KS, int NACC, int MODE>
 __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const TA *__restrict__ A, long long lda, int M, int K, const bf16_t *__restrict__ Wp, int ldw, int wrows, int nslab,
@@ -159,9 +160,10 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
     int convH, int convW, int gated_arg, const int *__restrict__ live_units, int unit_rows, bf16_t *__restrict__ aux, long long ld_aux,
     float norm_eps) {
-    constexpr bool EXT = MODE == 1, CONV = MODE == 2;
+    // MODE 1: gated SiLU (with or without the normalisation); 3: the normalisation alone; 4: the GELU epilogues
+    constexpr bool CONV = MODE == 2, NORM = MODE == 1 || MODE == 3;
     static_assert(!CONV || NACC > 0, "the convolution runs over several slabs");
-    const int gated = EXT ? gated_arg : 0;
+    const int gated = MODE == 1 ? (gated_arg == 1 ? 1 : 0) : MODE == 4 ? (gated_arg == 3 ? 3 : 2) : 0;
     // norm_eps >= 0 (one slab only): the rows of A are RMS-normalised on the way (nn.RMSNorm in front of the projection,
     // DSwinT_arch.py:355 / :357 with :343-345): C = (A W^T) / sqrt(mean_k A^2 + eps) + bias per row, the norm's weight
     // having been multiplied into W's columns by the caller.  The mean runs over the fp32 values as they are loaded.
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     bf16_t *Bs = As + (LN_BM + (CONV ? 2 : 0)) * ALS;
     float *biasl = reinterpret_cast<float *>(Bs + LN_CN * LS);  // bias of this block's columns, zero where there is none
     float *rstdl = biasl + chunks_per_block * LN_CN;            // 1 / rms of the block's rows (norm_eps >= 0)
-    const bool prenorm = EXT && !PERSIST && AH == 1 && norm_eps >= 0.f;  // the single-slab kernels of K <= 192 only
+    const bool prenorm = NORM && !PERSIST && AH == 1 && norm_eps >= 0.f;  // the single-slab kernels of K <= 192 only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     LN_STAMP(0);
@@ -836,14 +838,17 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
             return fail(DSW_EUNSUPPORTED, "dsw_linear: slabs of %d columns are single", KS);
         } else if constexpr (sizeof(TC) == 2) {
             if ((rc = conv ? go(linear_nt_kernel<TA, TC, KS, NACC, 2>)
-                           : ext ? go(linear_nt_kernel<TA, TC, KS, NACC, 1>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>)))
+                           : gated >= 2 ? go(linear_nt_kernel<TA, TC, KS, NACC, 4>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>)))
                 return rc;
         } else {
             if ((rc = conv ? go(linear_nt_kernel<TA, TC, KS, NACC, 2>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>))) return rc;
         }
     } else {
         if constexpr (sizeof(TC) == 2) {
-            if ((rc = ext ? go(linear_nt_kernel<TA, TC, KS, 0, 1>) : go(linear_nt_kernel<TA, TC, KS, 0, 0>))) return rc;
+            if ((rc = gated == 1 ? go(linear_nt_kernel<TA, TC, KS, 0, 1>)
+                      : gated >= 2 ? go(linear_nt_kernel<TA, TC, KS, 0, 4>)
+                      : ext ? go(linear_nt_kernel<TA, TC, KS, 0, 3>) : go(linear_nt_kernel<TA, TC, KS, 0, 0>)))
+                return rc;
         } else {
             if ((rc = go(linear_nt_kernel<TA, TC, KS, 0, 0>))) return rc;
         }
@@ -939,6 +944,7 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
     const int nslab = (Kp + KS - 1) / KS;
     if (norm_eps >= 0.f && (nslab != 1 || KS > 192 || live_units != nullptr))
         return fail(DSW_EUNSUPPORTED, "dsw_linear_rmsnorm: the normalised rows must fit one slab of K <= 192, no live-row counter (K=%d)", K);
+    if (gated >= 2 && norm_eps >= 0.f) return fail(DSW_EUNSUPPORTED, "dsw_linear: the GELU epilogues do not take the normalisation");
     if (gated >= 2 && (c_dtype != DSW_BF16 || ncols % 8 || ldc % 8 || resid != nullptr || accumulate || live_units != nullptr ||
                        (gated == 3 && aux == nullptr) || (aux != nullptr && (ld_aux < ncols || ld_aux % 8 || ((uintptr_t)aux & 15)))))
         return fail(DSW_EUNSUPPORTED, "dsw_linear_gelu: needs a bf16 result, ncols and the row strides multiples of 8, 16-byte aligned bases "
