@@ -353,7 +353,24 @@ int dsw_linear_gelu(const void *a, int a_dtype, long long lda, long long M, int 
                     void *a_copy, long long lda_copy, void *stream);
 int dsw_linear_gelu_bwd(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
                         int ldw, const void *pre, long long ld_pre, void *out, long long ldo, int ncols, void *a_copy,
-                        long long lda_copy, void *stream);
+                        long long lda_copy, float drop_p, unsigned long long drop_seed, void *stream);
+
+/* The residual dropout of the callers' blocks (msft_arch.py:163-165: x = self.drop_path(branch) + x, an nn.Dropout on
+ * the branch; DSwinT_arch.py:355-357) inside the projections on either side of it, with the seeded decisions of
+ * dsw_rezero_dropout_seeded_fwd / _bwd (a hash of the seed and the element's index in the dense [M][N] branch):
+ *   dsw_linear_residual_dropout: out = resid + *scale * dropout(a W^T + bias), fp32 - the projection that closes the
+ *     branch, the dropout and the residual in one launch (arguments as dsw_linear_residual, then drop_p, drop_seed);
+ *   dsw_linear_dropout_in: c = dropout(a) W^T for an fp32 a of dense rows [M][K] - the backward of the same: a is the
+ *     gradient of the block's output, masked and scaled on its way in (a_copy receives the masked bf16 values: the
+ *     operand of dsw_linear_wgrad), w_p the prepared transpose of the closing projection's weight;
+ *   dsw_linear_gelu_bwd takes drop_p / drop_seed for the same purpose when a is fp32 (0: no dropout). */
+int dsw_linear_dropout_in(const void *a, long long lda, long long M, int K, const void *w_p, int wrows, int ldw, void *c,
+                          int c_dtype, long long ldc, int ncols, void *a_copy, long long lda_copy, float drop_p,
+                          unsigned long long drop_seed, void *stream);
+int dsw_linear_residual_dropout(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows,
+                                int ldw, const float *bias, int N, const float *resid, long long ld_resid,
+                                const float *scale, float *out, long long ldo, int ncols, float drop_p,
+                                unsigned long long drop_seed, void *stream);
 
 /* Window attention with the q|k|v projection inside the kernel, forward only (inference): the nn.Linear of
  * DSwinT_arch.py:334 (WindowedMSA.qkv) or :303 (DeformableSparseWindowAttention.in_proj) followed by the

@@ -372,6 +372,68 @@ def test_msft_block_with_the_gradient_sums_inside_the_kernels(cuda0, autocast):
         assert rel_err(gp1[n], gp0[n]) < tol, n
 
 
+@pytest.mark.parametrize("C,heads", [(216, 4), (96, 6)])
+def test_msft_vitblock_with_the_residual_dropout_inside_the_projections(cuda0, C, heads):
+    """msft's ViTBlock on the token stream in training, drop_path 0.1 (msft_arch.py:163-165: x = drop_path(branch) + x):
+    the residual and its dropout inside the kernels of out_proj / the MLP's second projection, the mask applied to the
+    incoming gradient by the input-gradient kernels, against the same block with the residual as a pass of its own
+    (rezero_residual) under the same seeds: the same elements dropped (the kept fraction is checked on the output),
+    output and gradients equal up to the bf16 rounding of the branch that the fused form no longer makes."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd.msft import ViTBlock
+    torch.manual_seed(C)
+    H = W = 32
+    blk = ViTBlock(8, C, n_heads=heads, drop_path=0.1).to(cuda0).train()
+    blk.msa.attn_drop = 0.0
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn_like(p) * p[0].numel() ** -0.5)
+    t = torch.randn(2, H * W, C, device=cuda0)
+    r = torch.randn(2, H * W, C, device=cuda0)
+    calls = []
+    real_call = K.call
+
+    def spy(name, *args):
+        calls.append(name)
+        return real_call(name, *args)
+
+    res = []
+    for fuse in (True, False):
+        K.FUSE_RESIDUAL_DROPOUT = fuse
+        K.call = spy
+        calls.clear()
+        try:
+            torch.manual_seed(1234)          # the dropout seeds are drawn from torch's CPU generator, in the same order both times
+            blk.zero_grad(set_to_none=True)
+            tg = t.clone().requires_grad_()
+            tin = tg * 1.0
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk.forward_tokens(tin, H, W)
+            (y * r).sum().backward()
+        finally:
+            K.FUSE_RESIDUAL_DROPOUT = True
+            K.call = real_call
+        if fuse:
+            assert calls.count("dsw_linear_residual_dropout") == 2 and "dsw_linear_dropout_in" in calls and "dsw_linear_gelu_bwd" in calls
+            assert not any(c.startswith("dsw_rezero") for c in calls)
+        else:
+            assert calls.count("dsw_rezero_dropout_seeded_fwd") == 2 and "dsw_linear_residual_dropout" not in calls
+        res.append((y.detach().float(), tg.grad.clone(), {n: p.grad.float().clone() for n, p in blk.named_parameters()}))
+    (y1, gx1, gp1), (y0, gx0, gp0) = res
+    assert y1.dtype == torch.float32 and rel_err(y1, y0) < 2e-3
+    # an element of the second branch that was dropped leaves the stream as the first residual made it: the same in both runs
+    assert rel_err(gx1, gx0) < 2e-2
+    assert set(gp1) == set(gp0)
+    for n in gp0:
+        assert rel_err(gp1[n], gp0[n]) < 2e-2, n
+    # eval: no dropout, the plain fused residual
+    blk.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ye = blk.forward_tokens(t, H, W)
+    assert torch.isfinite(ye).all()
+
+
 @pytest.mark.parametrize("tokens,dim,scale", [(2 * 32 * 32, 216, 2), (1000, 96, 2), (515, 192, 4)])
 def test_msft_mlp_with_the_activation_inside_the_projections(cuda0, tokens, dim, scale):
     """msft's MLP (msft_arch.py:19-33) under bf16 autocast with GELU in the epilogue of the first projection and its

@@ -25,6 +25,7 @@ from visiontransformer_amd import functional as K  # noqa: E402
 K.FUSE_GELU = os.environ.get("DSW_FUSE_GELU", "1") != "0"
 K.BATCH_WEIGHT_PREP = os.environ.get("DSW_BATCH_PREP", "1") != "0"
 models.NHWC_ENDS_TRAINING = os.environ.get("DSW_NHWC_ENDS_TRAINING", "0") == "1"
+K.FUSE_RESIDUAL_DROPOUT = os.environ.get("DSW_FUSE_RESID_DROP", "1") != "0"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 t0 = None
 for i in range(steps):
@@ -39,4 +40,4 @@ for i in range(steps):
 torch.cuda.synchronize()
 if t0 is not None:
     print("%s: %.2f ms per step (FUSE_GELU=%s BATCH_WEIGHT_PREP=%s NHWC_ENDS_TRAINING=%s)" % (
-        which, (time.perf_counter() - t0) / (steps - 4) * 1e3, K.FUSE_GELU, K.BATCH_WEIGHT_PREP, models.NHWC_ENDS_TRAINING), flush=True)
+        which, (time.perf_counter() - t0) / (steps - 4) * 1e3, K.FUSE_GELU, K.BATCH_WEIGHT_PREP, models.NHWC_ENDS_TRAINING) + " FUSE_RESIDUAL_DROPOUT=%s" % K.FUSE_RESIDUAL_DROPOUT, flush=True)

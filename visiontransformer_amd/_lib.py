@@ -59,7 +59,11 @@ SIGNATURES = {
     "dsw_linear_gelu": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _I, _P, ctypes.c_longlong, _I, _P, ctypes.c_longlong,
                              _P, ctypes.c_longlong, _P]),
     "dsw_linear_gelu_bwd": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _I,
-                                 _P, ctypes.c_longlong, _P]),
+                                 _P, ctypes.c_longlong, _F, ctypes.c_ulonglong, _P]),
+    "dsw_linear_dropout_in": (_I, [_P, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _I, ctypes.c_longlong, _I, _P, ctypes.c_longlong,
+                                   _F, ctypes.c_ulonglong, _P]),
+    "dsw_linear_residual_dropout": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _I, _P, ctypes.c_longlong, _P, _P,
+                                         ctypes.c_longlong, _I, _F, ctypes.c_ulonglong, _P]),
     "dsw_linear_residual": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _I, _P, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _I, _P]),
     "dsw_sd_stencil_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "dsw_sd_gather_bwd": (_I, [_P, _I, _I, _I, _P, _P]),

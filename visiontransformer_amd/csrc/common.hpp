@@ -216,6 +216,15 @@ __device__ __forceinline__ uint32_t drop_hash(uint32_t pair_idx, uint32_t seed_l
     return x;
 }
 
+// inverted dropout on 4 consecutive elements with the decisions taken from the seed (DropArgs): e0 = index of the first of the 4 elements in the
+// dense [M][C] matrix (a multiple of 4); elements 2i, 2i+1 share pair index i (mod 2^32)
+__device__ __forceinline__ float4 drop4_seeded(float4 v, long long e0, const DropArgs &d) {
+    const uint32_t pair = (uint32_t)(e0 >> 1);
+    const uint32_t h0 = drop_hash(pair, d.seed_lo, d.seed_hi), h1 = drop_hash(pair + 1u, d.seed_lo, d.seed_hi);
+    return make_float4((h0 & 0xffffu) >= d.thr ? v.x * d.inv_keep : 0.f, (h0 >> 16) >= d.thr ? v.y * d.inv_keep : 0.f,
+                       (h1 & 0xffffu) >= d.thr ? v.z * d.inv_keep : 0.f, (h1 >> 16) >= d.thr ? v.w * d.inv_keep : 0.f);
+}
+
 int make_drop(const char *who, float p, unsigned long long seed, DropArgs &d);  // C-ABI arguments -> kernel form
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -67,6 +67,13 @@ template <> struct a_piece<float> {
         v.w = h ? pack_bf16(__uint_as_float(hi.z), __uint_as_float(hi.w)) : 0u;
         return v;
     }
+    // inverted dropout of the 8 elements, e0 = index of the first in the dense matrix the decisions are defined on
+    __device__ __forceinline__ void drop(long long e0, const DropArgs &d) {
+        const float4 a = drop4_seeded(make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w)), e0, d);
+        const float4 b = drop4_seeded(make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z), __uint_as_float(hi.w)), e0 + 4, d);
+        lo = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w));
+        hi = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w));
+    }
     // sum of the squares of the elements in front of column K (the fp32 values as they are in memory)
     __device__ __forceinline__ float sumsq(int k, int K) const {
         const bool l = k + 4 <= K, h = k + 8 <= K;
@@ -91,6 +98,7 @@ template <> struct a_piece<bf16_t> {
         const bool l = k + 4 <= K, h = k + 8 <= K;
         return make_uint4(l ? v.x : 0u, l ? v.y : 0u, h ? v.z : 0u, h ? v.w : 0u);
     }
+    __device__ __forceinline__ void drop(long long, const DropArgs &) {}   // the masked operand is always the fp32 gradient
     __device__ __forceinline__ float sumsq(int k, int K) const {
         const bool l = k + 4 <= K, h = k + 8 <= K;
         const unsigned u[4] = {v.x, v.y, v.z, v.w};
@@ -159,9 +167,14 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
     const float *__restrict__ bias, int N, TC *__restrict__ C, long long ldc, int ncols, bf16_t *__restrict__ a_copy,
     long long lda_copy, int chunks_per_block, const float *__restrict__ resid, long long ld_resid, const float *__restrict__ rscale,
     int convH, int convW, int gated_arg, const int *__restrict__ live_units, int unit_rows, bf16_t *__restrict__ aux, long long ld_aux,
-    float norm_eps) {
-    // MODE 1: gated SiLU (with or without the normalisation); 3: the normalisation alone; 4: the GELU epilogues
+    float norm_eps, DropArgs dropa, int drop_C) {
+    // MODE 1: gated SiLU (with or without the normalisation); 3: the normalisation alone; 4: the GELU epilogues; 5: dropout
+    // dropa.thr != 0 (MODE 4, 5): inverted dropout with seeded decisions on the dense [M][drop_C] matrix (the residual
+    // dropout of the callers' blocks, msft_arch.py:163-165 / DSwinT_arch.py:355-357).  fp32 A: A is a gradient that is
+    // masked on its way in (the copy for the weight gradient receives the masked values).  fp32 C with a residual
+    // (MODE 5): C = resid + rs * dropout(A W^T + bias).
     constexpr bool CONV = MODE == 2, NORM = MODE == 1 || MODE == 3;
+    constexpr bool DROP_IN = (MODE == 4 || MODE == 5) && sizeof(TA) == 4, DROP_OUT = MODE == 5 && sizeof(TC) == 4;
     static_assert(!CONV || NACC > 0, "the convolution runs over several slabs");
     const int gated = MODE == 1 ? (gated_arg == 1 ? 1 : 0) : MODE == 4 ? (gated_arg == 3 ? 3 : 2) : 0;
     // norm_eps >= 0 (one slab only): the rows of A are RMS-normalised on the way (nn.RMSNorm in front of the projection,
@@ -337,8 +350,11 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                 const int t = ps * TPP + tt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 v = make_float4(a[t][4 * g] * rn + bv[t][g].x, a[t][4 * g + 1] * rn + bv[t][g].y, a[t][4 * g + 2] * rn + bv[t][g].z,
-                                                 a[t][4 * g + 3] * rn + bv[t][g].w);
+                    float4 v = make_float4(a[t][4 * g] * rn + bv[t][g].x, a[t][4 * g + 1] * rn + bv[t][g].y, a[t][4 * g + 2] * rn + bv[t][g].z,
+                                           a[t][4 * g + 3] * rn + bv[t][g].w);
+                    if constexpr (DROP_OUT) {
+                        if (dropa.thr != 0u) v = drop4_seeded(v, (long long)(m0 + wave * 32 + l31) * drop_C + nb + t * 32 + 8 * g + 4 * hh, dropa);
+                    }
                     // bf16: a lane stores 8 bytes, and the rows 8 apart that one store instruction's 16-lane groups hold
                     // are 288 dwords apart - the same banks.  Rows 8-15 and 24-31 therefore keep the two halves of
                     // every 16-byte piece swapped (the reader below swaps them back in registers, for free: which
@@ -448,6 +464,17 @@ __global__ __launch_bounds__(LN_THREADS, 2) void linear_nt_kernel(
                         ap[h][p * (AW / 64) + j].load(rs_a, offs[p] + (h * AW + j * 64) * (unsigned)sizeof(TA), soff, half16);
             if (slab == 0) load_b(0, 0);
             if (slab == 0) LN_STAMP(1);
+            if constexpr (DROP_IN) {
+                if (dropa.thr != 0u) {
+#pragma unroll
+                    for (int h = 0; h < AH; ++h)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+#pragma unroll
+                            for (int j = 0; j < AW / 64; ++j)
+                                ap[h][p * (AW / 64) + j].drop((long long)(m0 + p * 32 + srow) * drop_C + kslab * KS + h * AW + j * 64 + scol, dropa);
+                }
+            }
             if (prenorm) {
                 // a row's columns lie with 8 neighbouring lanes (all halves and column groups of the slab)
 #pragma unroll
@@ -804,7 +831,8 @@ template <typename TA, typename TC, int KS>
 int launch_linear(const void *a, long long lda, int M, int K, const void *wp, int ldw, int wrows, int nslab, const float *bias, int N,
                   void *c, long long ldc, int ncols, void *a_copy, long long lda_copy, const float *resid, long long ld_resid,
                   const float *rscale, int convH, int convW, int gated, const int *live_units, int unit_rows, hipStream_t st,
-                  void *aux = nullptr, long long ld_aux = 0, float norm_eps = -1.f) {
+                  void *aux = nullptr, long long ld_aux = 0, float norm_eps = -1.f, DropArgs dropa = DropArgs{0u, 0u, 0u, 1.f},
+                  int drop_C = 0) {
     using cfg = LnCfg<KS>;
     const int mt = (M + LN_BM - 1) / LN_BM, total = (ncols + LN_CN - 1) / LN_CN;
     int cpb;
@@ -828,9 +856,10 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
         if ((rc = set_lds((const void *)kern, lds_k, "dsw_linear"))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(LN_THREADS), lds_k, st, (const TA *)a, lda, M, K, (const bf16_t *)wp, ldw, wrows, nslab,
                            bias, N, (TC *)c, ldc, ncols, (bf16_t *)a_copy, lda_copy, cpb, resid, ld_resid, rscale, convH, convW, gated, live_units,
-                           unit_rows, (bf16_t *)aux, ld_aux, norm_eps);
+                           unit_rows, (bf16_t *)aux, ld_aux, norm_eps, dropa, drop_C);
         return DSW_OK;
     };
+    const bool dropm = dropa.thr != 0u && gated < 2;   // (the GELU forms carry the mask of their fp32 operand themselves)
     if (ext && sizeof(TC) != 2) return fail(DSW_EUNSUPPORTED, "dsw_linear: the activation / normalisation forms write bf16");
     if (conv && (ext || nslab < 9 || cfg::AH > 1)) return fail(DSW_EINVAL, "dsw_conv3x3_nhwc: nine taps of whole slabs, no activation forms");
     if (nslab > 1) {
@@ -838,19 +867,23 @@ int launch_linear(const void *a, long long lda, int M, int K, const void *wp, in
             return fail(DSW_EUNSUPPORTED, "dsw_linear: slabs of %d columns are single", KS);
         } else if constexpr (sizeof(TC) == 2) {
             if ((rc = conv ? go(linear_nt_kernel<TA, TC, KS, NACC, 2>)
-                           : gated >= 2 ? go(linear_nt_kernel<TA, TC, KS, NACC, 4>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>)))
+                      : gated >= 2 ? go(linear_nt_kernel<TA, TC, KS, NACC, 4>)
+                      : dropm ? go(linear_nt_kernel<TA, TC, KS, NACC, 5>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>)))
                 return rc;
         } else {
-            if ((rc = conv ? go(linear_nt_kernel<TA, TC, KS, NACC, 2>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>))) return rc;
+            if ((rc = conv ? go(linear_nt_kernel<TA, TC, KS, NACC, 2>)
+                      : dropm ? go(linear_nt_kernel<TA, TC, KS, NACC, 5>) : go(linear_nt_kernel<TA, TC, KS, NACC, 0>)))
+                return rc;
         }
     } else {
         if constexpr (sizeof(TC) == 2) {
             if ((rc = gated == 1 ? go(linear_nt_kernel<TA, TC, KS, 0, 1>)
                       : gated >= 2 ? go(linear_nt_kernel<TA, TC, KS, 0, 4>)
-                      : ext ? go(linear_nt_kernel<TA, TC, KS, 0, 3>) : go(linear_nt_kernel<TA, TC, KS, 0, 0>)))
+                      : ext ? go(linear_nt_kernel<TA, TC, KS, 0, 3>)
+                      : dropm ? go(linear_nt_kernel<TA, TC, KS, 0, 5>) : go(linear_nt_kernel<TA, TC, KS, 0, 0>)))
                 return rc;
         } else {
-            if ((rc = go(linear_nt_kernel<TA, TC, KS, 0, 0>))) return rc;
+            if ((rc = dropm ? go(linear_nt_kernel<TA, TC, KS, 0, 5>) : go(linear_nt_kernel<TA, TC, KS, 0, 0>))) return rc;
         }
     }
     return check_launch("linear_nt_kernel");
@@ -908,7 +941,18 @@ extern "C" int dsw_weight_prep_batch(int n, const void *const *w, const int *w_d
 static int linear_impl(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                        const float *bias, int N, void *c, int c_dtype, long long ldc, int ncols, int accumulate, void *a_copy,
                        long long lda_copy, const float *resid, long long ld_resid, const float *rscale, void *stream, int gated = 0,
-                       const int *live_units = nullptr, int unit_rows = 0, void *aux = nullptr, long long ld_aux = 0, float norm_eps = -1.f) {
+                       const int *live_units = nullptr, int unit_rows = 0, void *aux = nullptr, long long ld_aux = 0, float norm_eps = -1.f,
+                       float drop_p = 0.f, unsigned long long drop_seed = 0ull, int drop_C = 0) {
+    DropArgs dropa{0u, 0u, 0u, 1.f};
+    if (drop_p != 0.f) {
+        // the masked side is the fp32 one: the operand (a gradient on its way in) or the result in front of its residual
+        const int rcd = make_drop("dsw_linear (dropout)", drop_p, drop_seed, dropa);
+        if (rcd) return rcd;
+        const bool in = a_dtype == DSW_F32 && resid == nullptr, out = c_dtype == DSW_F32 && resid != nullptr && !accumulate;
+        if (in == out || drop_C <= 0 || drop_C % 4 || norm_eps >= 0.f || gated == 1 || live_units != nullptr || (in && drop_C != K))
+            return fail(DSW_EUNSUPPORTED, "dsw_linear (dropout): an fp32 operand of dense rows (no residual) or an fp32 result with a "
+                                          "residual, a dense row length that is a multiple of 4 (drop_C=%d K=%d)", drop_C, K);
+    }
     if (M <= 0 || M > 0x7fffff00LL || K <= 0 || ncols <= 0 || wrows <= 0)
         return fail(DSW_EINVAL, "dsw_linear: bad sizes M=%lld K=%d ncols=%d wrows=%d", M, K, ncols, wrows);
     DSW_REQUIRE(a && w_p && c, "dsw_linear: null pointer");
@@ -958,7 +1002,7 @@ static int linear_impl(const void *a, int a_dtype, long long lda, long long M, i
     int rc = DSW_OK;
 #define DSW_LINEAR_KS(KSV)                                                                                                     \
     DSW_DISPATCH_DTYPE(a_dtype, TA, DSW_DISPATCH_DTYPE(c_dtype, TC, {                                                          \
-        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, live_units, unit_rows, st, aux, ld_aux, norm_eps); \
+        rc = launch_linear<TA, TC, KSV>(a, lda, (int)M, K, w_p, ldw, wrows, nslab, bias, N, c, ldc, ncols, a_copy, lda_copy, resid, ld_resid, rscale, 0, 0, gated, live_units, unit_rows, st, aux, ld_aux, norm_eps, dropa, drop_C); \
     }))
     if (KS == 192) DSW_LINEAR_KS(192);
     else if (KS == 256) DSW_LINEAR_KS(256);
@@ -1012,10 +1056,25 @@ extern "C" int dsw_linear_gelu(const void *a, int a_dtype, long long lda, long l
 
 extern "C" int dsw_linear_gelu_bwd(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
                                    const void *pre, long long ld_pre, void *out, long long ldo, int ncols, void *a_copy, long long lda_copy,
-                                   void *stream) {
+                                   float drop_p, unsigned long long drop_seed, void *stream) {
     DSW_REQUIRE(pre, "dsw_linear_gelu_bwd: null pointer");
     return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, nullptr, 0, out, DSW_BF16, ldo, ncols, 0, a_copy, lda_copy, nullptr, 0, nullptr,
-                       stream, 3, nullptr, 0, const_cast<void *>(pre), ld_pre);
+                       stream, 3, nullptr, 0, const_cast<void *>(pre), ld_pre, -1.f, drop_p, drop_seed, K);
+}
+
+extern "C" int dsw_linear_dropout_in(const void *a, long long lda, long long M, int K, const void *w_p, int wrows, int ldw, void *c, int c_dtype,
+                                     long long ldc, int ncols, void *a_copy, long long lda_copy, float drop_p, unsigned long long drop_seed,
+                                     void *stream) {
+    return linear_impl(a, DSW_F32, lda, M, K, w_p, wrows, ldw, nullptr, 0, c, c_dtype, ldc, ncols, 0, a_copy, lda_copy, nullptr, 0, nullptr,
+                       stream, 0, nullptr, 0, nullptr, 0, -1.f, drop_p, drop_seed, K);
+}
+
+extern "C" int dsw_linear_residual_dropout(const void *a, int a_dtype, long long lda, long long M, int K, const void *w_p, int wrows, int ldw,
+                                           const float *bias, int N, const float *resid, long long ld_resid, const float *scale, float *out,
+                                           long long ldo, int ncols, float drop_p, unsigned long long drop_seed, void *stream) {
+    DSW_REQUIRE(resid && scale, "dsw_linear_residual_dropout: null pointer");
+    return linear_impl(a, a_dtype, lda, M, K, w_p, wrows, ldw, bias, N, out, DSW_F32, ldo, ncols, 0, nullptr, 0, resid, ld_resid, scale, stream,
+                       0, nullptr, 0, nullptr, 0, -1.f, drop_p, drop_seed, N);
 }
 
 static int conv3x3_impl(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows, int ldw,

@@ -395,15 +395,6 @@ __device__ __forceinline__ float4 drop4(float4 v, uint32_t m4, float keep) {
                        (m4 & 0xff000000u) ? v.w * keep : 0.f);
 }
 
-// the same with the decisions taken from the seed (DropArgs): e0 = index of the first of the 4 elements in the
-// dense [M][C] matrix (a multiple of 4); elements 2i, 2i+1 share pair index i (mod 2^32)
-__device__ __forceinline__ float4 drop4_seeded(float4 v, long long e0, const DropArgs &d) {
-    const uint32_t pair = (uint32_t)(e0 >> 1);
-    const uint32_t h0 = drop_hash(pair, d.seed_lo, d.seed_hi), h1 = drop_hash(pair + 1u, d.seed_lo, d.seed_hi);
-    return make_float4((h0 & 0xffffu) >= d.thr ? v.x * d.inv_keep : 0.f, (h0 >> 16) >= d.thr ? v.y * d.inv_keep : 0.f,
-                       (h1 & 0xffffu) >= d.thr ? v.z * d.inv_keep : 0.f, (h1 >> 16) >= d.thr ? v.w * d.inv_keep : 0.f);
-}
-
 template <typename TB>
 __global__ __launch_bounds__(256) void rezero_fwd_kernel(const float *__restrict__ x, const TB *__restrict__ b, long long ldb,
                                                          const float *__restrict__ r, const unsigned char *__restrict__ mask, float keep,

@@ -1200,7 +1200,10 @@ class _LinearFn(torch.autograd.Function):
       chunk results are summed in fp32 (a split-K the library does not pick by itself)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act_dtype, pad_out, live=None, resid=None, pending_out=None, pending_in=None, gelu=None):
+    def forward(ctx, x, weight, bias, act_dtype, pad_out, live=None, resid=None, pending_out=None, pending_in=None, gelu=None, drop=None):
+        # drop = (p, seed), with resid: the result is resid + dropout(x W^T + b), the residual dropout of the caller's block
+        # (seeded decisions as in rezero_residual); the backward masks the incoming gradient as it loads it.
+        # pending_out may also be a GradSink: the residual's share of the gradient is then delivered to it
         # gelu = ("out", GeluLink): the result is gelu(x W^T + b) (the caller has checked that the kernel takes the call);
         # gelu = ("in", GeluLink): x is such a result, and the input gradient leaves as the gradient of the link's h
         # resid (fp32, the result's shape): the result is resid + (x W^T + b) as fp32, one kernel (the caller has
@@ -1235,9 +1238,14 @@ class _LinearFn(torch.autograd.Function):
                 if resid is not None:
                     assert a_copy is None and live is None
                     y_p = torch.empty(T, N, dtype=torch.float32, device=x2.device)
-                    call("dsw_linear_residual", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K,
-                         ptr(w_p), w_p.shape[0], w_p.shape[1], None if b32 is None else ptr(b32), N, ptr(resid), N, ptr(_one(x2.device)),
-                         ptr(y_p), N, N, stream(x2.device))
+                    if drop is None:
+                        call("dsw_linear_residual", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K,
+                             ptr(w_p), w_p.shape[0], w_p.shape[1], None if b32 is None else ptr(b32), N, ptr(resid), N, ptr(_one(x2.device)),
+                             ptr(y_p), N, N, stream(x2.device))
+                    else:
+                        call("dsw_linear_residual_dropout", a2.data_ptr(), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1], T, K,
+                             ptr(w_p), w_p.shape[0], w_p.shape[1], None if b32 is None else ptr(b32), N, ptr(resid), N, ptr(_one(x2.device)),
+                             ptr(y_p), N, N, _c_float(drop[0]), ctypes.c_ulonglong(drop[1]), stream(x2.device))
                 elif gelu is not None and gelu[0] == "out":
                     assert live is None and Nout % 8 == 0
                     y_p = torch.empty(T, Nout, dtype=act_dtype, device=x2.device)
@@ -1272,7 +1280,8 @@ class _LinearFn(torch.autograd.Function):
         ctx.live = live if mfma else None
         ctx.pending = (pending_out, pending_in)
         ctx.gelu = gelu if mfma else None
-        assert gelu is None or mfma
+        ctx.drop = drop
+        assert (gelu is None and drop is None) or mfma
         return y_p[:, :N].view(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -1295,10 +1304,18 @@ class _LinearFn(torch.autograd.Function):
                      stream(dh.device))
                 dy = dh[:, :N].view(dy.shape)
             link.done = None
+        drop = ctx.drop
         with torch.autocast("cuda", enabled=False):
             dy2 = dy.reshape(-1, N)
             T = dy2.shape[0]
-            dyk = _padded_rows(dy2, act)
+            if drop is not None:
+                # the gradient of resid + dropout(branch) arrives unmasked: the input-gradient kernel below masks it on load
+                # (and writes the masked bf16 copy that the weight and bias gradients are taken from)
+                if dy2.dtype != torch.float32 or not dy2.is_contiguous():
+                    dy2 = dy2.float().contiguous()
+                if not (mfma and need_dx and xdt == act and act == torch.bfloat16 and _mfma_operand(dy2) is not None and ctx.live is None):
+                    raise RuntimeError("projection with the residual dropout inside: its backward needs the kernel path")
+            dyk = _padded_rows(dy2, act) if drop is None else None
             PAD_STATS["taken" if dyk is not None else "copied"] += 1
             dx = None
             if mfma and need_dx and xdt in (torch.float32, torch.bfloat16):
@@ -1313,7 +1330,7 @@ class _LinearFn(torch.autograd.Function):
                         dy2 = dy2.contiguous()
                     if _mfma_operand(dy2) is not None:
                         a2, K = dy2, N
-                        if need_dw:
+                        if need_dw or drop is not None:
                             a_copy = dyk = _mark_padded(torch.empty(T, Np, dtype=act, device=dy2.device))
                     else:
                         a2 = dyk = _cast_padded(dy2, act)
@@ -1325,8 +1342,13 @@ class _LinearFn(torch.autograd.Function):
                         # dh = (dy W) * gelu'(h) in the kernel's epilogue
                         call("dsw_linear_gelu_bwd", ctypes.c_void_p(a2.data_ptr()), dtype_code(a2.dtype), a2.stride(0) if T > 1 else a2.shape[1],
                              T, K, ptr(w_s), w_s.shape[0], w_s.shape[1], ptr(link.h), Kp, ptr(dx_p), Kp, Kp,
-                             None if a_copy is None else ptr(a_copy), 0 if a_copy is None else a_copy.shape[1], stream(dy2.device))
+                             None if a_copy is None else ptr(a_copy), 0 if a_copy is None else a_copy.shape[1],
+                             _c_float(0.0 if drop is None else drop[0]), ctypes.c_ulonglong(0 if drop is None else drop[1]), stream(dy2.device))
                         link.done = torch._C._current_graph_task_id()
+                    elif drop is not None:
+                        call("dsw_linear_dropout_in", ptr(a2), a2.stride(0) if T > 1 else a2.shape[1], T, K, ptr(w_s), w_s.shape[0], w_s.shape[1],
+                             ptr(dx_p), dtype_code(dx_p.dtype), Kp, Kp, None if a_copy is None else ptr(a_copy),
+                             0 if a_copy is None else a_copy.shape[1], _c_float(drop[0]), ctypes.c_ulonglong(drop[1]), stream(dy2.device))
                     else:
                         _mfma_linear(a2, K, w_s, None, 0, dx_p, Kp, a_copy, live=ctx.live)
                     dx = dx_p[:, :Kd].view(xshape) if Kp != Kd else dx_p.view(xshape)
@@ -1385,19 +1407,32 @@ class _LinearFn(torch.autograd.Function):
                 dx = dx + extra.reshape(dx.shape).to(dx.dtype)
         d_resid = None
         if ctx.needs_input_grad[6]:
-            if ctx.pending[0] is not None:
-                ctx.pending[0].put(dy)
+            out = ctx.pending[0]
+            if isinstance(out, GradSink):
+                # as the residual op does it: dy itself is the residual's share; the norm's backward kernel adds it to its own
+                out._same_pass()
+                if out.buf is not None:
+                    out.buf.view(dy.shape).add_(dy)
+                    d_resid = out.deliver(out.buf)
+                else:
+                    d_resid = out.deliver(dy if dy.dtype == torch.float32 and dy.is_contiguous() else dy.float().contiguous())
+            elif out is not None:
+                out.put(dy)
             else:
                 d_resid = dy
-        return dx, dw, db, None, None, None, d_resid, None, None, None
+        return dx, dw, db, None, None, None, d_resid, None, None, None, None
 
 
-def linear_plus_residual(a, lin, resid, pending=None):
+def linear_plus_residual(a, lin, resid, pending=None, dropout=None, dropout_seed=None, gelu=None):
     """resid + lin(a) as fp32 in one kernel, with autograd (dsw_linear_residual with a scale of one: the projection that
     closes a branch with the plain residual around it, DSwinT_arch.py:337 with :355).  bf16 autocast, `a` in padded
     bf16 rows (what the attention kernels write), resid a contiguous fp32 tensor of the result's shape.  The backward
-    reads the fp32 gradient as it arrives; the residual's share of it goes to `pending` (PendingGrad) when given, back
-    to autograd otherwise.  None when the call is not one the kernel takes."""
+    reads the fp32 gradient as it arrives; the residual's share of it goes to `pending` (a PendingGrad, or the GradSink
+    shared with the norm in front of the branch) when given, back to autograd otherwise.  dropout: the nn.Dropout the
+    caller's block puts on the branch (msft_arch.py:163-165); in training it is applied inside the kernel in front of
+    the residual (dsw_linear_residual_dropout, the seeded decisions of rezero_residual) and the backward masks the
+    gradient as the input-gradient kernel loads it (dsw_linear_dropout_in): no pass over the stream for the residual
+    or its dropout, forward or backward.  gelu: see mlp_gelu.  None when the call is not one the kernel takes."""
     weight = lin.weight
     N, Kd = weight.shape
     if not (autocast_dtype(None) == torch.bfloat16 and a.is_cuda and resid.is_cuda and resid.dtype == torch.float32
@@ -1405,9 +1440,16 @@ def linear_plus_residual(a, lin, resid, pending=None):
             and a.numel() > 0 and weight.is_contiguous() and weight.dtype in (torch.float32, torch.bfloat16)
             and weight.data_ptr() % 16 == 0 and resid.data_ptr() % 16 == 0):
         return None
-    if _padded_rows(a.reshape(-1, Kd), torch.bfloat16) is None:
-        return None
-    return _run(_LinearFn, a, weight, lin.bias, torch.bfloat16, False, None, resid, pending, None, None)
+    a2 = a.reshape(-1, Kd)
+    if _padded_rows(a2, torch.bfloat16) is None and not (a2.dtype == torch.bfloat16 and Kd == _ceil_pad(Kd) and a2.is_contiguous()
+                                                            and a2.data_ptr() % 16 == 0):
+        return None      # (padded bf16 rows, or dense ones of a width that needs no padding)
+    drop = None
+    if dropout is not None and dropout.training and dropout.p > 0:
+        if dropout.p >= 1.0 or not torch.is_grad_enabled():
+            return None
+        drop = (float(dropout.p), draw_dropout_seed() if dropout_seed is None else int(dropout_seed))
+    return _run(_LinearFn, a, weight, lin.bias, torch.bfloat16, False, None, resid, pending, None, gelu, drop)
 
 
 def linear(x, lin, pad_out=False, live=None, grad_extra=None):
@@ -1420,17 +1462,20 @@ def linear(x, lin, pad_out=False, live=None, grad_extra=None):
     grad_extra: a PendingGrad; what it holds when the backward pass gets here is added to x's gradient by the kernel
     that writes it."""
     act = autocast_dtype(x.dtype)
-    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out), live, None, None, grad_extra, None)
+    return _run(_LinearFn, x, lin.weight, lin.bias, act, bool(pad_out), live, None, None, grad_extra, None, None)
 
 
 FUSE_GELU = True   # False: mlp_gelu always declines
+FUSE_RESIDUAL_DROPOUT = True   # False: the msft blocks keep their residual and its dropout as a pass of its own (rezero_residual)
 
 
-def mlp_gelu(x, fc1, fc2):
+def mlp_gelu(x, fc1, fc2, residual=None):
     """fc2(gelu(fc1(x))) of msft's MLP (msft_arch.py:19-33) with the activation inside the projection kernels: fc1's
     epilogue writes gelu(h) (and h on the side when a backward will want it), fc2's input-gradient kernel applies
     gelu'(h) as it writes dh - no pass over the hidden rows for the activation, forward or backward.  bf16 autocast
-    only; None when the call is not one the kernels take (the caller composes linear / gelu / linear)."""
+    only; None when the call is not one the kernels take (the caller composes linear / gelu / linear).
+    residual = (stream, dropout module or None, GradSink / PendingGrad or None): returns stream + dropout(mlp(x)), the
+    residual of the caller's block (msft_arch.py:165), taken inside fc2's kernel where that is possible."""
     w1, w2 = fc1.weight, fc2.weight
     Hd, Kd = w1.shape
     ok = (FUSE_GELU and autocast_dtype(None) == torch.bfloat16 and x.is_cuda and x.numel() > 0 and x.dtype in (torch.float32, torch.bfloat16)
@@ -1439,8 +1484,16 @@ def mlp_gelu(x, fc1, fc2):
     if not ok:
         return None
     link = GeluLink()
-    g = _run(_LinearFn, x, w1, fc1.bias, torch.bfloat16, True, None, None, None, None, ("out", link))
-    return _run(_LinearFn, g, w2, fc2.bias, torch.bfloat16, False, None, None, None, None, ("in", link))
+    g = _run(_LinearFn, x, w1, fc1.bias, torch.bfloat16, True, None, None, None, None, ("out", link), None)
+    if residual is not None:
+        # the block's residual and its dropout inside fc2's kernel (and the mask inside its input-gradient kernel)
+        y = linear_plus_residual(g, fc2, residual[0], residual[2], dropout=residual[1], gelu=("in", link))
+        if y is not None:
+            return y
+        branch = _run(_LinearFn, g, w2, fc2.bias, torch.bfloat16, False, None, None, None, None, ("in", link), None)
+        return rezero_residual(residual[0], _one(x.device), branch, sink=residual[2] if isinstance(residual[2], GradSink) else None,
+                               dropout=residual[1])
+    return _run(_LinearFn, g, w2, fc2.bias, torch.bfloat16, False, None, None, None, None, ("in", link), None)
 
 
 def linear_residual(a, lin, resid, r):

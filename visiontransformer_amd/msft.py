@@ -86,15 +86,28 @@ class WindowedMSA(nn.Module):
         # None = draw it from torch's CPU generator
         self.dropout_seed = None
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, residual=None):
+        """residual = (stream, dropout module or None, GradSink / PendingGrad or None): returns
+        stream + dropout(attention(x)) - the residual of the caller's block (msft_arch.py:163-164) - taken inside
+        out_proj's kernel where that is possible."""
         B, N, C = x.shape
         assert N == H * W
         qkv = K.linear(x, self.qkv)
         # the reference hands attn_drop to SDPA whatever the mode (msft_arch.py:136): dropout in eval() too
         z = K.window_attention(qkv, None, self.window_size, self.num_heads, QKV_CHUNKED, grid=(B, H, W),
                                lepe_w=self.pe_encoder.weight, lepe_b=self.pe_encoder.bias,
-                               dropout_p=self.attn_drop, dropout_seed=self.dropout_seed)
-        return self.proj_drop(K.linear(z, self.out_proj))
+                               dropout_p=self.attn_drop, dropout_seed=self.dropout_seed, pad_out=residual is not None)
+        if residual is None:
+            return self.proj_drop(K.linear(z, self.out_proj))
+        stream, drop, sink = residual
+        y = None
+        if K.FUSE_RESIDUAL_DROPOUT and torch.is_grad_enabled() and (not self.proj_drop.training or self.proj_drop.p == 0):
+            y = K.linear_plus_residual(z, self.out_proj, stream, sink, dropout=drop)
+        if y is None:
+            one = torch.ones(1, device=x.device)
+            y = K.rezero_residual(stream, one, self.proj_drop(K.linear(z, self.out_proj)),
+                                  sink=sink if isinstance(sink, K.GradSink) else None, dropout=drop)
+        return y
 
 
 class MLP(nn.Module):
@@ -107,15 +120,27 @@ class MLP(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(in_features, hidden_features), nn.GELU(),
                                  nn.Linear(hidden_features, out_features), nn.Dropout(drop))
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual = (stream, dropout module or None, GradSink / PendingGrad or None): returns stream + dropout(mlp(x)),
+        the residual of the caller's block (msft_arch.py:165), taken inside the second projection's kernel where that is
+        possible."""
         if not x.is_cuda:
             return self.mlp(x)
         # the two Linears through the projection kernels (they read the LayerNorm's fp32 output where it lies), the
         # activation in their epilogues under bf16 autocast
+        inner_drop = self.mlp[3].training and self.mlp[3].p > 0
+        if residual is not None and K.FUSE_RESIDUAL_DROPOUT and torch.is_grad_enabled() and not inner_drop:
+            y = K.mlp_gelu(x, self.mlp[0], self.mlp[2], residual=residual)
+            if y is not None:
+                return y
         y = K.mlp_gelu(x, self.mlp[0], self.mlp[2])
         if y is None:
             y = K.linear(K.gelu(K.linear(x, self.mlp[0], pad_out=True), pad_out=True), self.mlp[2])
-        return self.mlp[3](y)
+        y = self.mlp[3](y)
+        if residual is None:
+            return y
+        stream, drop, sink = residual
+        return K.rezero_residual(stream, torch.ones(1, device=x.device), y, sink=sink if isinstance(sink, K.GradSink) else None, dropout=drop)
 
 
 class ViTBlock(nn.Module):
@@ -149,10 +174,13 @@ class ViTBlock(nn.Module):
         one = self._one(t.device)
         sink = K.layer_norm_sink(t, self.ln1)
         n1 = K.layer_norm(t, self.ln1, for_projection=True, sink=sink, pending=grad_extra)
-        t = K.rezero_residual(t, one, self.msa(n1, H, W), sink=sink, dropout=self.drop_path)
+        if not torch.is_grad_enabled():
+            t = K.rezero_residual(t, one, self.msa(n1, H, W), sink=sink, dropout=self.drop_path)
+            return K.rezero_residual(t, one, self.mlp(K.layer_norm(t, self.ln2, for_projection=True)), dropout=self.drop_path)
+        # training: the residual and its dropout inside the branch's closing projection (msft.WindowedMSA / MLP)
+        t = self.msa(n1, H, W, residual=(t, self.drop_path, sink))
         sink = K.layer_norm_sink(t, self.ln2)
-        return K.rezero_residual(t, one, self.mlp(K.layer_norm(t, self.ln2, for_projection=True, sink=sink)), sink=sink,
-                                 dropout=self.drop_path)
+        return self.mlp(K.layer_norm(t, self.ln2, for_projection=True, sink=sink), residual=(t, self.drop_path, sink))
 
     def _one(self, device):
         o = getattr(self, "_one_buf", None)
