@@ -27,5 +27,5 @@ for r in last:
 tot = sum(v[0] for v in t.values())
 span = int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
 print("last step: %d launches, busy %.2f ms, span %.2f ms" % (len(last), tot / 1e6, span / 1e6))
-for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:45]:
+for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 45]:
     print("%8.3f ms %5.1f%% %5d  %s" % (v[0] / 1e6, 100.0 * v[0] / tot, v[1], k))
