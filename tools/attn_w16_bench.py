@@ -37,9 +37,17 @@ def main():
     for _ in range(200):  # bring the clocks up before the first measurement
         a = a @ a * 1e-3
     torch.cuda.synchronize()
-    for name, lead, layout, grid in (("wmsa", (B, HW, HW), QKV_INTERLEAVED, (B, HW, HW)), ("dsmsa", (128, w * w), QKV_CHUNKED, None)):
+    # "contig": the same 3 072 (window, head) work items as "wmsa" with every item's operands in one contiguous block of
+    # memory (one head, 16x16 images, a token's q|k|v in 180 bytes of a 256-byte row): what a head-major layout would
+    # give the kernels
+    for name, lead, layout, grid in (("wmsa", (B, HW, HW), QKV_INTERLEAVED, (B, HW, HW)), ("dsmsa", (128, w * w), QKV_CHUNKED, None),
+                                     ("contig", (3072, w, w), QKV_INTERLEAVED, (3072, w, w)),
+                                     ("contig2", (1536, w, w), QKV_INTERLEAVED, (1536, w, w))):
         if os.environ.get("W16_SHAPE", name) != name:
             continue
+        # "contig2": two heads, 360 of a 384-byte row used, a window's two work items in one 96 KB block
+        C, heads = {"contig": (30, 1), "contig2": (60, 2)}.get(name, (180, 6))
+        qp, op = {"contig": (128, 64), "contig2": (192, 64)}.get(name, (576, 192))
         for padded in (True, False, True):
             if os.environ.get("W16_PITCH", "both") not in ("both", "padded" if padded else "dense"):
                 continue
@@ -55,10 +63,10 @@ def main():
                 tab = (torch.randn((2 * w - 1) ** 2, heads, device=dev) * 0.02).requires_grad_() if bias else None
                 for _ in range(nsets):
                     if padded:
-                        buf = K._mark_padded(torch.zeros(T, 576, device=dev, dtype=torch.bfloat16))
+                        buf = K._mark_padded(torch.zeros(T, qp, device=dev, dtype=torch.bfloat16))
                         buf[:, :3 * C] = torch.randn(T, 3 * C, device=dev).bfloat16()
                         qkv = buf[:, :3 * C].view(lead + (3 * C,)).requires_grad_()
-                        gbuf = torch.zeros(T, 192, device=dev, dtype=torch.bfloat16)
+                        gbuf = torch.zeros(T, op, device=dev, dtype=torch.bfloat16)
                         gbuf[:, :C] = torch.randn(T, C, device=dev).bfloat16()
                         do = gbuf[:, :C].view(lead + (C,))
                     else:
