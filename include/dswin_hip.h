@@ -339,6 +339,24 @@ int dsw_linear_rmsnorm_gated_silu(const void *a, int a_dtype, long long lda, lon
                                   const void *w_p, int wrows, int ldw, const float *bias, void *out, long long ldo,
                                   void *stream);
 
+/* The gated MLP of DSWT's transformer block with the RMSNorm in front of it and the ReZero residual around it
+ * (DSwinT_arch.py:47-69 applied at :357 with the norm of :345), inference, one launch:
+ *   y = x + r * (fc2(silu(fc1_gate(n)) * fc1_content(n)) + b2),  n = x / sqrt(mean_k x^2 + eps) * g   (norm_eps < 0: n = x)
+ * x, y: fp32 rows of C values (C % 4 == 0, C <= 192; row strides ldx, ldy in elements), y may not alias x.  The hidden
+ * activations never reach memory.  Operand images prepared by the caller (bf16, 16-byte aligned), the hidden dimension
+ * in `hidden_chunks` chunks of 32 units (<= 16), zero rows / columns beyond the matrices:
+ *   w1c [chunks][64][192]: rows 0..31 of a chunk = the gate rows of its hidden units, rows 32..63 = their content rows,
+ *                          each row = W[h][0..C) * g[0..C) (the norm's weight folded in);
+ *   b1c [chunks][64] fp32, the same order;
+ *   w2c [chunks][192][32]: W2[out][hidden of the chunk], every 16 hidden units in the order 0-3, 8-11, 4-7, 12-15
+ *                          (the order in which a lane's MFMA accumulators hold the gated values);
+ *   b2 [192] fp32.  r: one float on the device.
+ * Gate, content and the gated product are rounded to bf16 as the separate kernels (dsw_linear_rmsnorm_gated_silu,
+ * dsw_linear_residual) round them; the second product is accumulated in another order (1e-6 relative). */
+int dsw_mlp_gated_residual(const float *x, long long ldx, long long M, int C, float norm_eps, const void *w1c,
+                           const float *b1c, const void *w2c, const float *b2, int hidden_chunks, const float *r,
+                           float *y, long long ldy, void *stream);
+
 /* The first projection of msft's MLP with its activation (msft_arch.py:22-25 applied at :33: Linear, then
  * nn.GELU() in its erf form): out = gelu(a W^T + bias) in one launch, bf16.  The pre-activation is rounded to bf16
  * first - what dsw_linear would have stored - so out has the bits of dsw_linear followed by dsw_gelu_fwd.

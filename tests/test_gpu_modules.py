@@ -763,6 +763,49 @@ def test_inference_with_the_rmsnorm_inside_the_projections(cuda0):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim,scale,shape", [(180, 2, (2, 40, 50)), (64, 2, (1, 1, 1)), (192, 2, (1, 16, 24)), (180, 1, (3, 129))])
+def test_inference_with_the_mlp_in_one_kernel(cuda0, dim, scale, shape):
+    """x + r * mlp(norm(x)) (DSwinT_arch.py:357 with :47-69, :345) through dsw_mlp_gated_residual - norm, fc1, gate, fc2
+    and the residual in one kernel - against the two-kernel path (same bf16 roundings, another summation order in
+    fc2) and against the stock fp32 modules; row counts that leave a partial block, widths below and at 192."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd.models import GatedMLP
+    torch.manual_seed(dim + scale)
+    mlp = GatedMLP(dim, ffn_scale=scale).to(cuda0).eval()
+    norm = torch.nn.RMSNorm(dim).to(cuda0)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.2 * torch.randn(dim, device=cuda0))
+    r = torch.full((1,), 0.3, device=cuda0)
+    x = torch.randn(*shape, dim, device=cuda0)
+    calls = []
+    real_call = K.call
+
+    def spy(name, *args):
+        calls.append(name)
+        return real_call(name, *args)
+
+    outs = []
+    for fuse in (True, False):
+        K.FUSE_MLP = fuse
+        K.call = spy
+        calls.clear()
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                outs.append(mlp(x, residual=(x, r), prenorm=norm))
+        finally:
+            K.FUSE_MLP = True
+            K.call = real_call
+        assert ("dsw_mlp_gated_residual" in calls) == fuse
+    y1, y0 = outs
+    assert y1.dtype == torch.float32 and y1.shape == x.shape
+    with torch.no_grad():
+        n = norm(x)
+        ref = r * mlp.fc2(torch.nn.functional.silu(mlp.fc1_gate(n)) * mlp.fc1_content(n))
+    assert rel_err(y1 - x, y0 - x) < 2e-3
+    assert rel_err(y1 - x, ref) < 2e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("window", [8, 16])
 def test_inference_with_the_projection_inside_the_attention_kernel(cuda0, window):
     """Without autograd the DSWT attention modules project q|k|v inside the attention kernel

@@ -1,0 +1,206 @@
+// The gated MLP of DSWT's transformer block with the RMSNorm in front of it and the ReZero residual around it
+// (DSwinT_arch.py:47-69 with :345 and :357) as ONE kernel, for inference:
+//
+//   y = x + r * ( fc2( silu(fc1_gate(n)) * fc1_content(n) ) + b2 ),   n = rms_norm(x) * g
+//
+// The hidden activations ([tokens, 2 * hidden] pre-activations, [tokens, hidden] gated values) never exist in memory:
+// x is read once and y written once, 2 * C * 4 bytes per token.
+//
+// Work split: a workgroup owns 128 rows of x, 32 per wave.  A wave holds its rows as the B operands of
+// H^T = W1 . X^T (x rows on the MFMA lanes: lane (n, g) keeps columns 96 g .. 96 g + 95 of row n, read straight from
+// memory as 24 consecutive 16-byte pieces, so 1 / rms of a row is a lane's own sum and one exchange with lane n + 32).
+// The hidden dimension is walked in chunks of 32 units whose weights go through LDS: 24 MFMAs give the chunk's gate and
+// content tiles [32 hidden x 32 rows]; gated, and rounded to bf16, a lane's accumulators ARE the B operand of
+// Out^T += W2[:, chunk] . Z^T (the hidden units of W2 are laid out in the order the accumulators hold them), so the
+// gated values never leave the registers: 12 more MFMAs into six persistent [32 out x 32 rows] tiles.  The result
+// leaves through a per-wave LDS staging area as whole 128-byte row segments, where the fp32 residual (x itself) is
+// read back in the same shape.
+#include "attn_common.hpp"
+
+namespace dsw {
+namespace {
+
+constexpr int ML_BM = 128;       // rows of x per workgroup
+constexpr int ML_THREADS = 256;  // 4 waves, 32 rows each
+constexpr int ML_K = 192;        // x row as MFMA operands: C <= 192, zero beyond C
+constexpr int ML_LS1 = ML_K + 8; // LDS row stride (elements) of the fc1 chunk: 16-byte reads of 8 rows on distinct banks
+constexpr int ML_HC = 32;        // hidden units per chunk
+constexpr int ML_LS2 = ML_HC + 8;
+constexpr int ML_N = 192;        // output columns as MFMA tiles: C <= 192
+constexpr int ML_SROW = 144;     // bytes per row of a wave's output staging (32 floats + padding)
+constexpr int ML_MAXCHUNKS = 16;
+
+__device__ __forceinline__ void ml_load_w1(uint4 (&r1)[6], const bf16_t *__restrict__ w1c, int c, int tid) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) r1[q] = *reinterpret_cast<const uint4 *>(w1c + (size_t)c * 64 * ML_K + (size_t)(tid + 256 * q) * 8);
+}
+__device__ __forceinline__ void ml_load_w2(uint4 (&r2)[3], const bf16_t *__restrict__ w2c, int c, int tid) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r2[q] = *reinterpret_cast<const uint4 *>(w2c + (size_t)c * ML_N * ML_HC + (size_t)(tid + 256 * q) * 8);
+}
+__device__ __forceinline__ void ml_write_w(const uint4 (&r1)[6], const uint4 (&r2)[3], bf16_t *W1s, bf16_t *W2s, int tid) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int p = tid + 256 * q, row = p / 24, c8 = p - row * 24;
+        *reinterpret_cast<uint4 *>(W1s + row * ML_LS1 + c8 * 8) = r1[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int p = tid + 256 * q, row = p >> 2, c8 = p & 3;
+        *reinterpret_cast<uint4 *>(W2s + row * ML_LS2 + c8 * 8) = r2[q];
+    }
+}
+
+__global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
+    const float *__restrict__ x, long long ldx, int M, int C, float norm_eps, const bf16_t *__restrict__ w1c,
+    const float *__restrict__ b1c, const bf16_t *__restrict__ w2c, const float *__restrict__ b2, int nchunk,
+    const float *__restrict__ rscale, float *__restrict__ y, long long ldy) {
+    // w1c [nchunk][64][192] bf16: rows 0..31 of a chunk the gate rows of its 32 hidden units, rows 32..63 their
+    //     content rows, the norm's weight multiplied into the columns, zero beyond the matrix
+    // b1c [nchunk][64] fp32, the same order; w2c [nchunk][192][32] bf16: W2[out][hidden of the chunk], every 16 hidden
+    //     units in the order 0-3, 8-11, 4-7, 12-15; b2 [192] fp32, zero beyond C
+    extern __shared__ __align__(16) unsigned char smem[];
+    bf16_t *W1s = reinterpret_cast<bf16_t *>(smem);
+    bf16_t *W2s = W1s + 64 * ML_LS1;
+    float *b1s = reinterpret_cast<float *>(W2s + ML_N * ML_LS2);
+    float *b2s = b1s + nchunk * 64;
+    unsigned char *stg_all = reinterpret_cast<unsigned char *>(b2s + ML_N);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * ML_BM;
+    const int mrow = m0 + wave * 32 + l31;
+
+    // weight chunks: global -> registers -> LDS, 16-byte pieces
+    uint4 r1[6], r2[3];
+    // the wave's rows of x: 24 pieces of 4 floats per lane
+    bf16x8 afr[12];
+    float rstd = 1.f;
+    {
+        float4 xv[24];
+        const float *xr = x + (size_t)(mrow < M ? mrow : 0) * ldx + 96 * hh;
+#pragma unroll
+        for (int i = 0; i < 24; ++i)
+            xv[i] = (mrow < M && 96 * hh + 4 * i + 4 <= C) ? *reinterpret_cast<const float4 *>(xr + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ml_load_w1(r1, w1c, 0, tid);
+        ml_load_w2(r2, w2c, 0, tid);
+        for (int i = tid; i < nchunk * 64; i += ML_THREADS) b1s[i] = b1c[i];
+        if (tid < ML_N) b2s[tid] = b2[tid];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+        ss += __shfl_xor(ss, 32, 64);
+        if (norm_eps >= 0.f) rstd = rsqrtf(ss / (float)C + norm_eps);
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks)
+            afr[ks] = as_bf16x8(make_uint4(pack_bf16(xv[2 * ks].x, xv[2 * ks].y), pack_bf16(xv[2 * ks].z, xv[2 * ks].w),
+                                           pack_bf16(xv[2 * ks + 1].x, xv[2 * ks + 1].y), pack_bf16(xv[2 * ks + 1].z, xv[2 * ks + 1].w)));
+        ml_write_w(r1, r2, W1s, W2s, tid);
+    }
+    lds_barrier();
+
+    f32x16 out[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
+
+    const bf16_t *w1g = W1s + l31 * ML_LS1 + 96 * hh, *w1k = w1g + 32 * ML_LS1;
+    const bf16_t *w2r = W2s + l31 * ML_LS2 + 8 * hh;
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        ml_load_w1(r1, w1c, more ? c + 1 : c, tid);   // (unconditional: a conditional load would send the staging registers through scratch memory)
+        f32x16 G, Cn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[r] = 0.f, Cn[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            const bf16x8 wg = as_bf16x8(*reinterpret_cast<const uint4 *>(w1g + ks * 8));
+            const bf16x8 wk = as_bf16x8(*reinterpret_cast<const uint4 *>(w1k + ks * 8));
+            G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, afr[ks], G, 0, 0, 0);
+            Cn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk, afr[ks], Cn, 0, 0, 0);
+        }
+        // gate and content rounded to bf16 first - what the stand-alone projection would have written - then the
+        // gated product, rounded to bf16 as the second projection's operand (accumulator register i of lane half g
+        // is hidden unit 8 (i / 4) + 4 g + i % 4 of the chunk)
+        uint32_t zp[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bg = *reinterpret_cast<const float4 *>(b1s + c * 64 + 8 * q + 4 * hh);
+            const float4 bk = *reinterpret_cast<const float4 *>(b1s + c * 64 + 32 + 8 * q + 4 * hh);
+            const float bgv[4] = {bg.x, bg.y, bg.z, bg.w}, bkv[4] = {bk.x, bk.y, bk.z, bk.w};
+            float z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gate = bf16_to_f32(f32_to_bf16(G[4 * q + j] * rstd + bgv[j]));
+                const float cont = bf16_to_f32(f32_to_bf16(Cn[4 * q + j] * rstd + bkv[j]));
+                z[j] = gated_silu_value(gate, cont);
+            }
+            zp[2 * q] = pack_bf16(z[0], z[1]);
+            zp[2 * q + 1] = pack_bf16(z[2], z[3]);
+        }
+        const bf16x8 zb[2] = {as_bf16x8(make_uint4(zp[0], zp[1], zp[2], zp[3])), as_bf16x8(make_uint4(zp[4], zp[5], zp[6], zp[7]))};
+        ml_load_w2(r2, w2c, more ? c + 1 : c, tid);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 w2 = as_bf16x8(*reinterpret_cast<const uint4 *>(w2r + t * 32 * ML_LS2 + s * 16));
+                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, zb[s], out[t], 0, 0, 0);
+            }
+        lds_barrier();   // every wave has read the chunk
+        if (more) ml_write_w(r1, r2, W1s, W2s, tid);
+        lds_barrier();
+    }
+
+    // y = x + r * (out + b2): each 32-column tile through the wave's staging rows, out as 128-byte row segments
+    const float rs = *rscale;
+    unsigned char *stg = stg_all + wave * 32 * ML_SROW;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        if (t * 32 >= C) break;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(stg + l31 * ML_SROW + (8 * q + 4 * hh) * 4) =
+                make_float4(out[t][4 * q], out[t][4 * q + 1], out[t][4 * q + 2], out[t][4 * q + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + (lane >> 3), m = m0 + wave * 32 + row, col = t * 32 + (lane & 7) * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(stg + row * ML_SROW + (lane & 7) * 16);
+            if (m < M && col + 4 <= C) {
+                const float4 xr = *reinterpret_cast<const float4 *>(x + (size_t)m * ldx + col);
+                const float4 b = *reinterpret_cast<const float4 *>(b2s + col);
+                *reinterpret_cast<float4 *>(y + (size_t)m * ldy + col) =
+                    make_float4(xr.x + rs * (v.x + b.x), xr.y + rs * (v.y + b.y), xr.z + rs * (v.z + b.z), xr.w + rs * (v.w + b.w));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+}  // namespace
+}  // namespace dsw
+
+using namespace dsw;
+
+extern "C" int dsw_mlp_gated_residual(const float *x, long long ldx, long long M, int C, float norm_eps, const void *w1c, const float *b1c,
+                                      const void *w2c, const float *b2, int hidden_chunks, const float *rscale, float *y, long long ldy,
+                                      void *stream) {
+    if (M < 0 || M > 0x7fffff00LL || C <= 0) return fail(DSW_EINVAL, "dsw_mlp_gated_residual: bad sizes M=%lld C=%d", M, C);
+    if (M == 0) return DSW_OK;
+    DSW_REQUIRE(x && w1c && b1c && w2c && b2 && rscale && y, "dsw_mlp_gated_residual: null pointer");
+    if (C > ML_K || C % 4 || ldx < C || ldy < C || ldx % 4 || ldy % 4 || hidden_chunks < 1 || hidden_chunks > ML_MAXCHUNKS)
+        return fail(DSW_EUNSUPPORTED, "dsw_mlp_gated_residual: C=%d (a multiple of 4, <= %d), row strides %lld / %lld (multiples of 4, >= C), "
+                    "%d hidden chunks (1..%d)", C, ML_K, ldx, ldy, hidden_chunks, ML_MAXCHUNKS);
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w1c | (uintptr_t)w2c | (uintptr_t)b1c | (uintptr_t)b2) & 15)
+        return fail(DSW_EUNSUPPORTED, "dsw_mlp_gated_residual: operands must be 16-byte aligned");
+    const size_t lds = (size_t)64 * ML_LS1 * 2 + (size_t)ML_N * ML_LS2 * 2 + ((size_t)hidden_chunks * 64 + ML_N) * 4 + (size_t)4 * 32 * ML_SROW;
+    auto kern = mlp_gated_residual_kernel;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DSW_ELAUNCH, "dsw_mlp_gated_residual: LDS attribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + ML_BM - 1) / ML_BM)), dim3(ML_THREADS), lds, as_stream(stream), x, ldx, (int)M, C, norm_eps,
+                       (const bf16_t *)w1c, b1c, (const bf16_t *)w2c, b2, hidden_chunks, rscale, y, ldy);
+    return check_launch("mlp_gated_residual_kernel");
+}

@@ -1569,6 +1569,63 @@ def _folded_weight(weight, norm_weight):
     return f
 
 
+FUSE_MLP = True   # False: mlp_gated_residual always declines (the MLP runs as two projection kernels)
+_MLP_HIDDEN_PERM = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def mlp_gated_operands(gate_w, content_w, gate_b, content_b, fc2_w, fc2_b, norm_weight):
+    """The operand images of dsw_mlp_gated_residual: (w1c [chunks, 64, 192] bf16, b1c [chunks, 64] fp32,
+    w2c [chunks, 192, 32] bf16, b2 [192] fp32, chunks) from the two fc1 weights [H, C] (with the RMSNorm weight [C]
+    multiplied into their columns), fc2's weight [C_out, H] and the biases (None = zero)."""
+    H, C = gate_w.shape
+    N = fc2_w.shape[0]
+    dev = gate_w.device
+    nch = (H + 31) // 32
+    Hp = nch * 32
+    g = norm_weight.detach().float()[None, :] if norm_weight is not None else 1.0
+    w1 = torch.zeros(nch, 2, 32, 192, device=dev)
+    b1 = torch.zeros(nch, 2, 32, device=dev)
+    for u, (w, b) in enumerate(((gate_w, gate_b), (content_w, content_b))):
+        wp = torch.zeros(Hp, 192, device=dev)
+        wp[:H, :C] = w.detach().float() * g
+        w1[:, u] = wp.view(nch, 32, 192)
+        if b is not None:
+            bp = torch.zeros(Hp, device=dev)
+            bp[:H] = b.detach().float()
+            b1[:, u] = bp.view(nch, 32)
+    w2 = torch.zeros(192, Hp, device=dev)
+    w2[:N, :H] = fc2_w.detach().float()
+    w2 = w2.view(192, Hp // 16, 16)[:, :, list(_MLP_HIDDEN_PERM)].reshape(192, nch, 32).permute(1, 0, 2)
+    b2 = torch.zeros(192, device=dev)
+    if fc2_b is not None:
+        b2[:N] = fc2_b.detach().float()
+    return (w1.view(nch, 64, 192).to(torch.bfloat16).contiguous(), b1.view(nch, 64).contiguous(),
+            w2.to(torch.bfloat16).contiguous(), b2, nch)
+
+
+def mlp_gated_ok(x, norm, hidden, out_features):
+    """whether mlp_gated_residual takes the call: inference under bf16 autocast on the contiguous fp32 stream"""
+    C = x.shape[-1]
+    return (FUSE_MLP and _prenorm_ok(x, norm, C) and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0
+            and out_features == C and 0 < hidden <= 512)
+
+
+def mlp_gated_residual(x, norm, operands, r):
+    """x + r * mlp(norm(x)) for the SiLU-gated MLP (DSwinT_arch.py:47-69 with :345 and :357) in one kernel
+    (dsw_mlp_gated_residual): x is read once and the result written once, the hidden activations stay in registers.
+    operands from mlp_gated_operands (with norm.weight folded in); r a one-element tensor; the caller has checked
+    mlp_gated_ok."""
+    C = x.shape[-1]
+    w1c, b1c, w2c, b2, nch = operands
+    x2 = x.view(-1, C)
+    y = torch.empty_like(x2)
+    eps = norm.eps if norm.eps is not None else torch.finfo(x.dtype).eps
+    r32 = r.detach().float().reshape(1)
+    call("dsw_mlp_gated_residual", ptr(x2), C, x2.shape[0], C, _c_float(eps), ptr(w1c), ptr(b1c), ptr(w2c), ptr(b2), nch, ptr(r32),
+         ptr(y), C, stream(x.device))
+    return y.view(x.shape)
+
+
 def _prenorm_ok(x, norm, Kd):
     return (FOLD_RMSNORM and not torch.is_grad_enabled() and autocast_dtype(None) == torch.bfloat16 and _norm_kernel_ok(x, norm)
             and x.shape[-1] == Kd and Kd <= 192 and x.numel() > 0 and x.data_ptr() % 16 == 0)

@@ -85,6 +85,19 @@ class GatedMLP(nn.Module):
             object.__setattr__(self, "_kept_fc1_inter", kept)
         return kept[1]
 
+    def _fused_operands(self, prenorm):
+        """the operand images of the one-kernel MLP (functional.mlp_gated_operands), kept between calls like _stacked()"""
+        ps = (self.fc1_gate.weight, self.fc1_content.weight, self.fc1_gate.bias, self.fc1_content.bias, self.fc2.weight, self.fc2.bias,
+              prenorm.weight)
+        if not K._may_keep_operands():
+            return K.mlp_gated_operands(*ps)
+        key = tuple(None if p is None else (p._version, p.data_ptr()) for p in ps)
+        kept = getattr(self, "_kept_fused", None)
+        if kept is None or kept[0] != key:
+            kept = (key, K.mlp_gated_operands(*ps))
+            object.__setattr__(self, "_kept_fused", kept)
+        return kept[1]
+
     def forward(self, x, residual=None, prenorm=None):
         """residual = (stream, r), inference only: returns stream + r * mlp(x), the residual taken inside fc2's
         kernel (the caller's ReZero residual, DSwinT_arch.py:357).  prenorm (with residual): the nn.RMSNorm the caller
@@ -93,6 +106,10 @@ class GatedMLP(nn.Module):
         if residual is not None:
             h = None
             Hd = self.fc1_gate.out_features
+            if (prenorm is not None and residual[0] is x and residual[1] is not None and torch.is_tensor(residual[1]) and residual[1].numel() == 1
+                    and isinstance(self.act, nn.SiLU) and K.mlp_gated_ok(x, prenorm, Hd, self.fc2.out_features)):
+                # norm, both projections, the gate and the residual in one kernel: the hidden activations stay in registers
+                return K.mlp_gated_residual(x, prenorm, self._fused_operands(prenorm), residual[1])
             fused_ok = (K.FUSE_GATED_SILU and (self.fc1_gate.bias is None) == (self.fc1_content.bias is None)
                         and (Hd + 31) // 32 * 32 == (Hd + 63) // 64 * 64 and self.fc1_gate.in_features <= 192)
             if prenorm is not None:
