@@ -351,8 +351,9 @@ int dsw_linear_rmsnorm_gated_silu(const void *a, int a_dtype, long long lda, lon
  *   w2c [chunks][192][32]: W2[out][hidden of the chunk], every 16 hidden units in the order 0-3, 8-11, 4-7, 12-15
  *                          (the order in which a lane's MFMA accumulators hold the gated values);
  *   b2 [192] fp32.  r: one float on the device.
- * Gate, content and the gated product are rounded to bf16 as the separate kernels (dsw_linear_rmsnorm_gated_silu,
- * dsw_linear_residual) round them; the second product is accumulated in another order (1e-6 relative). */
+ * The gated product is taken on the fp32 pre-activations and rounded to bf16 once, as the second product's operand
+ * (the separate kernels, dsw_linear_rmsnorm_gated_silu and dsw_linear_residual, also round gate and content to bf16
+ * as they store them: 4e-3 between the two forms). */
 int dsw_mlp_gated_residual(const float *x, long long ldx, long long M, int C, float norm_eps, const void *w1c,
                            const float *b1c, const void *w2c, const float *b2, int hidden_chunks, const float *r,
                            float *y, long long ldy, void *stream);

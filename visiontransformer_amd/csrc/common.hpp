@@ -77,7 +77,9 @@ __device__ __forceinline__ float4 operator/(float4 a, float s) { return make_flo
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // silu(g) * c of the gated MLP (DSwinT_arch.py:69), shared by the stand-alone kernel and the projection epilogue so
 // that both round alike
-__device__ __forceinline__ float gated_silu_value(float g, float c) { return g * (1.f / (1.f + __expf(-g))) * c; }
+// (the reciprocal as the hardware's v_rcp_f32, 1 ulp: the IEEE division costs ten instructions per element, which
+// the projection epilogues - vector-bound next to their MFMAs - cannot hide)
+__device__ __forceinline__ float gated_silu_value(float g, float c) { return g * __builtin_amdgcn_rcpf(1.f + __expf(-g)) * c; }
 
 // GELU in its erf form (nn.GELU() of msft's MLP, msft_arch.py:25), shared by the stand-alone kernels and the projection
 // epilogues so that both round alike.

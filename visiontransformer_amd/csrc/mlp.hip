@@ -30,6 +30,18 @@ constexpr int ML_N = 192;        // output columns as MFMA tiles: C <= 192
 constexpr int ML_SROW = 144;     // bytes per row of a wave's output staging (32 floats + padding)
 constexpr int ML_MAXCHUNKS = 16;
 
+// ML_STAMPS (diagnostic builds only, tools/mlp_stamps.py): thread 0 of every workgroup records the shader clock at
+// points of its life into a device array that dsw_debug_read_mlp_stamps copies out
+#ifdef ML_STAMPS
+__device__ unsigned long long g_mlp_stamps[16 * 8192];
+#define ML_STAMP(i)                                                                                              \
+    do {                                                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_mlp_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ML_STAMP(i) ((void)0)
+#endif
+
 __device__ __forceinline__ void ml_load_w1(uint4 (&r1)[6], const bf16_t *__restrict__ w1c, int c, int tid) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) r1[q] = *reinterpret_cast<const uint4 *>(w1c + (size_t)c * 64 * ML_K + (size_t)(tid + 256 * q) * 8);
@@ -69,6 +81,7 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int m0 = blockIdx.x * ML_BM;
     const int mrow = m0 + wave * 32 + l31;
+    ML_STAMP(0);
 
     // weight chunks: global -> registers -> LDS, 16-byte pieces
     uint4 r1[6], r2[3];
@@ -94,9 +107,11 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
         for (int ks = 0; ks < 12; ++ks)
             afr[ks] = as_bf16x8(make_uint4(pack_bf16(xv[2 * ks].x, xv[2 * ks].y), pack_bf16(xv[2 * ks].z, xv[2 * ks].w),
                                            pack_bf16(xv[2 * ks + 1].x, xv[2 * ks + 1].y), pack_bf16(xv[2 * ks + 1].z, xv[2 * ks + 1].w)));
+        ML_STAMP(1);   // loads issued
         ml_write_w(r1, r2, W1s, W2s, tid);
     }
     lds_barrier();
+    ML_STAMP(2);       // x and the first chunk arrived and staged
 
     f32x16 out[6];
 #pragma unroll
@@ -119,8 +134,9 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
             G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, afr[ks], G, 0, 0, 0);
             Cn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk, afr[ks], Cn, 0, 0, 0);
         }
-        // gate and content rounded to bf16 first - what the stand-alone projection would have written - then the
-        // gated product, rounded to bf16 as the second projection's operand (accumulator register i of lane half g
+        if (c == 0) ML_STAMP(3);
+        // the gated product of the fp32 pre-activations (the separate kernels round gate and content to bf16 first, as
+        // they store them), rounded to bf16 as the second projection's operand (accumulator register i of lane half g
         // is hidden unit 8 (i / 4) + 4 g + i % 4 of the chunk)
         uint32_t zp[8];
 #pragma unroll
@@ -131,13 +147,12 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
             float z[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float gate = bf16_to_f32(f32_to_bf16(G[4 * q + j] * rstd + bgv[j]));
-                const float cont = bf16_to_f32(f32_to_bf16(Cn[4 * q + j] * rstd + bkv[j]));
-                z[j] = gated_silu_value(gate, cont);
+                z[j] = gated_silu_value(G[4 * q + j] * rstd + bgv[j], Cn[4 * q + j] * rstd + bkv[j]);
             }
             zp[2 * q] = pack_bf16(z[0], z[1]);
             zp[2 * q + 1] = pack_bf16(z[2], z[3]);
         }
+        if (c == 0) ML_STAMP(4);
         const bf16x8 zb[2] = {as_bf16x8(make_uint4(zp[0], zp[1], zp[2], zp[3])), as_bf16x8(make_uint4(zp[4], zp[5], zp[6], zp[7]))};
         ml_load_w2(r2, w2c, more ? c + 1 : c, tid);
 #pragma unroll
@@ -147,14 +162,28 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
                 const bf16x8 w2 = as_bf16x8(*reinterpret_cast<const uint4 *>(w2r + t * 32 * ML_LS2 + s * 16));
                 out[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, zb[s], out[t], 0, 0, 0);
             }
+        if (c == 0) ML_STAMP(5);
         lds_barrier();   // every wave has read the chunk
         if (more) ml_write_w(r1, r2, W1s, W2s, tid);
         lds_barrier();
+        if (c == 0) ML_STAMP(6);
     }
 
     // y = x + r * (out + b2): each 32-column tile through the wave's staging rows, out as 128-byte row segments
+    ML_STAMP(7);
     const float rs = *rscale;
     unsigned char *stg = stg_all + wave * 32 * ML_SROW;
+    // the residual's values in the shape of the stores below, all requested before the first tile is staged (the
+    // operand registers are spent by now), so that their way from memory is waited for once
+    float4 xres[6][4];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wave * 32 + i * 8 + (lane >> 3), col = t * 32 + (lane & 7) * 4;
+            xres[t][i] = (m < M && col + 4 <= C) ? *reinterpret_cast<const float4 *>(x + (size_t)m * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    ML_STAMP(8);
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         if (t * 32 >= C) break;
@@ -168,7 +197,7 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
             const int row = i * 8 + (lane >> 3), m = m0 + wave * 32 + row, col = t * 32 + (lane & 7) * 4;
             const float4 v = *reinterpret_cast<const float4 *>(stg + row * ML_SROW + (lane & 7) * 16);
             if (m < M && col + 4 <= C) {
-                const float4 xr = *reinterpret_cast<const float4 *>(x + (size_t)m * ldx + col);
+                const float4 xr = xres[t][i];
                 const float4 b = *reinterpret_cast<const float4 *>(b2s + col);
                 *reinterpret_cast<float4 *>(y + (size_t)m * ldy + col) =
                     make_float4(xr.x + rs * (v.x + b.x), xr.y + rs * (v.y + b.y), xr.z + rs * (v.z + b.z), xr.w + rs * (v.w + b.w));
@@ -176,6 +205,7 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    ML_STAMP(9);
 }
 
 }  // namespace
@@ -204,3 +234,9 @@ extern "C" int dsw_mlp_gated_residual(const float *x, long long ldx, long long M
                        (const bf16_t *)w1c, b1c, (const bf16_t *)w2c, b2, hidden_chunks, rscale, y, ldy);
     return check_launch("mlp_gated_residual_kernel");
 }
+
+#ifdef ML_STAMPS
+extern "C" int dsw_debug_read_mlp_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dsw::g_mlp_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif

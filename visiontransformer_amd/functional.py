@@ -1570,7 +1570,6 @@ def _folded_weight(weight, norm_weight):
 
 
 FUSE_MLP = True   # False: mlp_gated_residual always declines (the MLP runs as two projection kernels)
-_MLP_HIDDEN_PERM = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
 
 
 def mlp_gated_operands(gate_w, content_w, gate_b, content_b, fc2_w, fc2_b, norm_weight):
@@ -1595,7 +1594,9 @@ def mlp_gated_operands(gate_w, content_w, gate_b, content_b, fc2_w, fc2_b, norm_
             b1[:, u] = bp.view(nch, 32)
     w2 = torch.zeros(192, Hp, device=dev)
     w2[:N, :H] = fc2_w.detach().float()
-    w2 = w2.view(192, Hp // 16, 16)[:, :, list(_MLP_HIDDEN_PERM)].reshape(192, nch, 32).permute(1, 0, 2)
+    # every 16 hidden units in the order 0-3, 8-11, 4-7, 12-15: as views (an index tensor would be a host copy, which a
+    # stream capture does not take)
+    w2 = w2.view(192, Hp // 16, 2, 2, 4).transpose(2, 3).reshape(192, nch, 32).permute(1, 0, 2)
     b2 = torch.zeros(192, device=dev)
     if fc2_b is not None:
         b2[:N] = fc2_b.detach().float()
