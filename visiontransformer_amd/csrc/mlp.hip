@@ -7,8 +7,8 @@
 // x is read once and y written once, 2 * C * 4 bytes per token.
 //
 // Work split: a workgroup owns 128 rows of x, 32 per wave.  A wave holds its rows as the B operands of
-// H^T = W1 . X^T (x rows on the MFMA lanes: lane (n, g) keeps columns 96 g .. 96 g + 95 of row n, read straight from
-// memory as 24 consecutive 16-byte pieces, so 1 / rms of a row is a lane's own sum and one exchange with lane n + 32).
+// H^T = W1 . X^T (x rows on the MFMA lanes: lane (n, g) keeps columns 96 g .. 96 g + 95 of row n; the rows come from
+// memory as whole 128-byte lines, 8 threads per row, which also sum the squares for 1 / rms, and cross LDS once as bf16).
 // The hidden dimension is walked in chunks of 32 units whose weights go through LDS: 24 MFMAs give the chunk's gate and
 // content tiles [32 hidden x 32 rows]; gated, and rounded to bf16, a lane's accumulators ARE the B operand of
 // Out^T += W2[:, chunk] . Z^T (the hidden units of W2 are laid out in the order the accumulators hold them), so the
@@ -42,25 +42,28 @@ __device__ unsigned long long g_mlp_stamps[16 * 8192];
 #define ML_STAMP(i) ((void)0)
 #endif
 
-__device__ __forceinline__ void ml_load_w1(uint4 (&r1)[6], const bf16_t *__restrict__ w1c, int c, int tid) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) r1[q] = *reinterpret_cast<const uint4 *>(w1c + (size_t)c * 64 * ML_K + (size_t)(tid + 256 * q) * 8);
+// a thread's nine 16-byte pieces of a weight chunk pair on their way from L2 to LDS (named members, not arrays: an
+// array that lives across the chunk loop ends up in scratch memory)
+struct MlPieces {
+    uint4 a0, a1, a2, a3, a4, a5, b0, b1, b2;
+};
+__device__ __forceinline__ void ml_load_w1(MlPieces &r, const bf16_t *__restrict__ w1c, int c, int tid) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(w1c + (size_t)c * 64 * ML_K) + tid;
+    r.a0 = src[0], r.a1 = src[256], r.a2 = src[512], r.a3 = src[768], r.a4 = src[1024], r.a5 = src[1280];
 }
-__device__ __forceinline__ void ml_load_w2(uint4 (&r2)[3], const bf16_t *__restrict__ w2c, int c, int tid) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) r2[q] = *reinterpret_cast<const uint4 *>(w2c + (size_t)c * ML_N * ML_HC + (size_t)(tid + 256 * q) * 8);
+__device__ __forceinline__ void ml_load_w2(MlPieces &r, const bf16_t *__restrict__ w2c, int c, int tid) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(w2c + (size_t)c * ML_N * ML_HC) + tid;
+    r.b0 = src[0], r.b1 = src[256], r.b2 = src[512];
 }
-__device__ __forceinline__ void ml_write_w(const uint4 (&r1)[6], const uint4 (&r2)[3], bf16_t *W1s, bf16_t *W2s, int tid) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int p = tid + 256 * q, row = p / 24, c8 = p - row * 24;
-        *reinterpret_cast<uint4 *>(W1s + row * ML_LS1 + c8 * 8) = r1[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int p = tid + 256 * q, row = p >> 2, c8 = p & 3;
-        *reinterpret_cast<uint4 *>(W2s + row * ML_LS2 + c8 * 8) = r2[q];
-    }
+__device__ __forceinline__ void ml_put_w1(bf16_t *W1s, int p, uint4 v) {
+    const int row = p / 24, c8 = p - row * 24;
+    *reinterpret_cast<uint4 *>(W1s + row * ML_LS1 + c8 * 8) = v;
+}
+__device__ __forceinline__ void ml_put_w2(bf16_t *W2s, int p, uint4 v) { *reinterpret_cast<uint4 *>(W2s + (p >> 2) * ML_LS2 + (p & 3) * 8) = v; }
+__device__ __forceinline__ void ml_write_w(const MlPieces &r, bf16_t *W1s, bf16_t *W2s, int tid) {
+    ml_put_w1(W1s, tid, r.a0), ml_put_w1(W1s, tid + 256, r.a1), ml_put_w1(W1s, tid + 512, r.a2);
+    ml_put_w1(W1s, tid + 768, r.a3), ml_put_w1(W1s, tid + 1024, r.a4), ml_put_w1(W1s, tid + 1280, r.a5);
+    ml_put_w2(W2s, tid, r.b0), ml_put_w2(W2s, tid + 256, r.b1), ml_put_w2(W2s, tid + 512, r.b2);
 }
 
 __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
@@ -72,43 +75,72 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
     // b1c [nchunk][64] fp32, the same order; w2c [nchunk][192][32] bf16: W2[out][hidden of the chunk], every 16 hidden
     //     units in the order 0-3, 8-11, 4-7, 12-15; b2 [192] fp32, zero beyond C
     extern __shared__ __align__(16) unsigned char smem[];
-    bf16_t *W1s = reinterpret_cast<bf16_t *>(smem);
-    bf16_t *W2s = W1s + 64 * ML_LS1;
-    float *b1s = reinterpret_cast<float *>(W2s + ML_N * ML_LS2);
+    float *b1s = reinterpret_cast<float *>(smem);
     float *b2s = b1s + nchunk * 64;
-    unsigned char *stg_all = reinterpret_cast<unsigned char *>(b2s + ML_N);
+    float *rstdl = b2s + ML_N;                                  // 1 / rms of the block's rows
+    bf16_t *W1s = reinterpret_cast<bf16_t *>(rstdl + ML_BM);
+    bf16_t *W2s = W1s + 64 * ML_LS1;
+    unsigned char *stg_all = reinterpret_cast<unsigned char *>(W2s + ML_N * ML_LS2);
+    bf16_t *As = W1s;   // the block's rows of x as bf16 on their way into the operand registers: [128][ML_LS1], over the
+                        // weight chunk and the output staging, which are not in use yet
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int m0 = blockIdx.x * ML_BM;
-    const int mrow = m0 + wave * 32 + l31;
     ML_STAMP(0);
 
     // weight chunks: global -> registers -> LDS, 16-byte pieces
-    uint4 r1[6], r2[3];
-    // the wave's rows of x: 24 pieces of 4 floats per lane
+    MlPieces wp;
+    // The block's rows of x: 8 threads per row, 8 columns each per 64-column group (whole 128-byte lines per row and
+    // instruction), summed squares over the 8 lanes of a row, then through LDS as bf16 into the operand registers.
     bf16x8 afr[12];
     float rstd = 1.f;
     {
-        float4 xv[24];
-        const float *xr = x + (size_t)(mrow < M ? mrow : 0) * ldx + 96 * hh;
+        const int srow = tid >> 3, scol = (tid & 7) * 8;
+        float4 xv[4][3][2];
 #pragma unroll
-        for (int i = 0; i < 24; ++i)
-            xv[i] = (mrow < M && 96 * hh + 4 * i + 4 <= C) ? *reinterpret_cast<const float4 *>(xr + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        ml_load_w1(r1, w1c, 0, tid);
-        ml_load_w2(r2, w2c, 0, tid);
+        for (int p = 0; p < 4; ++p) {
+            const int m = m0 + p * 32 + srow;
+            const float *xr = x + (size_t)(m < M ? m : 0) * ldx + scol;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    xv[p][j][h] = (m < M && 64 * j + scol + 4 * h + 4 <= C) ? *reinterpret_cast<const float4 *>(xr + 64 * j + 4 * h)
+                                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        ml_load_w1(wp, w1c, 0, tid);
+        ml_load_w2(wp, w2c, 0, tid);
         for (int i = tid; i < nchunk * 64; i += ML_THREADS) b1s[i] = b1c[i];
         if (tid < ML_N) b2s[tid] = b2[tid];
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < 24; ++i) ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
-        ss += __shfl_xor(ss, 32, 64);
-        if (norm_eps >= 0.f) rstd = rsqrtf(ss / (float)C + norm_eps);
-#pragma unroll
-        for (int ks = 0; ks < 12; ++ks)
-            afr[ks] = as_bf16x8(make_uint4(pack_bf16(xv[2 * ks].x, xv[2 * ks].y), pack_bf16(xv[2 * ks].z, xv[2 * ks].w),
-                                           pack_bf16(xv[2 * ks + 1].x, xv[2 * ks + 1].y), pack_bf16(xv[2 * ks + 1].z, xv[2 * ks + 1].w)));
         ML_STAMP(1);   // loads issued
-        ml_write_w(r1, r2, W1s, W2s, tid);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 v = xv[p][j][h];
+                    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            ss += __shfl_xor(ss, 4, 64);
+            if ((tid & 7) == 0) rstdl[p * 32 + srow] = norm_eps >= 0.f ? rsqrtf(ss / (float)C + norm_eps) : 1.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 a = xv[p][j][0], b = xv[p][j][1];
+                *reinterpret_cast<uint4 *>(As + (p * 32 + srow) * ML_LS1 + 64 * j + scol) =
+                    make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+            }
+        }
+        lds_barrier();
+        const bf16_t *arow = As + (wave * 32 + l31) * ML_LS1 + 96 * hh;   // lane (n, g) keeps columns 96 g .. 96 g + 95 of row n
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) afr[ks] = as_bf16x8(*reinterpret_cast<const uint4 *>(arow + ks * 8));
+        rstd = rstdl[wave * 32 + l31];
+        lds_barrier();   // every wave holds its operands: the chunk's weights may take the place of the rows
+        ml_write_w(wp, W1s, W2s, tid);
     }
     lds_barrier();
     ML_STAMP(2);       // x and the first chunk arrived and staged
@@ -123,7 +155,7 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
     const bf16_t *w2r = W2s + l31 * ML_LS2 + 8 * hh;
     for (int c = 0; c < nchunk; ++c) {
         const bool more = c + 1 < nchunk;
-        ml_load_w1(r1, w1c, more ? c + 1 : c, tid);   // (unconditional: a conditional load would send the staging registers through scratch memory)
+        ml_load_w1(wp, w1c, more ? c + 1 : c, tid);   // (unconditional: a conditional load would send the staging registers through scratch memory)
         f32x16 G, Cn;
 #pragma unroll
         for (int r = 0; r < 16; ++r) G[r] = 0.f, Cn[r] = 0.f;
@@ -154,7 +186,7 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
         }
         if (c == 0) ML_STAMP(4);
         const bf16x8 zb[2] = {as_bf16x8(make_uint4(zp[0], zp[1], zp[2], zp[3])), as_bf16x8(make_uint4(zp[4], zp[5], zp[6], zp[7]))};
-        ml_load_w2(r2, w2c, more ? c + 1 : c, tid);
+        ml_load_w2(wp, w2c, more ? c + 1 : c, tid);
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -164,7 +196,7 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
             }
         if (c == 0) ML_STAMP(5);
         lds_barrier();   // every wave has read the chunk
-        if (more) ml_write_w(r1, r2, W1s, W2s, tid);
+        if (more) ml_write_w(wp, W1s, W2s, tid);
         lds_barrier();
         if (c == 0) ML_STAMP(6);
     }
@@ -224,7 +256,8 @@ extern "C" int dsw_mlp_gated_residual(const float *x, long long ldx, long long M
                     "%d hidden chunks (1..%d)", C, ML_K, ldx, ldy, hidden_chunks, ML_MAXCHUNKS);
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w1c | (uintptr_t)w2c | (uintptr_t)b1c | (uintptr_t)b2) & 15)
         return fail(DSW_EUNSUPPORTED, "dsw_mlp_gated_residual: operands must be 16-byte aligned");
-    const size_t lds = (size_t)64 * ML_LS1 * 2 + (size_t)ML_N * ML_LS2 * 2 + ((size_t)hidden_chunks * 64 + ML_N) * 4 + (size_t)4 * 32 * ML_SROW;
+    const size_t lds = (size_t)64 * ML_LS1 * 2 + (size_t)ML_N * ML_LS2 * 2 + ((size_t)hidden_chunks * 64 + ML_N + ML_BM) * 4 + (size_t)4 * 32 * ML_SROW;
+    static_assert((size_t)ML_BM * ML_LS1 * 2 <= (size_t)64 * ML_LS1 * 2 + (size_t)ML_N * ML_LS2 * 2 + (size_t)4 * 32 * ML_SROW, "the rows of x fit over the weight chunk and the staging");
     auto kern = mlp_gated_residual_kernel;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
