@@ -66,6 +66,21 @@ __device__ __forceinline__ void ml_write_w(const MlPieces &r, bf16_t *W1s, bf16_
     ml_put_w2(W2s, tid, r.b0), ml_put_w2(W2s, tid + 256, r.b1), ml_put_w2(W2s, tid + 512, r.b2);
 }
 
+// MFMA weight operands of two k steps: gate and content fragments of fc1 (k steps 2 g, 2 g + 1) / both k steps of the
+// output tiles 2 u and 2 u + 1 of fc2
+__device__ __forceinline__ void ml_read_w1(const bf16_t *w1g, const bf16_t *w1k, int g, bf16x8 (&d)[4]) {
+    d[0] = as_bf16x8(*reinterpret_cast<const uint4 *>(w1g + (2 * g) * 8));
+    d[1] = as_bf16x8(*reinterpret_cast<const uint4 *>(w1k + (2 * g) * 8));
+    d[2] = as_bf16x8(*reinterpret_cast<const uint4 *>(w1g + (2 * g + 1) * 8));
+    d[3] = as_bf16x8(*reinterpret_cast<const uint4 *>(w1k + (2 * g + 1) * 8));
+}
+__device__ __forceinline__ void ml_read_w2(const bf16_t *w2r, int u, bf16x8 (&d)[4]) {
+    d[0] = as_bf16x8(*reinterpret_cast<const uint4 *>(w2r + (2 * u) * 32 * ML_LS2));
+    d[1] = as_bf16x8(*reinterpret_cast<const uint4 *>(w2r + (2 * u) * 32 * ML_LS2 + 16));
+    d[2] = as_bf16x8(*reinterpret_cast<const uint4 *>(w2r + (2 * u + 1) * 32 * ML_LS2));
+    d[3] = as_bf16x8(*reinterpret_cast<const uint4 *>(w2r + (2 * u + 1) * 32 * ML_LS2 + 16));
+}
+
 __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
     const float *__restrict__ x, long long ldx, int M, int C, float norm_eps, const bf16_t *__restrict__ w1c,
     const float *__restrict__ b1c, const bf16_t *__restrict__ w2c, const float *__restrict__ b2, int nchunk,
@@ -159,12 +174,19 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
         f32x16 G, Cn;
 #pragma unroll
         for (int r = 0; r < 16; ++r) G[r] = 0.f, Cn[r] = 0.f;
+        // weight operands are read from LDS one group of four MFMAs ahead (left to itself the compiler issues each read
+        // right in front of its MFMA)
+        bf16x8 wf[2][4];
+        ml_read_w1(w1g, w1k, 0, wf[0]);
 #pragma unroll
-        for (int ks = 0; ks < 12; ++ks) {
-            const bf16x8 wg = as_bf16x8(*reinterpret_cast<const uint4 *>(w1g + ks * 8));
-            const bf16x8 wk = as_bf16x8(*reinterpret_cast<const uint4 *>(w1k + ks * 8));
-            G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, afr[ks], G, 0, 0, 0);
-            Cn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk, afr[ks], Cn, 0, 0, 0);
+        for (int g = 0; g < 6; ++g) {
+            if (g + 1 < 6) ml_read_w1(w1g, w1k, g + 1, wf[(g + 1) & 1]);
+            else ml_read_w2(w2r, 0, wf[0]);
+            G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g & 1][0], afr[2 * g], G, 0, 0, 0);
+            Cn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g & 1][1], afr[2 * g], Cn, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g & 1][2], afr[2 * g + 1], G, 0, 0, 0);
+            Cn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g & 1][3], afr[2 * g + 1], Cn, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (c == 0) ML_STAMP(3);
         // the gated product of the fp32 pre-activations (the separate kernels round gate and content to bf16 first, as
@@ -187,13 +209,16 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_gated_residual_kernel(
         if (c == 0) ML_STAMP(4);
         const bf16x8 zb[2] = {as_bf16x8(make_uint4(zp[0], zp[1], zp[2], zp[3])), as_bf16x8(make_uint4(zp[4], zp[5], zp[6], zp[7]))};
         ml_load_w2(wp, w2c, more ? c + 1 : c, tid);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 w2 = as_bf16x8(*reinterpret_cast<const uint4 *>(w2r + t * 32 * ML_LS2 + s * 16));
-                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, zb[s], out[t], 0, 0, 0);
-            }
+        for (int u = 0; u < 3; ++u) {
+            if (u + 1 < 3) ml_read_w2(w2r, u + 1, wf[(u + 1) & 1]);
+            out[2 * u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u & 1][0], zb[0], out[2 * u], 0, 0, 0);
+            out[2 * u + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u & 1][2], zb[0], out[2 * u + 1], 0, 0, 0);
+            out[2 * u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u & 1][1], zb[1], out[2 * u], 0, 0, 0);
+            out[2 * u + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u & 1][3], zb[1], out[2 * u + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (c == 0) ML_STAMP(5);
         lds_barrier();   // every wave has read the chunk
         if (more) ml_write_w(wp, W1s, W2s, tid);
