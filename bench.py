@@ -192,12 +192,22 @@ def _window_rooflines(device, iters, warm, k, x, out):
     gather_b = lambda: call("dsw_gather_bwd", ptr(dg), bfc, ptr(sel.cellmap), ptr(sel.win_h1), ptr(sel.win_w1), n, B, H, W, C,
                             WIN, C, ptr(dx), f32c, 0, st)
     t_gb = time_calls(gather_b, iters, warm)
+    # the form the training step runs: the windows' gradients added into the input-gradient map that the other
+    # branches of the module share (only the pixels a window covers are read and written)
+    dx.zero_()
+    gather_ba = lambda: call("dsw_gather_bwd", ptr(dg), bfc, ptr(sel.cellmap), ptr(sel.win_h1), ptr(sel.win_w1), n, B, H, W, C,
+                             WIN, C, ptr(dx), f32c, 1, st)
+    t_gba = time_calls(gather_ba, iters, warm)
+    by_gba = n * C * (L * 2 + (WIN + 1) ** 2 * 4 * 2)
     by_g = n * C * ((WIN + 1) ** 2 * 4 + L * 2)
     by_gb = n * C * L * 2 + B * H * W * C * 4
     out["gather_fwd"] = dict(bound="hbm", achieved=by_g / t_g / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t_g * 1e6,
                              algorithmic=by_g)
     out["gather_bwd"] = dict(bound="hbm", achieved=by_gb / t_gb / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t_gb * 1e6,
                              algorithmic=by_gb)
+    out["gather_bwd_accumulate"] = dict(bound="hbm", achieved=by_gba / t_gba / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t_gba * 1e6,
+                                        algorithmic=by_gba, note="adds into an existing map; bytes = the windows' gradients + read and write of the "
+                                        "(w+1)^2 pixels each window covers")
     after = torch.randn(n, L, C, device=device).to(bf)
     y = torch.empty_like(x)
     gd, sdl = sel.gates_delta.float().contiguous(), sel.scores_delta.float().contiguous()
