@@ -988,10 +988,14 @@ def test_rezero_residual_with_dropout(cuda0, bdtype, padded, p):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Ci,Co,xdtype", [(1, 5, 7, 12, 8, torch.float32), (2, 33, 20, 180, 180, torch.float32),
-                                                (1, 64, 64, 192, 64, torch.bfloat16), (3, 16, 16, 64, 256, torch.float32)])
+                                                (1, 64, 64, 192, 64, torch.bfloat16), (3, 16, 16, 64, 256, torch.float32),
+                                                (2, 6, 64, 64, 64, torch.bfloat16), (1, 3, 128, 64, 8, torch.float32),
+                                                (3, 5, 64, 64, 256, torch.bfloat16), (2, 1, 192, 64, 4, torch.float32),
+                                                (2, 4, 64, 16, 4, torch.bfloat16), (1, 7, 128, 36, 72, torch.float32)])
 def test_conv3x3_nhwc(cuda0, B, H, W, Ci, Co, xdtype):
     """The NHWC 3x3 convolution (inference, bf16 autocast) against F.conv2d on the same bf16-rounded
-    operands: borders, image boundaries inside the batch, channel counts off the 64 grid."""
+    operands: borders, image boundaries inside the batch, channel counts off the 64 grid; 64 input channels on
+    widths that are multiples of 64 (the weight gradient's three-row-strip kernel), one to six image rows."""
     import torch.nn.functional as F
     from visiontransformer_amd import functional as K
     torch.manual_seed(B + H + Ci)

@@ -24,7 +24,7 @@ tgt = torch.rand(32, 3, 256, 256, device=dev) * 2 - 1
 from visiontransformer_amd import functional as K  # noqa: E402
 K.FUSE_GELU = os.environ.get("DSW_FUSE_GELU", "1") != "0"
 K.BATCH_WEIGHT_PREP = os.environ.get("DSW_BATCH_PREP", "1") != "0"
-models.NHWC_ENDS_TRAINING = os.environ.get("DSW_NHWC_ENDS_TRAINING", "0") == "1"
+models.NHWC_ENDS_TRAINING = os.environ.get("DSW_NHWC_ENDS_TRAINING", "1") == "1"
 K.FUSE_RESIDUAL_DROPOUT = os.environ.get("DSW_FUSE_RESID_DROP", "1") != "0"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 t0 = None

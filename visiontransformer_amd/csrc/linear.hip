@@ -791,6 +791,139 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_wgrad_kernel(const bf1
             }
 }
 
+// Weight gradient of a 3x3 convolution with at most 64 input channels (rows of X padded to 64): the layers of a reconstruction tail
+// (DSwinT_arch.py:430-437: 64 -> 256 in front of a PixelShuffle, 64 -> 64, 64 -> 3) run over millions of pixels with
+// tiny outputs, and a 192 x 192 block per tap uses a ninth of its MFMAs there and reads dY nine times.  Here a workgroup
+// owns dW[64 output channels][9 taps x 64 input channels] - the same 36 accumulator tiles on 6 waves - and walks its pixel range in
+// stages of 64 pixels of one image row (W % 64 == 0): dY's tile and a three-row strip of X (pixels x0 - 1 .. x0 + 64 of
+// the rows y - 1, y, y + 1, zero outside the image) go through LDS once, and a tap's operand is the strip read at the
+// tap's row and column offset.  Partials in the layout of linear_wgrad_kernel's convolution mode with Kpr = 64.
+constexpr int CS_THREADS = 384, CS_LSY = 96, CS_LSX = 96, CS_SROWS = 3 * 66;
+constexpr int CS_YP = 64 * 8, CS_XP = CS_SROWS * 8;                  // 16-byte pieces of dY's tile / of the strip
+constexpr int CS_YN = (CS_YP + CS_THREADS - 1) / CS_THREADS, CS_XN = (CS_XP + CS_THREADS - 1) / CS_THREADS;   // per thread: 2, 5
+constexpr size_t CS_LDS = (size_t)(64 * CS_LSY + CS_SROWS * CS_LSX) * sizeof(bf16_t);
+__global__ __launch_bounds__(CS_THREADS) void conv_wgrad_strip_kernel(const bf16_t *__restrict__ dY, long long ldy, const bf16_t *__restrict__ X,
+                                                                      long long ldx, int M, int K, int Np, int rows_per_block, int convH,
+                                                                      int convW, float *__restrict__ partial, int gx) {
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);   // the output-channel blocks of a pixel range on one XCD: they share the strip
+    const int bx = bid % gx, by = bid / gx;
+    extern __shared__ __align__(16) unsigned char smem[];
+    bf16_t *Ys = reinterpret_cast<bf16_t *>(smem);
+    bf16_t *Xs = Ys + 64 * CS_LSY;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int n0 = bx * 64, m_begin = by * rows_per_block;
+    const int rows = max(0, min(M - m_begin, rows_per_block));
+    const int nst = (rows + 63) / 64;
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(dY + (size_t)m_begin * ldy + n0, rows > 0 ? ((size_t)(rows - 1) * ldy + (Np - n0)) * sizeof(bf16_t) : 0);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(X, ((size_t)(M - 1) * ldx + 64) * sizeof(bf16_t));
+
+    uint4 yrA[CS_YN], xrA[CS_XN], yrB[CS_YN], xrB[CS_XN];
+    auto load_stage = [&](int st, uint4 (&yr)[CS_YN], uint4 (&xr)[CS_XN]) {
+        const unsigned ys = (unsigned)((size_t)st * 64 * ldy * sizeof(bf16_t));
+#pragma unroll
+        for (int i = 0; i < CS_YN; ++i) {
+            const int p = tid + CS_THREADS * i;
+            yr[i] = p < CS_YP ? buf_load16(rs_y, (unsigned)(((size_t)(p >> 3) * ldy + (p & 7) * 8) * sizeof(bf16_t)), ys) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        const int ms = m_begin + st * 64;               // the stage's first pixel; all 64 lie in one image row
+        const int xw0 = ms % convW, yh = (ms / convW) % convH;
+#pragma unroll
+        for (int i = 0; i < CS_XN; ++i) {
+            const int p = tid + CS_THREADS * i, srow = p >> 3, dyr = srow / 66, pos = srow - dyr * 66;
+            const int yy = yh + dyr - 1, xx = xw0 + pos - 1;
+            const bool in = p < CS_XP && yy >= 0 && yy < convH && xx >= 0 && xx < convW;
+            const long long src = (long long)ms + (long long)(dyr - 1) * convW + (pos - 1);
+            xr[i] = buf_load16(rs_x, in ? (unsigned)(((size_t)src * ldx + (p & 7) * 8) * sizeof(bf16_t)) : 0x80000000u, 0u);
+        }
+    };
+    auto write_stage = [&](const uint4 (&yr)[CS_YN], const uint4 (&xr)[CS_XN]) {
+#pragma unroll
+        for (int i = 0; i < CS_YN; ++i) {
+            const int p = tid + CS_THREADS * i;
+            if (p < CS_YP) *reinterpret_cast<uint4 *>(Ys + (p >> 3) * CS_LSY + (p & 7) * 8) = yr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CS_XN; ++i) {
+            const int p = tid + CS_THREADS * i;
+            uint4 x = xr[i];
+            // K < 64: column K of the strip's middle row holds ones, which makes column K of the centre tap's result the
+            // bias gradient (K % 4 == 0: element 0 or 4 of its piece); the other taps' column K is not read by the sum
+            if (K < 64 && (p >> 3) / 66 == 1 && (p & 7) == (K >> 3)) {
+                if (K & 4) x.z = (x.z & 0xffff0000u) | 0x3f80u;
+                else x.x = (x.x & 0xffff0000u) | 0x3f80u;
+            }
+            if (p < CS_XP) *reinterpret_cast<uint4 *>(Xs + (p >> 3) * CS_LSX + (p & 7) * 8) = x;
+        }
+    };
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transposing reads as in linear_wgrad_kernel; wave `wave` owns the column tiles 3 wave .. 3 wave + 2 of the 18
+    // (tile j = tap j / 2, input channels 32 (j % 2) ..)
+    const int trq = (lane >> 2) & 3, trp = lane & 3, trg = (lane >> 4) & 1;
+    const bf16_t *ytr = Ys + (4 * hh + trq) * CS_LSY + 16 * trg + 4 * trp;
+    const bf16_t *xtr[3];
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) {
+        const int j = 3 * wave + tb, tap = j >> 1, half = j & 1;
+        xtr[tb] = Xs + ((tap / 3) * 66 + 1 + (tap % 3 - 1) + 4 * hh + trq) * CS_LSX + half * 32 + 16 * trg + 4 * trp;
+    }
+    auto products = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[2], b[3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint2 r0 = lds_read_tr16(ytr + (16 * ks) * CS_LSY + 32 * t), r1 = lds_read_tr16(ytr + (16 * ks + 8) * CS_LSY + 32 * t);
+                a[t] = as_bf16x8(make_uint4(r0.x, r0.y, r1.x, r1.y));
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const uint2 r0 = lds_read_tr16(xtr[t] + (16 * ks) * CS_LSX), r1 = lds_read_tr16(xtr[t] + (16 * ks + 8) * CS_LSX);
+                b[t] = as_bf16x8(make_uint4(r0.x, r0.y, r1.x, r1.y));
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 3; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+    };
+    if (nst > 0) load_stage(0, yrA, xrA);
+    if (nst > 1) load_stage(1, yrB, xrB);
+    for (int st = 0; st < nst; st += 2) {
+        if (st > 0) lds_barrier();
+        write_stage(yrA, xrA);
+        lds_barrier();
+        if (st + 2 < nst) load_stage(st + 2, yrA, xrA);
+        products();
+        if (st + 1 < nst) {
+            lds_barrier();
+            write_stage(yrB, xrB);
+            lds_barrier();
+            if (st + 3 < nst) load_stage(st + 3, yrB, xrB);
+            products();
+        }
+    }
+    float *pb = partial + (size_t)by * Np * 576;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb) {
+            const int j = 3 * wave + tb;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + ta * 32 + rho(r) + 4 * hh;
+                if (n < Np) pb[(size_t)n * 576 + (j >> 1) * 64 + (j & 1) * 32 + l31] = acc[ta][tb][r];
+            }
+        }
+}
+
 // dw[n][t][k] = sum_s partial[s][n][t * Kpr + k] (n < N, k < K, t < ntap); db[n] = the same sum at column K of
 // tap ntap / 2 (the only tap, or the centre one).  A workgroup sums 16 groups of 4 columns, its 16 thread
 // slices taking every 16th partial block; the slices meet in LDS and are added in slice order (a fixed tree:
@@ -1144,9 +1277,25 @@ static void wgrad_split(long long M, int Np, int Kp, int ntap, int *rows_per_blo
     *S = (int)((M + rpb - 1) / rpb);
 }
 
-static size_t wgrad_ws(long long M, int N, int K, int ntap) {
+// the strip kernel takes a 3x3 convolution with at most 64 input channels on images whose width is a multiple of 64
+static bool conv_strip(int K, int convW) { return K <= 64 && K % 4 == 0 && convW > 0 && convW % 64 == 0 && getenv("DSW_CONV_WGRAD_NO_STRIP") == nullptr; }
+static void conv_strip_split(long long M, int Np, int *rows_per_block, int *S) {
+    long long want = 512 / (Np / 64);   // about two workgroups per CU
+    if (want < 1) want = 1;
+    long long rpb = (M + want - 1) / want;
+    rpb = (rpb + 63) / 64 * 64;
+    *rows_per_block = (int)rpb;
+    *S = (int)((M + rpb - 1) / rpb);
+}
+
+static size_t wgrad_ws(long long M, int N, int K, int ntap, int convW = 0) {
     if (M <= 0 || N <= 0 || K <= 0 || M > 0x7fffff00LL) return 0;
     const int Np = (N + 63) / 64 * 64, Kp = (K + 63) / 64 * 64;
+    if (ntap == 9 && conv_strip(K, convW)) {
+        int rpb, S;
+        conv_strip_split(M, Np, &rpb, &S);
+        return (size_t)S * Np * 576;
+    }
     const int TK = wgrad_wide(Kp) ? WgWide::TK : WgNarrow::TK, Kpr = (Kp + TK - 1) / TK * TK;
     int rpb, S;
     wgrad_split(M, Np, Kp, ntap, &rpb, &S);
@@ -1154,7 +1303,7 @@ static size_t wgrad_ws(long long M, int N, int K, int ntap) {
 }
 
 extern "C" size_t dsw_linear_wgrad_workspace(long long M, int N, int K) { return wgrad_ws(M, N, K, 1); }
-extern "C" size_t dsw_conv3x3_wgrad_workspace(int B, int H, int W, int Co, int Ci) { return wgrad_ws((long long)B * H * W, Co, Ci, 9); }
+extern "C" size_t dsw_conv3x3_wgrad_workspace(int B, int H, int W, int Co, int Ci) { return wgrad_ws((long long)B * H * W, Co, Ci, 9, W); }
 
 static int wgrad_launch(const char *who, const void *dy, long long ldy, const void *x, long long ldx, long long M, int N, int K, int convH,
                         int convW, float *dw, float *db, float *workspace, void *stream, const int *live_units = nullptr, int unit_rows = 0) {
@@ -1172,6 +1321,23 @@ static int wgrad_launch(const char *who, const void *dy, long long ldy, const vo
                                       "(ldy=%lld ldx=%lld)", who, Np, Kp, ldy, ldx);
     if (((uintptr_t)dw & 15) || ((uintptr_t)workspace & 15)) return fail(DSW_EUNSUPPORTED, "%s: dw / workspace must be 16-byte aligned", who);
     int rpb, S;
+    if (ntap == 9 && conv_strip(K, convW)) {
+        if (db != nullptr && K == 64) return fail(DSW_EUNSUPPORTED, "%s: the bias gradient rides in a padding column of x, K=%d leaves none", who, K);
+        conv_strip_split(M, Np, &rpb, &S);
+        if ((long long)rpb * ldy * 2 >= 0x7fffffffLL || (size_t)M * ldx * 2 >= 0x80000000ull)
+            return fail(DSW_EUNSUPPORTED, "%s: operands beyond 2 GiB per block (%d rows) or per tensor", who, rpb);
+        hipStream_t st = as_stream(stream);
+        int rc = set_lds((const void *)conv_wgrad_strip_kernel, CS_LDS, who);
+        if (rc) return rc;
+        const int gx = Np / 64;
+        hipLaunchKernelGGL(conv_wgrad_strip_kernel, dim3(gx * S), dim3(CS_THREADS), CS_LDS, st, (const bf16_t *)dy, ldy, (const bf16_t *)x, ldx,
+                           (int)M, K, Np, rpb, convH, convW, workspace, gx);
+        rc = check_launch("conv_wgrad_strip_kernel");
+        if (rc) return rc;
+        const int items = N * (9 * 64 / 4);
+        hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((items + 15) / 16), dim3(256), 0, st, workspace, S, Np, 64, 9, N, K, dw, db);
+        return check_launch("linear_wgrad_reduce_kernel");
+    }
     wgrad_split(M, Np, Kp, ntap, &rpb, &S);
     if ((long long)rpb * (ldy > ldx ? ldy : ldx) * 2 >= 0x7fffffffLL || (ntap > 1 && (size_t)M * ldx * 2 >= 0x80000000ull))
         return fail(DSW_EUNSUPPORTED, "%s: operands beyond 2 GiB per block (%d rows) or per tensor", who, rpb);

@@ -315,8 +315,8 @@ class DSWTransformer(nn.Module):
         # Without autograd under bf16 autocast the stem and the reconstruction tail stay on NHWC tensors and on the
         # package's convolution kernel (NHWC_ENDS): no NCHW <-> NHWC copies around them, the stem writes the fp32
         # stream directly (3 input channels padded to 4), the tail never materialises an NCHW tensor.  With autograd
-        # the same path works (NHWC_ENDS_TRAINING) but is off: the weight-gradient kernel, built for 192-wide blocks,
-        # is slower than MIOpen on the tail's 16- to 64-channel layers (training step 65.4 -> 69.6 ms with it on).
+        # the same path runs (NHWC_ENDS_TRAINING): the weight gradients of the tail's 16- to 64-channel layers have a
+        # kernel of their own (a three-row strip of x through LDS, all nine taps in one workgroup).
         nhwc_ends = (NHWC_ENDS and (NHWC_ENDS_TRAINING or not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
                      and K.autocast_dtype(x.dtype) == torch.bfloat16)
         xs = None
@@ -352,7 +352,7 @@ class DSWTransformer(nn.Module):
 # ------------------------------------------------------------------------------------------------
 DSMSA_BF16_INPUT = True   # inference under bf16 autocast: the norm in front of DS-MSA writes bf16 (False: fp32, as the reference's norm does)
 NHWC_ENDS = True     # False: DSWTransformer's stem and reconstruction tail always run as stock NCHW convolutions
-NHWC_ENDS_TRAINING = False   # True: the NHWC ends with autograd as well (see DSWTransformer.forward)
+NHWC_ENDS_TRAINING = True    # False: with autograd the two ends run as stock NCHW convolutions (see DSWTransformer.forward)
 NHWC_STREAM = True   # False: MSFTransformer runs its trunk module by module on NCHW tensors, as the reference does
 
 
