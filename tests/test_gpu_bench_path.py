@@ -525,3 +525,53 @@ def test_nhwc_reconstruction_tail_gradients_against_the_stock_convolutions(cuda0
     for n in g0:
         assert g1[n].shape == g0[n].shape
         assert rel_err(g1[n], g0[n]) < 3e-2, n
+
+@pytest.mark.gpu
+def test_msft_nhwc_stem_and_tail_in_training_against_the_stock_convolutions(cuda0):
+    """MSFTransformer under bf16 autocast with autograd: the stem and the reconstruction tail on the NHWC kernels
+    (models.NHWC_ENDS, NHWC_ENDS_TRAINING; msft_arch.py builds the same two ends as DSwinT_arch.py:426-437) against the
+    same network with the two ends as stock NCHW convolutions: output, input gradient and the gradients of the ends'
+    own parameters.  Both runs are bf16; they differ by the summation order of the convolutions."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd import models
+    torch.manual_seed(3)
+    cfg = dict(models.MSFT_CONFIG_C)
+    cfg.update(n_blocks=1, n_sub_blocks=1)
+    net = models.MSFTransformer(**cfg).to(cuda0).train()
+    for m in net.modules():
+        if hasattr(m, "attn_drop"):
+            m.attn_drop = 0.0
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    x = torch.rand(2, 3, 64, 64, device=cuda0)
+    tgt = torch.rand(2, 3, 256, 256, device=cuda0)
+    calls = []
+    real_call = K.call
+
+    def spy(name, *args):
+        calls.append(name)
+        return real_call(name, *args)
+
+    res = []
+    for ends in (True, False):
+        models.NHWC_ENDS_TRAINING = ends
+        K.call = spy
+        calls.clear()
+        try:
+            net.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(xg)
+            torch.nn.functional.l1_loss(y.float(), tgt).backward()
+        finally:
+            models.NHWC_ENDS_TRAINING = True
+            K.call = real_call
+        n_conv = calls.count("dsw_conv3x3_wgrad")
+        res.append((y.detach().float(), xg.grad.clone(), {n: p.grad.float().clone() for n, p in net.named_parameters()
+                                                          if n.startswith(("feature_extractor", "img_reconstruction"))}, n_conv))
+    (y1, gx1, gp1, c1), (y0, gx0, gp0, c0) = res
+    assert c1 - c0 == 1 + sum(isinstance(m, torch.nn.Conv2d) for m in net.img_reconstruction)   # the stem and every tail convolution
+    assert y1.shape == (2, 3, 256, 256) and rel_err(y1, y0) < 2e-2
+    assert rel_err(gx1, gx0) < 5e-2
+    for n in gp0:
+        assert rel_err(gp1[n], gp0[n]) < 5e-2, n

@@ -481,15 +481,36 @@ class MSFTransformer(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        x = self.feature_extractor(self.padding(x))
-        if NHWC_STREAM and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.dim % 8 == 0:
+        x = self.padding(x)
+        nhwc = NHWC_STREAM and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.dim % 8 == 0
+        # the stem and the reconstruction tail on NHWC tensors and on the package's convolution kernels, as in
+        # DSWTransformer.forward (msft_arch.py builds the same two ends): under bf16 autocast, with or without autograd
+        nhwc_ends = (nhwc and NHWC_ENDS and (NHWC_ENDS_TRAINING or not torch.is_grad_enabled()) and x.dtype == torch.float32
+                     and K.autocast_dtype(x.dtype) == torch.bfloat16)
+        xs = None
+        if nhwc_ends:
+            xs = F.pad(x.permute(0, 2, 3, 1), (0, -x.shape[1] % 4))
+            if not K.conv3x3_nhwc_infer_ok(xs.shape, xs.dtype, self.feature_extractor, "pad_in4"):
+                xs = None
+            elif torch.is_grad_enabled():
+                xs = K.conv3x3_nhwc_variant(xs, self.feature_extractor, "pad_in4").float()
+            else:
+                xs = K.conv3x3_nhwc_infer(xs, self.feature_extractor, "pad_in4", out_dtype=torch.float32)
+        if xs is None:
+            x = self.feature_extractor(x)
+        if nhwc:
             # the trunk on a channels-last fp32 stream (the attention modules work on token rows: every NCHW <-> token
             # copy of the blocks falls away, and the convolutions between them run in the NHWC kernels)
-            xs = x.permute(0, 2, 3, 1).float().contiguous()
+            if xs is None:
+                xs = x.permute(0, 2, 3, 1).float().contiguous()
             y = xs
             for blk in self.layers:
                 y = blk.forward_nhwc(y)
             y = _conv3x3_nhwc(y, self.feature_transition) + xs
+            steps = _tail_plan(self.img_reconstruction, y) if nhwc_ends else None
+            if steps is not None:
+                x = _tail_nhwc(self.img_reconstruction, y, steps)
+                return x[:, :, :H * self.scale_factor, :W * self.scale_factor]
             x = y.permute(0, 3, 1, 2)
             if not torch.is_autocast_enabled("cuda"):
                 x = x.contiguous()
