@@ -598,7 +598,10 @@ int dsw_conv3x3_nhwc_residual(const void *x, int x_dtype, long long ldx, int B, 
 /* Its weight and bias gradient: dw[co][t][ci] = sum_px dy[px][co] x[px + off(t)][ci] (tap-major, fp32
  * [Co][9][Ci]), db[co] = sum_px dy[px][co]; dy, x bf16 in zero-padded rows as for dsw_linear_wgrad (x_copy
  * of the forward call has that form).  The input gradient is the same convolution applied to dy with the
- * flipped, transposed weight.  workspace: dsw_conv3x3_wgrad_workspace(B, H, W, Co, Ci) floats. */
+ * flipped, transposed weight.  workspace: dsw_conv3x3_wgrad_workspace(B, H, W, Co, Ci) floats.
+ * Ci <= 64 on images whose width is a multiple of 64 (the 16- to 64-channel layers of the reconstruction tail,
+ * DSwinT_arch.py:430-437, at 128 x 128 and 256 x 256 pixels per patch) takes a kernel of its own: a workgroup owns
+ * dw[64 output channels][9 taps][64] and reads a three-row strip of x through LDS once for all nine taps. */
 size_t dsw_conv3x3_wgrad_workspace(int B, int H, int W, int Co, int Ci);
 int dsw_conv3x3_wgrad(const void *dy, long long ldy, const void *x, long long ldx, int B, int H, int W, int Co,
                       int Ci, float *dw, float *db, float *workspace, void *stream);
