@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """dsw_linear_wgrad at the bench shapes (131 072 tokens): q|k|v (N 540, K 180), out projection (N 180, K 180), MLP
-(N 360, K 180 and N 180, K 360), medians of five rounds.  DSW_WGRAD_WGS sets the workgroup count aimed at."""
+(N 360, K 180 and N 180, K 360), medians of five rounds; WGRAD_SHAPES=msft: the widths of msft's fuse block.  DSW_WGRAD_WGS sets the workgroup count aimed at."""
 import os
 import statistics
 import sys
@@ -15,7 +15,10 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 c64 = lambda n: (n + 63) // 64 * 64
 M = 131072
-for N, K in ((540, 180), (180, 180), (360, 180), (180, 360)):
+SHAPES = ((540, 180), (180, 180), (360, 180), (180, 360))
+if os.environ.get("WGRAD_SHAPES") == "msft":    # msft's fuse block: C = 216
+    SHAPES = ((648, 216), (432, 216), (216, 432), (216, 216))
+for N, K in SHAPES:
     dy = torch.zeros(M, c64(N), device=dev, dtype=torch.bfloat16)
     dy[:, :N] = torch.randn(M, N, device=dev).bfloat16()
     x = torch.zeros(M, c64(K), device=dev, dtype=torch.bfloat16)
