@@ -595,6 +595,11 @@ int dsw_conv3x3_nhwc(const void *x, int x_dtype, long long ldx, int B, int H, in
 int dsw_conv3x3_nhwc_residual(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p, int wrows,
                               int ldw, const float *bias, int N, const float *resid, long long ld_resid, float *out,
                               long long ldo, int ncols, void *stream);
+/* The same with the bf16 copy of x that dsw_conv3x3_nhwc leaves for the weight gradient (x_copy, ld_copy as there):
+ * the training forward of a residual block's closing convolution. */
+int dsw_conv3x3_nhwc_residual_copy(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p,
+                                   int wrows, int ldw, const float *bias, int N, const float *resid, long long ld_resid,
+                                   float *out, long long ldo, int ncols, void *x_copy, long long ld_copy, void *stream);
 /* Its weight and bias gradient: dw[co][t][ci] = sum_px dy[px][co] x[px + off(t)][ci] (tap-major, fp32
  * [Co][9][Ci]), db[co] = sum_px dy[px][co]; dy, x bf16 in zero-padded rows as for dsw_linear_wgrad (x_copy
  * of the forward call has that form).  The input gradient is the same convolution applied to dy with the

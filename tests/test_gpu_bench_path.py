@@ -575,3 +575,36 @@ def test_msft_nhwc_stem_and_tail_in_training_against_the_stock_convolutions(cuda
     assert rel_err(gx1, gx0) < 5e-2
     for n in gp0:
         assert rel_err(gp1[n], gp0[n]) < 5e-2, n
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C", [(2, 20, 24, 180), (1, 8, 64, 64)])
+def test_closing_convolution_with_the_skip_connection_in_training(cuda0, B, H, W, C):
+    """out_layer(layers(x)) + x (DSwinT_arch.py:373-374) with autograd under bf16 autocast: the skip connection in the
+    convolution's epilogue (dsw_conv3x3_nhwc_residual_copy, fp32 result, no bf16 rounding of the convolution's output)
+    against the convolution kernel followed by an addition: result and all four gradients."""
+    from visiontransformer_amd import functional as K
+    torch.manual_seed(C)
+    conv = torch.nn.Conv2d(C, C, 3, 1, 1).to(cuda0)
+    x = torch.randn(B, H, W, C, device=cuda0)
+    r = torch.randn(B, H, W, C, device=cuda0)
+    dy = torch.randn(B, H, W, C, device=cuda0)
+    res = []
+    for fuse in (True, False):
+        K.FUSE_CONV_RESIDUAL_TRAINING = fuse
+        try:
+            conv.zero_grad(set_to_none=True)
+            xg, rg = x.clone().requires_grad_(), r.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = K.conv3x3_nhwc_residual(xg, conv, rg)
+                assert (y is not None) == fuse
+                if y is None:
+                    y = K.conv3x3_nhwc(xg, conv) + rg
+            y.backward(dy)
+        finally:
+            K.FUSE_CONV_RESIDUAL_TRAINING = True
+        res.append((y.detach().float(), xg.grad.clone(), rg.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    a, b = res
+    assert a[0].dtype == torch.float32 and rel_err(a[0] - r, b[0] - r) < 5e-3
+    assert torch.equal(a[2], dy) and torch.equal(b[2], dy)
+    for i in (1, 3, 4):
+        assert rel_err(a[i], b[i]) < 2e-2, i

@@ -26,6 +26,7 @@ K.FUSE_GELU = os.environ.get("DSW_FUSE_GELU", "1") != "0"
 K.BATCH_WEIGHT_PREP = os.environ.get("DSW_BATCH_PREP", "1") != "0"
 models.NHWC_ENDS_TRAINING = os.environ.get("DSW_NHWC_ENDS_TRAINING", "1") == "1"
 K.FUSE_RESIDUAL_DROPOUT = os.environ.get("DSW_FUSE_RESID_DROP", "1") != "0"
+K.FUSE_CONV_RESIDUAL_TRAINING = os.environ.get("DSW_FUSE_CONV_RESID", "1") != "0"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 t0 = None
 for i in range(steps):

@@ -90,6 +90,8 @@ SIGNATURES = {
     "dsw_rezero_dropout_seeded_bwd": (_I, [_P, _P, _I, ctypes.c_longlong, _P, _F, ctypes.c_ulonglong, ctypes.c_longlong, _I, _P,
                                            ctypes.c_longlong, _P, _P]),
     "dsw_conv3x3_nhwc": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, ctypes.c_longlong, _I, _P, ctypes.c_longlong, _P]),
+    "dsw_conv3x3_nhwc_residual_copy": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _I,
+                                            _P, ctypes.c_longlong, _P]),
     "dsw_conv3x3_nhwc_residual": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _I, _P]),
     "dsw_conv3x3_wgrad_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "dsw_conv3x3_wgrad": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

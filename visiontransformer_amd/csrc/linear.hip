@@ -1261,6 +1261,15 @@ extern "C" int dsw_conv3x3_nhwc_residual(const void *x, int x_dtype, long long l
     return conv3x3_impl(x, x_dtype, ldx, B, H, W, C, w_p, wrows, ldw, bias, N, out, DSW_F32, ldo, ncols, nullptr, 0, resid, ld_resid, stream);
 }
 
+extern "C" int dsw_conv3x3_nhwc_residual_copy(const void *x, int x_dtype, long long ldx, int B, int H, int W, int C, const void *w_p,
+                                              int wrows, int ldw, const float *bias, int N, const float *resid, long long ld_resid,
+                                              float *out, long long ldo, int ncols, void *x_copy, long long ld_copy, void *stream) {
+    DSW_REQUIRE(resid, "dsw_conv3x3_nhwc_residual_copy: null pointer");
+    if (ld_resid < ncols || ld_resid % 4 || ((uintptr_t)resid & 15))
+        return fail(DSW_EUNSUPPORTED, "dsw_conv3x3_nhwc_residual_copy: the residual needs rows of >= %d floats, a multiple of 4, 16-byte aligned", ncols);
+    return conv3x3_impl(x, x_dtype, ldx, B, H, W, C, w_p, wrows, ldw, bias, N, out, DSW_F32, ldo, ncols, x_copy, ld_copy, resid, ld_resid, stream);
+}
+
 static void wgrad_split(long long M, int Np, int Kp, int ntap, int *rows_per_block, int *S) {
     const int TN = wgrad_wide(Kp) ? WgWide::TN : WgNarrow::TN, TK = wgrad_wide(Kp) ? WgWide::TK : WgNarrow::TK;
     const int nb = ((Np + TN - 1) / TN) * ((Kp + TK - 1) / TK) * ntap;

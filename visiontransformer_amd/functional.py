@@ -2030,17 +2030,26 @@ class _Conv3x3Fn(torch.autograd.Function):
     flipped, transposed weight) and weight / bias gradient (dsw_conv3x3_wgrad) on the matrix cores."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, resid=None):
+        # resid (fp32, the result's shape): the result is resid + conv(x) as fp32, the skip connection of the residual
+        # block this convolution closes (DSwinT_arch.py:373-374) added in the kernel's epilogue; its gradient is dy itself
         B, H, W, Ci = x.shape
         Co = weight.shape[0]
         M = B * H * W
         x2 = x.reshape(M, Ci)
         b32 = None if bias is None else bias.detach().float().contiguous()
-        out = torch.empty(B, H, W, Co, dtype=act, device=x.device)
+        out = torch.empty(B, H, W, Co, dtype=act if resid is None else torch.float32, device=x.device)
         xk = _mark_padded(torch.empty(M, _ceil_pad(Ci), dtype=torch.bfloat16, device=x.device)) if ctx.needs_input_grad[1] else None
-        _conv3x3_call(x2, B, H, W, Ci, _conv3x3_operand(weight), b32, Co, out, xk)
+        if resid is None:
+            _conv3x3_call(x2, B, H, W, Ci, _conv3x3_operand(weight), b32, Co, out, xk)
+        else:
+            w_p = _conv3x3_operand(weight)
+            call("dsw_conv3x3_nhwc_residual_copy", _dptr(x2), dtype_code(x2.dtype), x2.stride(0), B, H, W, Ci, ptr(w_p), w_p.shape[0], w_p.shape[1],
+                 None if b32 is None else ptr(b32), Co, ptr(resid), Co, ptr(out), Co, Co, None if xk is None else ptr(xk),
+                 0 if xk is None else xk.shape[1], stream(out.device))
         ctx.save_for_backward(xk if xk is not None else x2, weight)
         ctx.meta = (x.shape, x.dtype, None if bias is None else bias.dtype)
+        ctx.with_resid = resid is not None
         return out
 
     @staticmethod
@@ -2079,7 +2088,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             dw = dwt.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous().to(weight.dtype)
             if bdt is not None:
                 db = (dbf if fused_db else colsum(dyk)[:Co]).to(bdt)
-        return dx, dw, db, None
+        return dx, dw, db, None, (dy if ctx.with_resid and ctx.needs_input_grad[4] else None)
 
 
 def conv3x3_nhwc(x, conv):
@@ -2094,9 +2103,10 @@ def conv3x3_nhwc(x, conv):
           and B * H * W * max(_ceil_pad(Ci), _ceil_pad(conv.out_channels)) * 4 < 2 ** 31)
     if not ok:
         return None
-    return _run(_Conv3x3Fn, x.contiguous(), conv.weight, conv.bias, act)
+    return _run(_Conv3x3Fn, x.contiguous(), conv.weight, conv.bias, act, None)
 
 
+FUSE_CONV_RESIDUAL_TRAINING = True   # False: with autograd the skip connection behind a closing convolution is an addition of its own
 _CONV_VARIANTS = ("plain", "shuffle2", "pad_in4", "pad_out4")
 
 
@@ -2158,15 +2168,19 @@ def conv3x3_nhwc_infer(x, conv, variant="plain", out_dtype=torch.bfloat16):
 
 
 def conv3x3_nhwc_residual(x, conv, resid):
-    """Without autograd under bf16 autocast: resid + conv(x) as fp32 in one kernel (dsw_conv3x3_nhwc_residual), the
-    closing convolution of a residual block with the block's skip connection (DSwinT_arch.py:373-374, :501); None
-    when the call is not one the kernel takes."""
-    if torch.is_grad_enabled() or autocast_dtype(None) != torch.bfloat16 or not x.is_cuda:
+    """Under bf16 autocast: resid + conv(x) as fp32 in one kernel (dsw_conv3x3_nhwc_residual; with autograd
+    dsw_conv3x3_nhwc_residual_copy through _Conv3x3Fn), the closing convolution of a residual block with the block's
+    skip connection (DSwinT_arch.py:373-374, :501); None when the call is not one the kernel takes."""
+    if autocast_dtype(None) != torch.bfloat16 or not x.is_cuda:
         return None
     B, H, W, Ci = x.shape
     if not (conv3x3_nhwc_infer_ok(x.shape, x.dtype, conv) and resid.is_cuda and resid.dtype == torch.float32 and resid.is_contiguous()
             and resid.shape == (B, H, W, conv.out_channels) and resid.data_ptr() % 16 == 0):
         return None
+    if torch.is_grad_enabled():
+        if not FUSE_CONV_RESIDUAL_TRAINING:
+            return None
+        return _run(_Conv3x3Fn, x.contiguous(), conv.weight, conv.bias, torch.bfloat16, resid)
     x = x.contiguous()
     w_p, b32, Co, _ = _conv3x3_variant(conv, "plain")
     out = torch.empty(B, H, W, Co, dtype=torch.float32, device=x.device)
@@ -2219,7 +2233,7 @@ def conv3x3_nhwc_variant(x, conv, variant="plain"):
         extra = -weight.shape[0] % 4
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, extra))
         bias = None if bias is None else torch.nn.functional.pad(bias, (0, extra))
-    return _Conv3x3Fn.apply(x.contiguous(), weight, bias, torch.bfloat16)
+    return _Conv3x3Fn.apply(x.contiguous(), weight, bias, torch.bfloat16, None)
 
 
 # ---------------------------------------------------------------------------------------------

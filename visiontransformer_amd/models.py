@@ -361,6 +361,12 @@ def _pointwise(conv):
     return _Stacked(conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
 
 
+def _conv3x3_nhwc_plus(x, conv, resid):
+    """conv(x) + resid on NHWC tensors: in the convolution's epilogue where the kernel takes the call"""
+    y = K.conv3x3_nhwc_residual(x, conv, resid) if resid.dtype == torch.float32 else None
+    return y if y is not None else _conv3x3_nhwc(x, conv) + resid
+
+
 def _conv3x3_nhwc(x, conv):
     y = K.conv3x3_nhwc(x, conv)   # bf16 autocast: NHWC kernels (fwd and bwd), no layout copies
     if y is not None:
@@ -448,7 +454,7 @@ class MSFTResidualBlock(nn.Module):
         y = x
         for blk in self.layers:
             y = blk.forward_nhwc(y)
-        return _conv3x3_nhwc(y, self.out_layer) + x
+        return _conv3x3_nhwc_plus(y, self.out_layer, x)
 
 
 class MSFTransformer(nn.Module):
@@ -506,7 +512,7 @@ class MSFTransformer(nn.Module):
             y = xs
             for blk in self.layers:
                 y = blk.forward_nhwc(y)
-            y = _conv3x3_nhwc(y, self.feature_transition) + xs
+            y = _conv3x3_nhwc_plus(y, self.feature_transition, xs)
             steps = _tail_plan(self.img_reconstruction, y) if nhwc_ends else None
             if steps is not None:
                 x = _tail_nhwc(self.img_reconstruction, y, steps)
