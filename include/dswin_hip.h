@@ -354,6 +354,12 @@ int dsw_linear_rmsnorm_gated_silu(const void *a, int a_dtype, long long lda, lon
  * The gated product is taken on the fp32 pre-activations and rounded to bf16 once, as the second product's operand
  * (the separate kernels, dsw_linear_rmsnorm_gated_silu and dsw_linear_residual, also round gate and content to bf16
  * as they store them: 4e-3 between the two forms). */
+/* Its operand images from the modules' fp32 parameters in one launch: gate_w, content_w [H][C], fc2_w [N][H] row-major,
+ * biases and norm_w (the RMSNorm weight [C]) may be NULL (zero / one); w1c, b1c, w2c, b2 as described above with
+ * ceil(H / 32) chunks. */
+int dsw_mlp_gated_prep(const float *gate_w, const float *content_w, const float *gate_b, const float *content_b,
+                       const float *fc2_w, const float *fc2_b, const float *norm_w, int H, int C, int N, void *w1c,
+                       float *b1c, void *w2c, float *b2, void *stream);
 int dsw_mlp_gated_residual(const float *x, long long ldx, long long M, int C, float norm_eps, const void *w1c,
                            const float *b1c, const void *w2c, const float *b2, int hidden_chunks, const float *r,
                            float *y, long long ldy, void *stream);

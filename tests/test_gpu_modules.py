@@ -804,6 +804,15 @@ def test_inference_with_the_mlp_in_one_kernel(cuda0, dim, scale, shape):
         assert ("dsw_mlp_gated_residual" in calls) == fuse
     y1, y0 = outs
     assert y1.dtype == torch.float32 and y1.shape == x.shape
+    # the operand images: the preparation kernel against the same function written as tensor expressions, bit for bit
+    ps = (mlp.fc1_gate.weight, mlp.fc1_content.weight, mlp.fc1_gate.bias, mlp.fc1_content.bias, mlp.fc2.weight, mlp.fc2.bias, norm.weight)
+    by_kernel = K.mlp_gated_operands(*ps)
+    K.MLP_PREP_KERNEL = False
+    try:
+        by_torch = K.mlp_gated_operands(*ps)
+    finally:
+        K.MLP_PREP_KERNEL = True
+    assert by_kernel[4] == by_torch[4] and all(torch.equal(a, b) for a, b in zip(by_kernel[:4], by_torch[:4]))
     with torch.no_grad():
         n = norm(x)
         ref = r * mlp.fc2(torch.nn.functional.silu(mlp.fc1_gate(n)) * mlp.fc1_content(n))

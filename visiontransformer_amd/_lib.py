@@ -56,6 +56,7 @@ SIGNATURES = {
     "dsw_linear_gated_silu": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _P, ctypes.c_longlong, _P]),
     "dsw_linear_rmsnorm": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _F, _P, _I, _I, _P, _I, _P, _I, ctypes.c_longlong, _I, _P]),
     "dsw_linear_rmsnorm_gated_silu": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _F, _P, _I, _I, _P, _P, ctypes.c_longlong, _P]),
+    "dsw_mlp_gated_prep": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dsw_mlp_gated_residual": (_I, [_P, ctypes.c_longlong, ctypes.c_longlong, _I, _F, _P, _P, _P, _P, _I, _P, _P, ctypes.c_longlong, _P]),
     "dsw_linear_gelu": (_I, [_P, _I, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _I, _I, _P, _I, _P, ctypes.c_longlong, _I, _P, ctypes.c_longlong,
                              _P, ctypes.c_longlong, _P]),

@@ -293,6 +293,58 @@ extern "C" int dsw_mlp_gated_residual(const float *x, long long ldx, long long M
     return check_launch("mlp_gated_residual_kernel");
 }
 
+namespace dsw {
+namespace {
+// the operand images of mlp_gated_residual_kernel from the modules' fp32 parameters, one launch
+__global__ __launch_bounds__(256) void mlp_gated_prep_kernel(const float *__restrict__ gate_w, const float *__restrict__ content_w,
+                                                             const float *__restrict__ gate_b, const float *__restrict__ content_b,
+                                                             const float *__restrict__ fc2_w, const float *__restrict__ fc2_b,
+                                                             const float *__restrict__ norm_w, int H, int C, int N, int nchunk,
+                                                             bf16_t *__restrict__ w1c, float *__restrict__ b1c, bf16_t *__restrict__ w2c,
+                                                             float *__restrict__ b2) {
+    const int R1 = nchunk * 64 * ML_K, R2 = nchunk * ML_N * ML_HC, R3 = nchunk * 64;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < R1) {
+        const int c = i / (64 * ML_K), r = (i / ML_K) % 64, k = i % ML_K;
+        const int h = 32 * c + (r & 31);
+        const float *w = r < 32 ? gate_w : content_w;
+        w1c[i] = f32_to_bf16((h < H && k < C) ? w[(size_t)h * C + k] * (norm_w != nullptr ? norm_w[k] : 1.f) : 0.f);
+        return;
+    }
+    i -= R1;
+    if (i < R2) {
+        // position p of a chunk's 32 hidden columns: every 16 in the order 0-3, 8-11, 4-7, 12-15
+        const int c = i / (ML_N * ML_HC), o = (i / ML_HC) % ML_N, p = i % ML_HC;
+        const int q = p & 15, h = 32 * c + (p & 16) + 8 * ((q >> 2) & 1) + 4 * (q >> 3) + (q & 3);
+        w2c[i] = f32_to_bf16((o < N && h < H) ? fc2_w[(size_t)o * H + h] : 0.f);
+        return;
+    }
+    i -= R2;
+    if (i < R3) {
+        const int c = i / 64, r = i % 64, h = 32 * c + (r & 31);
+        const float *b = r < 32 ? gate_b : content_b;
+        b1c[i] = (b != nullptr && h < H) ? b[h] : 0.f;
+        return;
+    }
+    i -= R3;
+    if (i < ML_N) b2[i] = (fc2_b != nullptr && i < N) ? fc2_b[i] : 0.f;
+}
+}  // namespace
+}  // namespace dsw
+
+extern "C" int dsw_mlp_gated_prep(const float *gate_w, const float *content_w, const float *gate_b, const float *content_b, const float *fc2_w,
+                                  const float *fc2_b, const float *norm_w, int H, int C, int N, void *w1c, float *b1c, void *w2c, float *b2,
+                                  void *stream) {
+    if (H <= 0 || C <= 0 || N <= 0 || C > ML_K || N > ML_N || (H + 31) / 32 > ML_MAXCHUNKS)
+        return fail(DSW_EUNSUPPORTED, "dsw_mlp_gated_prep: H=%d C=%d N=%d (C <= %d, N <= %d, H <= %d)", H, C, N, ML_K, ML_N, 32 * ML_MAXCHUNKS);
+    DSW_REQUIRE(gate_w && content_w && fc2_w && w1c && b1c && w2c && b2, "dsw_mlp_gated_prep: null pointer");
+    const int nchunk = (H + 31) / 32;
+    const int total = nchunk * 64 * ML_K + nchunk * ML_N * ML_HC + nchunk * 64 + ML_N;
+    hipLaunchKernelGGL(mlp_gated_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), gate_w, content_w, gate_b, content_b,
+                       fc2_w, fc2_b, norm_w, H, C, N, nchunk, (bf16_t *)w1c, b1c, (bf16_t *)w2c, b2);
+    return check_launch("mlp_gated_prep_kernel");
+}
+
 #ifdef ML_STAMPS
 extern "C" int dsw_debug_read_mlp_stamps(unsigned long long *host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dsw::g_mlp_stamps), (size_t)n * sizeof(unsigned long long));

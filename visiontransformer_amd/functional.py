@@ -1570,6 +1570,7 @@ def _folded_weight(weight, norm_weight):
 
 
 FUSE_MLP = True   # False: mlp_gated_residual always declines (the MLP runs as two projection kernels)
+MLP_PREP_KERNEL = True   # False: mlp_gated_operands builds the images with tensor expressions (tests)
 
 
 def mlp_gated_operands(gate_w, content_w, gate_b, content_b, fc2_w, fc2_b, norm_weight):
@@ -1581,6 +1582,16 @@ def mlp_gated_operands(gate_w, content_w, gate_b, content_b, fc2_w, fc2_b, norm_
     dev = gate_w.device
     nch = (H + 31) // 32
     Hp = nch * 32
+    ps = (gate_w, content_w, gate_b, content_b, fc2_w, fc2_b, norm_weight)
+    if MLP_PREP_KERNEL and gate_w.is_cuda and all(p is None or (p.dtype == torch.float32 and p.is_contiguous()) for p in ps):
+        # one launch (dsw_mlp_gated_prep); the tensor expressions below are the same function for other dtypes
+        w1c = torch.empty(nch, 64, 192, dtype=torch.bfloat16, device=dev)
+        b1c = torch.empty(nch, 64, dtype=torch.float32, device=dev)
+        w2c = torch.empty(nch, 192, 32, dtype=torch.bfloat16, device=dev)
+        b2 = torch.empty(192, dtype=torch.float32, device=dev)
+        call("dsw_mlp_gated_prep", *(None if p is None else ptr(p.detach()) for p in ps), H, C, N, ptr(w1c), ptr(b1c), ptr(w2c), ptr(b2),
+             stream(dev))
+        return w1c, b1c, w2c, b2, nch
     g = norm_weight.detach().float()[None, :] if norm_weight is not None else 1.0
     w1 = torch.zeros(nch, 2, 32, 192, device=dev)
     b1 = torch.zeros(nch, 2, 32, device=dev)
