@@ -58,6 +58,25 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == 1 and b"multiples of the window size" in lib.dswin_last_error_string()
 
 
+def test_argument_errors_of_the_one_kernel_mlp():
+    """dsw_mlp_gated_residual / dsw_mlp_gated_prep refuse widths beyond their tiles and misaligned operands before any launch"""
+    import ctypes as C
+    from visiontransformer_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    f = C.c_float(1e-6)
+    rc = lib.dsw_mlp_gated_residual(p, 200, 4, 200, f, p, p, p, p, 12, p, p, 200, None)
+    assert rc == 2 and b"C=200" in lib.dswin_last_error_string()
+    rc = lib.dsw_mlp_gated_residual(p, 180, 4, 180, f, p, p, p, p, 17, p, p, 180, None)
+    assert rc == 2 and b"hidden chunks" in lib.dswin_last_error_string()
+    rc = lib.dsw_mlp_gated_residual(C.c_void_p(p.value + 4), 180, 4, 180, f, p, p, p, p, 12, p, p, 180, None)
+    assert rc == 2 and b"16-byte aligned" in lib.dswin_last_error_string()
+    assert lib.dsw_mlp_gated_residual(p, 180, 0, 180, f, p, p, p, p, 12, p, p, 180, None) == 0      # no rows: nothing to do
+    rc = lib.dsw_mlp_gated_prep(p, p, None, None, p, None, None, 600, 180, 180, p, p, p, p, None)
+    assert rc == 2 and b"H=600" in lib.dswin_last_error_string()
+
+
 def test_cpu_tensors_are_refused():
     import torch
     from visiontransformer_amd import functional as K
