@@ -739,23 +739,27 @@ __global__ __launch_bounds__(256) void sd_stencil_fwd_kernel(const float *__rest
 // image), bf16 rows of 64 with columns 36.. zero.  Then dx = G . Wf and dWf = G^T . x are plain GEMMs
 // (Wf[4 t + o][c] = w0[o][c][t]), and column 16 + o of G summed over pixels is db0[o].
 __global__ __launch_bounds__(256) void sd_gather_bwd_kernel(const float *__restrict__ dt0, int B, int H, int W, bf16_t *__restrict__ G) {
-    const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+    // thread = (pixel, 16-byte piece of its 128-byte row): piece i < 4 holds taps 2 i and 2 i + 1, piece 4 tap 8 and
+    // zeros, pieces 5..7 zeros - eight neighbouring lanes write one whole row (a thread per pixel writing its 128
+    // bytes in eight stores touched 64 lines per store instruction: 11.5 us for 17 MB)
+    const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long px = gi >> 3;
+    const int piece = (int)(gi & 7);
     if (px >= (long long)B * H * W) return;
     const int xw = (int)(px % W), yh = (int)((px / W) % H);
-    uint32_t out[32];
+    uint32_t out[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        float4 v = f4zero();
-        if (yh - dy >= 0 && yh - dy < H && xw - dx >= 0 && xw - dx < W) v = *reinterpret_cast<const float4 *>(dt0 + (size_t)(px - dy * W - dx) * 4);
-        out[2 * t] = pack_bf16(v.x, v.y);
-        out[2 * t + 1] = pack_bf16(v.z, v.w);
+    for (int k = 0; k < 2; ++k) {
+        const int t = 2 * piece + k;
+        if (t < 9) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            float4 v = f4zero();
+            if (yh - dy >= 0 && yh - dy < H && xw - dx >= 0 && xw - dx < W) v = *reinterpret_cast<const float4 *>(dt0 + (size_t)(px - dy * W - dx) * 4);
+            out[2 * k] = pack_bf16(v.x, v.y);
+            out[2 * k + 1] = pack_bf16(v.z, v.w);
+        }
     }
-#pragma unroll
-    for (int i = 18; i < 32; ++i) out[i] = 0u;
-    uint4 *dst = reinterpret_cast<uint4 *>(G + (size_t)px * 64);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+    *reinterpret_cast<uint4 *>(G + (size_t)px * 64 + piece * 8) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 }  // namespace dsw
@@ -846,7 +850,8 @@ extern "C" int dsw_sd_gather_bwd(const float *dt0, int B, int H, int W, void *G,
     if (B <= 0 || H <= 0 || W <= 0) return fail(DSW_EINVAL, "dsw_sd_gather_bwd: bad sizes B=%d H=%d W=%d", B, H, W);
     DSW_REQUIRE(dt0 && G, "dsw_sd_gather_bwd: null pointer");
     const long long n = (long long)B * H * W;
-    hipLaunchKernelGGL(sd_gather_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), dt0, B, H, W, (bf16_t *)G);
+    if (n > 0x0fffffffLL) return fail(DSW_EUNSUPPORTED, "dsw_sd_gather_bwd: %lld pixels", n);
+    hipLaunchKernelGGL(sd_gather_bwd_kernel, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, as_stream(stream), dt0, B, H, W, (bf16_t *)G);
     return check_launch("sd_gather_bwd_kernel");
 }
 
