@@ -410,17 +410,21 @@ __global__ void sd_stage_b_kernel(const float *__restrict__ u, const float *__re
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * 4 * Hw * Ww) return;
     const int c = i % Ww, r = (i / Ww) % Hw, o = (i / (Ww * Hw)) % 4, b = i / (Ww * Hw * 4);
+    // all 36 taps are requested at once (a position outside the map reads the thread's own cell and is not added:
+    // with a branch per tap the loads went out one after the other, 36 trips to L2 in a row), then added in tap order
+    float uv[36];
+    bool in[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        const int c2 = k / 9, a = (k % 9) / 3, bb = k % 3;
+        const int rr = r + a - 1, cc = c + bb - 1;
+        in[k] = rr >= 0 && rr < Hw && cc >= 0 && cc < Ww;
+        uv[k] = u[((size_t)(b * 4 + c2) * Hw + (in[k] ? rr : r)) * Ww + (in[k] ? cc : c)];
+    }
     float acc = b4[o];
-    for (int c2 = 0; c2 < 4; ++c2)
-        for (int a = 0; a < 3; ++a) {
-            const int rr = r + a - 1;
-            if (rr < 0 || rr >= Hw) continue;
-            for (int bb = 0; bb < 3; ++bb) {
-                const int cc = c + bb - 1;
-                if (cc < 0 || cc >= Ww) continue;
-                acc = fmaf(w4[(o * 4 + c2) * 9 + a * 3 + bb], silu(u[((size_t)(b * 4 + c2) * Hw + rr) * Ww + cc]), acc);
-            }
-        }
+#pragma unroll
+    for (int k = 0; k < 36; ++k)
+        if (in[k]) acc = fmaf(w4[o * 36 + k], silu(uv[k]), acc);
     io<TO>::st(sd + i, acc);
 }
 
@@ -432,17 +436,21 @@ __global__ void sd_bwd_b_kernel(const TG *__restrict__ dsd, const float *__restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * 4 * Hw * Ww) return;
     const int c = i % Ww, r = (i / Ww) % Hw, c2 = (i / (Ww * Hw)) % 4, b = i / (Ww * Hw * 4);
+    float gv[36];      // all taps requested at once, as in sd_stage_b_kernel
+    bool in[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        const int o = k / 9, a = (k % 9) / 3, bb = k % 3;
+        const int rr = r - (a - 1), cc = c - (bb - 1);
+        in[k] = rr >= 0 && rr < Hw && cc >= 0 && cc < Ww;
+        gv[k] = io<TG>::ld(dsd + ((size_t)(b * 4 + o) * Hw + (in[k] ? rr : r)) * Ww + (in[k] ? cc : c));
+    }
     float acc = 0.f;
-    for (int o = 0; o < 4; ++o)
-        for (int a = 0; a < 3; ++a) {
-            const int rr = r - (a - 1);
-            if (rr < 0 || rr >= Hw) continue;
-            for (int bb = 0; bb < 3; ++bb) {
-                const int cc = c - (bb - 1);
-                if (cc < 0 || cc >= Ww) continue;
-                acc = fmaf(w4[(o * 4 + c2) * 9 + a * 3 + bb], io<TG>::ld(dsd + ((size_t)(b * 4 + o) * Hw + rr) * Ww + cc), acc);
-            }
-        }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        const int o = k / 9, t = k % 9;
+        if (in[k]) acc = fmaf(w4[(o * 4 + c2) * 9 + t], gv[k], acc);
+    }
     du[i] = acc * silu_grad(u[i]);
 }
 
