@@ -3,7 +3,7 @@
 Adam), once with every training-side fusion of the package on and once with them off (stock NCHW ends, separate
 residual / activation / norm passes), from the same initial weights and seeds: prints both loss curves and the largest
 relative difference.  A check that the fused training path optimises the same function, over more steps than the unit
-tests run.  usage: tools/soak_train.py [dswt|msft] [steps]"""
+tests run.  usage: [SOAK_FULL=1] tools/soak_train.py [dswt|msft] [steps]"""
 import copy
 import os
 import sys
@@ -18,7 +18,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 cfg = dict(models.DSWT_DEFAULT if which == "dswt" else models.MSFT_CONFIG_C)
-cfg.update(n_blocks=2, n_sub_blocks=2)
+if os.environ.get("SOAK_FULL") != "1":     # SOAK_FULL=1: the whole default network (8 x 3 blocks)
+    cfg.update(n_blocks=2, n_sub_blocks=2)
 net0 = (models.DSWTransformer(**cfg) if which == "dswt" else models.MSFTransformer(**cfg)).to(dev).train()
 with torch.no_grad():      # open the ReZero gates a little so that every branch takes part from the first step
     for n, p in net0.named_parameters():
@@ -51,4 +52,7 @@ a, b = curves[True], curves[False]
 print("%s, %d steps: fused %.4f -> %.4f, separate %.4f -> %.4f" % (which, steps, a[0], a[-1], b[0], b[-1]))
 print("loss every 10th step, fused   :", " ".join("%.4f" % v for v in a[::10]))
 print("loss every 10th step, separate:", " ".join("%.4f" % v for v in b[::10]))
+if os.environ.get("SOAK_ALL") == "1":
+    print("fused   :", " ".join("%.3f" % v for v in a))
+    print("separate:", " ".join("%.3f" % v for v in b))
 print("largest relative difference of the two curves: %.3e" % max(abs(u - v) / max(abs(v), 1e-9) for u, v in zip(a, b)))
