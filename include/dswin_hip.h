@@ -129,6 +129,16 @@ int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int afte
                          int B, int H, int W, int C, int w, int ld_after, void *y, int y_dtype,
                          void *stream);
 
+/* The same for a selection whose window count lives on the device (n_live, one int): when it holds 0 nothing is
+ * written - y stays as it was - and the pass over the map is saved; the caller's next kernel must then read x instead
+ * (dsw_dwconv3x3_fwd_src / dsw_dwconv3x3_residual_fwd_src with x_if_zero = x), which is what DS-MSA's early return
+ * (DSwinT_arch.py:291-292: no window passed, return x) amounts to without a host read. */
+int dsw_scatter_mean_fwd_live(const void *x, int x_dtype, const void *after, int after_dtype,
+                              const float *gates_delta, const float *scores_delta,
+                              const int *cellmap, const int *win_h1, const int *win_w1, int n_win,
+                              int B, int H, int W, int C, int w, int ld_after, void *y, int y_dtype,
+                              const int *n_live, void *stream);
+
 /* Backward of (4).  dy [B,H,W,C] -> dx [B,H,W,C] (identity path + the -roi_align path),
  * d_after [n_win, w*w, C], d_gates_delta / d_scores_delta [n_win] fp32.
  * partial: caller-provided scratch of 2*n_win*w floats (per window-row partial sums, reduced
@@ -267,6 +277,13 @@ int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const flo
 int dsw_dwconv3x3_residual_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
                                int C, const float *resid, const float *rscale, float *y, const int *identity_if_zero,
                                void *stream);
+/* Both with a second source for the identity case: when *identity_if_zero == 0 the kernels copy x_if_zero (same
+ * dtype and shape as x, 16-byte aligned) instead of x - x is then never read (see dsw_scatter_mean_fwd_live). */
+int dsw_dwconv3x3_fwd_src(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W, int C,
+                          void *y, int y_dtype, const int *identity_if_zero, const void *x_if_zero, void *stream);
+int dsw_dwconv3x3_residual_fwd_src(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
+                                   int C, const float *resid, const float *rscale, float *y, const int *identity_if_zero,
+                                   const void *x_if_zero, void *stream);
 int dsw_dwconv3x3_bwd_blocks(int B, int H, int W);
 int dsw_dwconv3x3_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype, const float *weight,
                       int B, int H, int W, int C, void *dx, int dx_dtype, float *d_weight,

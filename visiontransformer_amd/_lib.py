@@ -45,6 +45,9 @@ SIGNATURES = {
     "dsw_unshuffle_nhwc_ln_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dsw_shuffle_nchw_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dsw_unshuffle_nhwc_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dsw_scatter_mean_fwd_live": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P] + [_I] * 7 + [_P, _I, _P, _P]),
+    "dsw_dwconv3x3_fwd_src": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "dsw_dwconv3x3_residual_fwd_src": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "dsw_dwconv3x3_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "dsw_dwconv3x3_residual_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dsw_cast_rows": (_I, [_P, _I, ctypes.c_longlong, _P, _I, ctypes.c_longlong, ctypes.c_longlong,

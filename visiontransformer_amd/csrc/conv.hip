@@ -49,7 +49,8 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
                                                                    const float *__restrict__ bias, int H, int W, int C,
                                                                    int segs, TO *__restrict__ y, const int *__restrict__ identity_if_zero,
                                                                    const float *__restrict__ resid = nullptr,
-                                                                   const float *__restrict__ rscale = nullptr) {
+                                                                   const float *__restrict__ rscale = nullptr,
+                                                                   const TI *__restrict__ x_if_zero = nullptr) {
     // identity_if_zero: a device counter; when it holds 0 the kernel copies its input instead of convolving
     // (DS-MSA returns its input untouched when no window passed the gate, DSwinT_arch.py:291-292, and this
     // lets a caller that never reads the count on the host keep that behaviour)
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_stream_kernel(const TI *__r
     }
     const float4 bq = (bias != nullptr && !FLIP) ? *reinterpret_cast<const float4 *>(bias + c) : f4zero();
     const size_t rs = (size_t)W * C;
-    const TI *src = x + (size_t)b * H * rs + (size_t)i * 4;
+    // x_if_zero: what the identity copies when the counter holds 0 (the producer of x skipped its pass in that case)
+    const TI *src = (ident && x_if_zero != nullptr ? x_if_zero : x) + (size_t)b * H * rs + (size_t)i * 4;
     TO *dst = y + (size_t)b * H * rs + (size_t)i * 4;
     const bool has_l = xx > 0, has_r = xx < W - 1;
     const int h0 = hb * CW_ROWS, h1 = min(h0 + CW_ROWS, H);
@@ -774,34 +776,62 @@ __global__ __launch_bounds__(256) void sd_gather_bwd_kernel(const float *__restr
 
 using namespace dsw;
 
-extern "C" int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
-                                 int C, void *y, int y_dtype, const int *identity_if_zero, void *stream) {
+static int dwconv3x3_fwd_impl(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W, int C, void *y,
+                              int y_dtype, const int *identity_if_zero, const void *x_if_zero, void *stream) {
     int rc = check_conv("dsw_dwconv3x3_fwd", B, H, W, C);
     if (rc) return rc;
     DSW_REQUIRE(x && weight && y, "dsw_dwconv3x3_fwd: null pointer");
+    if (x_if_zero != nullptr && (identity_if_zero == nullptr || ((uintptr_t)x_if_zero & 15)))
+        return fail(DSW_EINVAL, "dsw_dwconv3x3_fwd_src: x_if_zero needs the counter and a 16-byte aligned base");
     if ((rc = check_conv_params("dsw_dwconv3x3_fwd", weight, bias))) return rc;
     const int segs = walk_segs(W, C);
     DSW_DISPATCH_DTYPE(x_dtype, TI, DSW_DISPATCH_DTYPE(y_dtype, TO, {
         hipLaunchKernelGGL((dwconv_stream_kernel<TI, TO, false>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), 0,
-                           as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, (TO *)y, identity_if_zero);
+                           as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, (TO *)y, identity_if_zero,
+                           (const float *)nullptr, (const float *)nullptr, (const TI *)x_if_zero);
     }));
     return check_launch("dwconv_stream_kernel");
+}
+
+static int dwconv3x3_residual_fwd_impl(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W, int C,
+                                       const float *resid, const float *rscale, float *y, const int *identity_if_zero,
+                                       const void *x_if_zero, void *stream) {
+    int rc = check_conv("dsw_dwconv3x3_residual_fwd", B, H, W, C);
+    if (rc) return rc;
+    DSW_REQUIRE(x && weight && y && resid && rscale, "dsw_dwconv3x3_residual_fwd: null pointer");
+    if (((uintptr_t)resid | (uintptr_t)y) & 15) return fail(DSW_EUNSUPPORTED, "dsw_dwconv3x3_residual_fwd: resid and y must be 16-byte aligned");
+    if (x_if_zero != nullptr && (identity_if_zero == nullptr || ((uintptr_t)x_if_zero & 15)))
+        return fail(DSW_EINVAL, "dsw_dwconv3x3_residual_fwd_src: x_if_zero needs the counter and a 16-byte aligned base");
+    if ((rc = check_conv_params("dsw_dwconv3x3_residual_fwd", weight, bias))) return rc;
+    const int segs = walk_segs(W, C);
+    DSW_DISPATCH_DTYPE(x_dtype, TI, {
+        hipLaunchKernelGGL((dwconv_stream_kernel<TI, float, false, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), 0,
+                           as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, y, identity_if_zero, resid, rscale,
+                           (const TI *)x_if_zero);
+    });
+    return check_launch("dwconv_stream_kernel<residual>");
+}
+
+extern "C" int dsw_dwconv3x3_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
+                                 int C, void *y, int y_dtype, const int *identity_if_zero, void *stream) {
+    return dwconv3x3_fwd_impl(x, x_dtype, weight, bias, B, H, W, C, y, y_dtype, identity_if_zero, nullptr, stream);
+}
+
+extern "C" int dsw_dwconv3x3_fwd_src(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W, int C,
+                                     void *y, int y_dtype, const int *identity_if_zero, const void *x_if_zero, void *stream) {
+    return dwconv3x3_fwd_impl(x, x_dtype, weight, bias, B, H, W, C, y, y_dtype, identity_if_zero, x_if_zero, stream);
 }
 
 extern "C" int dsw_dwconv3x3_residual_fwd(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
                                           int C, const float *resid, const float *rscale, float *y, const int *identity_if_zero,
                                           void *stream) {
-    int rc = check_conv("dsw_dwconv3x3_residual_fwd", B, H, W, C);
-    if (rc) return rc;
-    DSW_REQUIRE(x && weight && y && resid && rscale, "dsw_dwconv3x3_residual_fwd: null pointer");
-    if (((uintptr_t)resid | (uintptr_t)y) & 15) return fail(DSW_EUNSUPPORTED, "dsw_dwconv3x3_residual_fwd: resid and y must be 16-byte aligned");
-    if ((rc = check_conv_params("dsw_dwconv3x3_residual_fwd", weight, bias))) return rc;
-    const int segs = walk_segs(W, C);
-    DSW_DISPATCH_DTYPE(x_dtype, TI, {
-        hipLaunchKernelGGL((dwconv_stream_kernel<TI, float, false, true>), dim3(walk_blocks(B, H, segs)), dim3(CV_THREADS), 0,
-                           as_stream(stream), (const TI *)x, weight, bias, H, W, C, segs, y, identity_if_zero, resid, rscale);
-    });
-    return check_launch("dwconv_stream_kernel<residual>");
+    return dwconv3x3_residual_fwd_impl(x, x_dtype, weight, bias, B, H, W, C, resid, rscale, y, identity_if_zero, nullptr, stream);
+}
+
+extern "C" int dsw_dwconv3x3_residual_fwd_src(const void *x, int x_dtype, const float *weight, const float *bias, int B, int H, int W,
+                                              int C, const float *resid, const float *rscale, float *y, const int *identity_if_zero,
+                                              const void *x_if_zero, void *stream) {
+    return dwconv3x3_residual_fwd_impl(x, x_dtype, weight, bias, B, H, W, C, resid, rscale, y, identity_if_zero, x_if_zero, stream);
 }
 
 extern "C" int dsw_dwconv3x3_bwd_blocks(int B, int H, int W) {

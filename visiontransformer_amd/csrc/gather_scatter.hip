@@ -248,7 +248,11 @@ template <typename TX, typename TA, typename TY>
 __global__ __launch_bounds__(GS_THREADS) void scatter_fwd_kernel(
     const TX *__restrict__ x, const TA *__restrict__ after, const float *__restrict__ gates_delta,
     const float *__restrict__ scores_delta, const int *__restrict__ cellmap, const int *__restrict__ win_h1,
-    const int *__restrict__ win_w1, int H, int W, int C, int w, int lda, int tiles_per_row, TY *__restrict__ yout) {
+    const int *__restrict__ win_w1, int H, int W, int C, int w, int lda, int tiles_per_row, TY *__restrict__ yout,
+    const int *__restrict__ skip_if_zero) {
+    // skip_if_zero: a device counter (the number of windows that passed); when it holds 0 nothing is written - the
+    // caller's next kernel reads x itself in that case (dsw_dwconv3x3_fwd_src), and the pass over the map is saved
+    if (skip_if_zero != nullptr && *skip_if_zero == 0) return;
     __shared__ Cover cov[TILE_PIX];
     const int Hw = H / w, Ww = W / w;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD takes whole images: vertical neighbours share its L2
@@ -513,11 +517,10 @@ extern "C" int dsw_gather_bwd(const void *dout, int dout_dtype, const int *cellm
     return check_launch("gather_bwd_kernel");
 }
 
-extern "C" int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int after_dtype,
-                                    const float *gates_delta, const float *scores_delta,
-                                    const int *cellmap, const int *win_h1, const int *win_w1, int n_win,
-                                    int B, int H, int W, int C, int w, int ld_after, void *y, int y_dtype,
-                                    void *stream) {
+static int scatter_mean_fwd_impl(const void *x, int x_dtype, const void *after, int after_dtype, const float *gates_delta,
+                                 const float *scores_delta, const int *cellmap, const int *win_h1, const int *win_w1, int n_win,
+                                 int B, int H, int W, int C, int w, int ld_after, void *y, int y_dtype, const int *skip_if_zero,
+                                 void *stream) {
     int rc = check_geometry("dsw_scatter_mean_fwd", B, H, W, C, w);
     if (rc) return rc;
     if (!ld_after) ld_after = C;
@@ -529,9 +532,26 @@ extern "C" int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *afte
     DSW_DISPATCH_DTYPE(x_dtype, TX, DSW_DISPATCH_DTYPE(after_dtype, TA, DSW_DISPATCH_DTYPE(y_dtype, TY, {
         hipLaunchKernelGGL((scatter_fwd_kernel<TX, TA, TY>), dim3(B * H * tiles), dim3(GS_THREADS), 0,
                            as_stream(stream), (const TX *)x, (const TA *)after, gates_delta, scores_delta, cellmap,
-                           win_h1, win_w1, H, W, C, w, ld_after, tiles, (TY *)y);
+                           win_h1, win_w1, H, W, C, w, ld_after, tiles, (TY *)y, skip_if_zero);
     })));
     return check_launch("scatter_fwd_kernel");
+}
+
+extern "C" int dsw_scatter_mean_fwd(const void *x, int x_dtype, const void *after, int after_dtype,
+                                    const float *gates_delta, const float *scores_delta,
+                                    const int *cellmap, const int *win_h1, const int *win_w1, int n_win,
+                                    int B, int H, int W, int C, int w, int ld_after, void *y, int y_dtype,
+                                    void *stream) {
+    return scatter_mean_fwd_impl(x, x_dtype, after, after_dtype, gates_delta, scores_delta, cellmap, win_h1, win_w1, n_win, B, H, W, C, w,
+                                 ld_after, y, y_dtype, nullptr, stream);
+}
+
+extern "C" int dsw_scatter_mean_fwd_live(const void *x, int x_dtype, const void *after, int after_dtype, const float *gates_delta,
+                                         const float *scores_delta, const int *cellmap, const int *win_h1, const int *win_w1,
+                                         int n_win, int B, int H, int W, int C, int w, int ld_after, void *y, int y_dtype,
+                                         const int *n_live, void *stream) {
+    return scatter_mean_fwd_impl(x, x_dtype, after, after_dtype, gates_delta, scores_delta, cellmap, win_h1, win_w1, n_win, B, H, W, C, w,
+                                 ld_after, y, y_dtype, n_live, stream);
 }
 
 static int scatter_mean_bwd_impl(const void *dy, int dy_dtype, const void *x, int x_dtype,

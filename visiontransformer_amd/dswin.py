@@ -294,22 +294,23 @@ class DeformableSparseWindowAttention(WindowedAttention):
                 qkv = K.linear(before, self.in_proj, pad_out=True, live=live)
                 z = K.window_attention(qkv, self.pe.table(), w, self.num_heads, QKV_CHUNKED, pad_out=True, n_live=sel.n_dev)
             after = K.linear(z, self.out_proj, pad_out=True, live=live)
-            y = K.scatter_mean_residual(x, after, sel, w, sink=sink)
-            # no window passed (DSwinT_arch.py:291-292: return x): the last kernel copies instead of convolving
+            # no window passed (DSwinT_arch.py:291-292: return x): the scatter leaves its map unwritten and the last
+            # kernel copies x instead of convolving
+            y = K.scatter_mean_residual(x, after, sel, w, sink=sink, skip_if_dead=True)
             if residual is not None and torch.is_grad_enabled():
                 if residual[1] is None or isinstance(residual[1], (int, float)):   # a plain residual (forward() checked: 1)
                     # the stream's gradient meets the three readers of x in the sink when the stream is x
                     pend = sink.pending if (sink is not None and residual[0] is x_in) else None
                     out = K.dwconv3x3_plus_residual_nhwc(y, self.out_conv.weight, self.out_conv.bias, residual[0], pend,
-                                                         identity_if_zero=sel.n_dev)
+                                                         identity_if_zero=sel.n_dev, identity_src=x)
                     if out is not None:
                         return out, True
             elif residual is not None:
                 out = K.dwconv3x3_residual_nhwc(y, self.out_conv.weight, self.out_conv.bias, residual[0], residual[1],
-                                                identity_if_zero=sel.n_dev)
+                                                identity_if_zero=sel.n_dev, identity_src=x)
                 if out is not None:
                     return out, True
-            return K.dwconv3x3_nhwc(y, self.out_conv.weight, self.out_conv.bias, out_dtype=act, identity_if_zero=sel.n_dev)
+            return K.dwconv3x3_nhwc(y, self.out_conv.weight, self.out_conv.bias, out_dtype=act, identity_if_zero=sel.n_dev, identity_src=x)
         sel = K.select_windows(sd, None, noise, self.temperature, k, w, H, W)  # sigmoids taken in the kernels
         self.last_selection = sel.detached()
         if sel.n == 0:  # DSwinT_arch.py:291-292

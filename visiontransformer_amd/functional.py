@@ -393,7 +393,9 @@ def gather_windows(x, sel, w, out_dtype=None, sink=None, pad_out=False):
 
 class _ScatterMeanFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, w, sink, n_live=None):
+    def forward(ctx, x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, w, sink, n_live=None, skip_if_dead=False):
+        # skip_if_dead (with n_live): when no window passed, the result is not written at all - the caller's next kernel
+        # reads x itself in that case (dwconv3x3_*(..., identity_src=x)) and the pass over the map is saved
         _lib.require_cuda(x, after)
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -403,9 +405,14 @@ class _ScatterMeanFn(torch.autograd.Function):
         scores_delta = scores_delta.to(torch.float32).contiguous()
         n = win_b.numel()
         y = torch.empty_like(x)
-        call("dsw_scatter_mean_fwd", ptr(x), dtype_code(x.dtype), _dptr(after), dtype_code(after.dtype),
-             ptr(gates_delta), ptr(scores_delta), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
-             B, H, W, C, w, lda, ptr(y), dtype_code(y.dtype), stream(x.device))
+        if skip_if_dead and n_live is not None:
+            call("dsw_scatter_mean_fwd_live", ptr(x), dtype_code(x.dtype), _dptr(after), dtype_code(after.dtype),
+                 ptr(gates_delta), ptr(scores_delta), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
+                 B, H, W, C, w, lda, ptr(y), dtype_code(y.dtype), ptr(n_live), stream(x.device))
+        else:
+            call("dsw_scatter_mean_fwd", ptr(x), dtype_code(x.dtype), _dptr(after), dtype_code(after.dtype),
+                 ptr(gates_delta), ptr(scores_delta), ptr(cellmap), ptr(win_h1), ptr(win_w1), n,
+                 B, H, W, C, w, lda, ptr(y), dtype_code(y.dtype), stream(x.device))
         ctx.save_for_backward(x, after, gates_delta, scores_delta, cellmap, win_b, win_h1, win_w1, n_live)
         ctx.w = w
         ctx.sink = sink
@@ -443,14 +450,27 @@ class _ScatterMeanFn(torch.autograd.Function):
                  ptr(win_b), ptr(win_h1), ptr(win_w1), n, B, H, W, C, w, lda, ptr(dx), dtype_code(dx.dtype), acc,
                  ptr(d_after), dtype_code(d_after.dtype), lda, ptr(dg[0]), ptr(dg[1]), ptr(partial),
                  None if n_live is None else ptr(n_live), stream(dev))
-        return _dx_deliver(sink, dx), d_after[:, :C].view(after_shape), dg[0], dg[1], None, None, None, None, None, None, None
+        return _dx_deliver(sink, dx), d_after[:, :C].view(after_shape), dg[0], dg[1], None, None, None, None, None, None, None, None
 
 
-def scatter_mean_residual(x, after, sel, w, sink=None):
+SKIP_DEAD_SCATTER = True   # False: the static DS-MSA path writes the scattered map even when no window passed
+
+
+def scatter_mean_residual(x, after, sel, w, sink=None, skip_if_dead=False):
     """x + mean over covering windows of (after - roi_align(x)) * gates * scores
-    (DSwinT_arch.py:308-315), NHWC in and out.  `sink`: see GradSink."""
+    (DSwinT_arch.py:308-315), NHWC in and out.  `sink`: see GradSink.  skip_if_dead (selections with a device-side
+    count): the result is left unwritten when no window passed; only for a caller whose next kernel then reads x
+    instead (identity_src of the dwconv3x3 functions)."""
     return _run(_ScatterMeanFn, x, after, sel.gates_delta, sel.scores_delta, sel.cellmap, sel.win_b,
-                                sel.win_h1, sel.win_w1, int(w), sink, sel.n_dev)
+                                sel.win_h1, sel.win_w1, int(w), sink, sel.n_dev, bool(skip_if_dead and SKIP_DEAD_SCATTER))
+
+
+def _identity_src(x, src, ident):
+    """pointer of the tensor the depthwise kernels copy when the counter holds 0, or None"""
+    if src is None or ident is None:
+        return None
+    assert src.shape == x.shape and src.dtype == x.dtype and src.is_contiguous() and src.data_ptr() % 16 == 0
+    return ptr(src)
 
 
 def _row_view(t, n):
@@ -721,15 +741,21 @@ def unshuffle_nhwc(x, scale=1):
 # ---------------------------------------------------------------------------------------------
 class _DWConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, out_dtype, identity_if_zero=None):
+    def forward(ctx, x, weight, bias, out_dtype, identity_if_zero=None, identity_src=None):
+        # identity_src: the tensor to copy when the counter holds 0, in place of x (whose producer left it unwritten then)
         _lib.require_cuda(x)
         x = x.contiguous()
         B, H, W, C = x.shape
         w32 = weight.detach().to(torch.float32).reshape(C, 9).contiguous()
         b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
         y = torch.empty(B, H, W, C, dtype=out_dtype, device=x.device)
-        call("dsw_dwconv3x3_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(y),
-             dtype_code(out_dtype), None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
+        src = _identity_src(x, identity_src, identity_if_zero)
+        if src is not None:
+            call("dsw_dwconv3x3_fwd_src", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(y),
+                 dtype_code(out_dtype), ptr(identity_if_zero), src, stream(x.device))
+        else:
+            call("dsw_dwconv3x3_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(y),
+                 dtype_code(out_dtype), None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
         ctx.save_for_backward(x, w32, identity_if_zero)
         ctx.meta = (weight.shape, weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -748,14 +774,15 @@ class _DWConvFn(torch.autograd.Function):
         partial = torch.empty((nblk + 1) * C * 10, dtype=torch.float32, device=dev)
         call("dsw_dwconv3x3_bwd", ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype), ptr(w32), B, H, W, C,
              ptr(dx), dtype_code(dx.dtype), ptr(dw), ptr(db), ptr(partial), None if ident is None else ptr(ident), stream(dev))
-        return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), None, None
+        return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), None, None, None
 
 
-def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None, identity_if_zero=None):
+def dwconv3x3_nhwc(x, weight, bias=None, out_dtype=None, identity_if_zero=None, identity_src=None):
     """Depthwise 3x3 conv, stride 1, zero padding 1, on an NHWC tensor (out_conv of DS-MSA,
     DSwinT_arch.py:198, :317).  weight [C,1,3,3].  identity_if_zero: an int32 device counter; the result
-    is x itself (cast) when it holds 0, and the backward then passes the gradient through to x alone."""
-    return _run(_DWConvFn, x, weight, bias, out_dtype or x.dtype, identity_if_zero)
+    is x itself (cast) when it holds 0, and the backward then passes the gradient through to x alone.
+    identity_src: the tensor that is copied in that case instead of x (see scatter_mean_residual's skip_if_dead)."""
+    return _run(_DWConvFn, x, weight, bias, out_dtype or x.dtype, identity_if_zero, identity_src)
 
 
 class _DWConvResidualFn(torch.autograd.Function):
@@ -765,7 +792,7 @@ class _DWConvResidualFn(torch.autograd.Function):
     autograd otherwise."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, pending, identity_if_zero=None):
+    def forward(ctx, x, weight, bias, resid, pending, identity_if_zero=None, identity_src=None):
         _lib.require_cuda(x, resid)
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -773,8 +800,13 @@ class _DWConvResidualFn(torch.autograd.Function):
         b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
         one = torch.ones(1, dtype=torch.float32, device=x.device)
         y = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
-        call("dsw_dwconv3x3_residual_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(resid), ptr(one), ptr(y),
-             None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
+        src = _identity_src(x, identity_src, identity_if_zero)
+        if src is not None:
+            call("dsw_dwconv3x3_residual_fwd_src", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(resid), ptr(one), ptr(y),
+                 ptr(identity_if_zero), src, stream(x.device))
+        else:
+            call("dsw_dwconv3x3_residual_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(resid), ptr(one), ptr(y),
+                 None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
         ctx.save_for_backward(x, w32, identity_if_zero)
         ctx.meta = (weight.shape, weight.dtype, None if bias is None else bias.dtype)
         ctx.pending = pending
@@ -800,19 +832,19 @@ class _DWConvResidualFn(torch.autograd.Function):
                 ctx.pending.put(dy)
             else:
                 d_resid = dy
-        return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), d_resid, None, None
+        return dx, dw.view(wshape).to(wdt), (None if bdt is None else db.to(bdt)), d_resid, None, None, None
 
 
-def dwconv3x3_plus_residual_nhwc(x, weight, bias, resid, pending=None, identity_if_zero=None):
+def dwconv3x3_plus_residual_nhwc(x, weight, bias, resid, pending=None, identity_if_zero=None, identity_src=None):
     """resid + dwconv3x3(x), fp32, with autograd (see _DWConvResidualFn); None when the call is not one the kernel
     takes - the caller then composes dwconv3x3_nhwc() and an addition."""
     if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and resid.is_cuda and resid.dtype == torch.float32
             and resid.is_contiguous() and resid.shape == x.shape and x.shape[-1] % 4 == 0 and resid.data_ptr() % 16 == 0):
         return None
-    return _run(_DWConvResidualFn, x, weight, bias, resid, pending, identity_if_zero)
+    return _run(_DWConvResidualFn, x, weight, bias, resid, pending, identity_if_zero, identity_src)
 
 
-def dwconv3x3_residual_nhwc(x, weight, bias, resid, r, identity_if_zero=None):
+def dwconv3x3_residual_nhwc(x, weight, bias, resid, r, identity_if_zero=None, identity_src=None):
     """resid + r * dwconv3x3(x) as fp32 in one kernel (dsw_dwconv3x3_residual_fwd): DS-MSA's closing convolution with
     the ReZero residual of the block around it (DSwinT_arch.py:317 with :356).  Without autograd only; returns None
     when the call is not one the kernel takes, and the caller then composes dwconv3x3_nhwc() and rezero_residual()."""
@@ -826,8 +858,13 @@ def dwconv3x3_residual_nhwc(x, weight, bias, resid, r, identity_if_zero=None):
     b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
     r32 = r.detach().float().reshape(1).contiguous()
     y = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
-    call("dsw_dwconv3x3_residual_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(resid), ptr(r32), ptr(y),
-         None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
+    src = _identity_src(x, identity_src, identity_if_zero)
+    if src is not None:
+        call("dsw_dwconv3x3_residual_fwd_src", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(resid), ptr(r32), ptr(y),
+             ptr(identity_if_zero), src, stream(x.device))
+    else:
+        call("dsw_dwconv3x3_residual_fwd", ptr(x), dtype_code(x.dtype), ptr(w32), ptr(b32), B, H, W, C, ptr(resid), ptr(r32), ptr(y),
+             None if identity_if_zero is None else ptr(identity_if_zero), stream(x.device))
     return y
 
 
