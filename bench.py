@@ -24,6 +24,7 @@ The JSON line also carries
                  cores on a bounded sample of the same workload (N = 1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -101,6 +102,7 @@ def kernel_rooflines(device, iters=20, warm=3, k=4, attention=True):
     x = torch.randn(B_PER_GPU, HW, HW, C, device=device)
     _window_rooflines(device, iters, warm, k, x, out)
     _projection_rooflines(device, iters, warm, x, out)
+    _mlp_roofline(device, iters, warm, x, out)
     for v in out.values():
         if "achieved" in v:
             v["frac"] = v["achieved"] / v["peak"]
@@ -264,6 +266,31 @@ def _projection_rooflines(device, iters, warm, x, out):
                               ("linear_qkv_dgrad", t_d, by_d, "bf16 in, fp32 out"),
                               ("linear_qkv_wgrad", t_w, by_w, "two kernels: split-K product, fixed-order sum")):
         out[name] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t * 1e6, algorithmic=by, note=note)
+
+
+def _mlp_roofline(device, iters, warm, x, out):
+    """The gated MLP of a DSWT block with its norm and its ReZero residual as one kernel (inference; the whole branch of
+    DSwinT_arch.py:357) through the C ABI, at the bench's token count: x read once, y written once."""
+    from visiontransformer_amd import functional as K
+    from visiontransformer_amd._lib import call, ptr, stream
+    M, Hd = x.numel() // C, 2 * C
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mk = lambda *shape: (torch.randn(*shape, generator=g) * 0.05).to(device)
+    ops = K.mlp_gated_operands(mk(Hd, C), mk(Hd, C), mk(Hd), mk(Hd), mk(C, Hd), mk(C), 1.0 + mk(C))
+    w1c, b1c, w2c, b2, nch = ops
+    x2 = x.view(M, C)
+    y = torch.empty_like(x2)
+    r = torch.full((1,), 0.2, device=device)
+    eps = ctypes.c_float(1e-6)
+    run = lambda: call("dsw_mlp_gated_residual", ptr(x2), C, M, C, eps, ptr(w1c), ptr(b1c), ptr(w2c), ptr(b2), nch, ptr(r), ptr(y), C,
+                       stream(device))
+    t = time_calls(run, iters, warm)
+    by = M * C * 8
+    fl = 2.0 * M * (192 * 2 * 32 * nch + 32 * nch * 192)      # the MFMA work as issued: K and C padded to 192, hidden to 32 * chunks
+    out["mlp_gated_residual"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", us=t * 1e6, algorithmic=by,
+                                     flops=fl, mfma_frac=fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                     note="inference: rms norm + fc1 (gate, content) + gated SiLU + fc2 + ReZero residual in one kernel; "
+                                          "the two-kernel form moves 2.6 x the bytes")
 
 
 def pmc_traffic(kernel):
